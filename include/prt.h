@@ -1,0 +1,201 @@
+/*
+ * prt.h -- C-ABI of libprt_hip.so, the MI355X (gfx950) ray-propagation engine that sits
+ * under PyRayT's RayTracer.trace() hot path.
+ *
+ * Every entry point is plain C: pointers, sizes, ints.  No torch / C++ types cross this
+ * boundary.  Device pointers are raw HIP device addresses (e.g. torch.Tensor.data_ptr()).
+ * Streams are passed as void* (a hipStream_t; NULL = the default stream).
+ *
+ * Each function cites the reference interface (path:line under the PyRayT tree) it replaces.
+ * The reference has no FFI layer of its own (it is pure Python + numpy), so the seam is the
+ * duck-typed Python interface of pyrayt/_pyrayt.py, tinygfx/g3d/world_objects.py,
+ * tinygfx/g3d/csg.py and pyrayt/materials.py.  INTEGRATION.md shows the ctypes stubs a
+ * maintainer would add on the reference side.
+ *
+ * Ownership: the caller owns every buffer.  The library copies the scene description at
+ * prt_scene_create() and never retains caller pointers beyond a call (stream-ordered work
+ * excepted: buffers must stay alive until the stream has drained).
+ * Errors: 0 = OK, negative = error; prt_last_error() returns a thread-local message.
+ */
+#ifndef PRT_H
+#define PRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRT_VERSION 100 /* 0.1.0 */
+
+/* ---- ray buffer layout: pyrayt/_pyrayt.py:13-144 (RaySet) -------------------------------
+ * A ray set is a row-major (13, n) float64 matrix with leading dimension `ld` (elements
+ * between consecutive rows, ld >= n): one contiguous row per field, i.e. SoA. */
+enum {
+  PRT_ROW_OX = 0, PRT_ROW_OY = 1, PRT_ROW_OZ = 2, PRT_ROW_OW = 3,
+  PRT_ROW_DX = 4, PRT_ROW_DY = 5, PRT_ROW_DZ = 6, PRT_ROW_DW = 7,
+  PRT_ROW_GENERATION = 8, PRT_ROW_INTENSITY = 9, PRT_ROW_WAVELENGTH = 10,
+  PRT_ROW_INDEX = 11, PRT_ROW_ID = 12,
+  PRT_RAY_ROWS = 13
+};
+
+/* ---- result rows: pyrayt/_pyrayt.py:154-165 (_RayTraceDataframe.df_columns) --------------
+ * A record block is a row-major (15, cap) float64 matrix (one contiguous row per DataFrame
+ * column) with leading dimension ld_rows. */
+enum {
+  PRT_COL_GENERATION = 0, PRT_COL_INTENSITY = 1, PRT_COL_WAVELENGTH = 2, PRT_COL_INDEX = 3,
+  PRT_COL_ID = 4, PRT_COL_SURFACE = 5, PRT_COL_X0 = 6, PRT_COL_Y0 = 7, PRT_COL_Z0 = 8,
+  PRT_COL_X1 = 9, PRT_COL_Y1 = 10, PRT_COL_Z1 = 11, PRT_COL_XTILT = 12, PRT_COL_YTILT = 13,
+  PRT_COL_ZTILT = 14,
+  PRT_RECORD_COLS = 15
+};
+
+/* ---- scene snapshot ---------------------------------------------------------------------- */
+
+/* primitive kinds: tinygfx/g3d/primitives.py (Sphere :220, Cylinder :621, Plane :422,
+ * Cube :501, Paraboloid :299) */
+enum {
+  PRT_PRIM_SPHERE = 0,     /* params: radius */
+  PRT_PRIM_CYLINDER = 1,   /* params: radius, h_min, h_max */
+  PRT_PRIM_PLANE = 2,      /* params: width (x), length (y) */
+  PRT_PRIM_CUBE = 3,       /* params: xmin, xmax, ymin, ymax, zmin, zmax */
+  PRT_PRIM_PARABOLOID = 4  /* params: focus, height */
+};
+
+/* material kinds: pyrayt/materials.py (:41 absorber, :53 mirror, :102 BasicRefractor,
+ * :121 SellmeierRefractor).  PRT_MAT_NONE is a surface whose material has no trace()
+ * (the reference's default GoochMaterial, world_objects.py:341): hitting it is an error. */
+enum {
+  PRT_MAT_NONE = 0,
+  PRT_MAT_ABSORBER = 1,
+  PRT_MAT_MIRROR = 2,
+  PRT_MAT_CONST_INDEX = 3, /* coef[0] = n */
+  PRT_MAT_SELLMEIER = 4    /* coef = b1, b2, b3, c1, c2, c3 (wavelength in um) */
+};
+
+/* CSG operations: tinygfx/g3d/csg.py:7-10 (Operation) */
+enum { PRT_NODE_LEAF = 0, PRT_NODE_UNION = 1, PRT_NODE_INTERSECT = 2, PRT_NODE_DIFFERENCE = 3 };
+
+/* one TracerSurface (world_objects.py:338-422): primitive + cached world->object matrix */
+typedef struct prt_prim {
+  int32_t type;          /* PRT_PRIM_* */
+  int32_t material;      /* index into the material table */
+  int32_t normal_scale;  /* +1 / -1: Intersectable._normal_scale (world_objects.py:305,319) */
+  int32_t reserved;
+  int64_t surface_id;    /* CountedObject id (world_objects.py:26-40); written to `surface` */
+  double params[6];
+  double minv[16];       /* row-major _object_coordinate_transform (world_objects.py:122) */
+} prt_prim;
+
+/* one node of a component tree: leaf = TracerSurface, inner = CSGSurface (csg.py:64-91) */
+typedef struct prt_node {
+  int32_t op;            /* PRT_NODE_* */
+  int32_t left, right;   /* child node indices (inner nodes) */
+  int32_t prim;          /* primitive index (leaf nodes) */
+  double aabb[6];        /* inner nodes: world-space CSGSurface._aobb axis spans
+                            xmin,xmax,ymin,ymax,zmin,zmax (csg.py:93-116) */
+} prt_node;
+
+typedef struct prt_material {
+  int32_t kind;          /* PRT_MAT_* */
+  int32_t reserved;
+  double coef[6];
+} prt_material;
+
+typedef struct prt_scene prt_scene; /* opaque */
+
+/* ---- library ------------------------------------------------------------------------------ */
+
+int prt_version(void);
+const char* prt_last_error(void);
+/* number of visible HIP devices (0 if none / no driver) */
+int prt_device_count(void);
+
+/* Build a scene from a snapshot.  roots[] lists the node index of every top-level component
+ * in RayTracer._components order (pyrayt/_pyrayt.py:229-239); the surface look-up table of
+ * _pyrayt.py:257-260 is the depth-first leaf order of those roots. */
+int prt_scene_create(const prt_prim* prims, int n_prims, const prt_node* nodes, int n_nodes,
+                     const int32_t* roots, int n_roots, const prt_material* mats, int n_mats,
+                     prt_scene** out);
+void prt_scene_destroy(prt_scene* scene);
+/* rows of the hit list component `root` returns from intersect(): 2 * (#leaves under it) */
+int prt_scene_component_rows(const prt_scene* scene, int root);
+
+/* ---- per-state entry points (drop-ins for the reference's Python methods) ------------------ */
+
+/* component.intersect(rays) -> (hits (m,n) sorted ascending, inf = miss ; surface ids (m,n)):
+ * TracerSurface.intersect world_objects.py:360-383, CSGSurface.intersect csg.py:118-160.
+ * rays: device (8+, n) matrix, rows 0-7 used.  hits_out / ids_out: device (m, n) with leading
+ * dimension ld_out, m = prt_scene_component_rows().  ids are defined where the hit is finite
+ * and -1 elsewhere. */
+int prt_intersect(prt_scene* scene, int device, int root, const double* rays, int64_t n,
+                  int64_t ld, double* hits_out, int64_t* ids_out, int64_t ld_out, void* stream);
+
+/* RayTracer._st_propagate (pyrayt/_pyrayt.py:370-392): nearest positive hit over all
+ * components.  t_out (n) float64 (inf = no hit), surf_out (n) int64 surface id (-1 = none). */
+int prt_propagate(prt_scene* scene, int device, const double* rays, int64_t n, int64_t ld,
+                  double* t_out, int64_t* surf_out, void* stream);
+
+/* TracerSurface.get_world_normals (world_objects.py:401-418) for primitive `prim`:
+ * points (4,k) -> normals (4,k), both device, row-major with leading dimension ld. */
+int prt_world_normals(prt_scene* scene, int device, int prim, const double* points, int64_t k,
+                      int64_t ld, double* normals_out, void* stream);
+
+/* surface.material.trace(surface, ray_set) (pyrayt/materials.py:47-50, :58-62, :70-75):
+ * shades, in place, every ray of the (13,k) set as having hit primitive `prim` at its current
+ * origin. */
+int prt_material_trace(prt_scene* scene, int device, int prim, double* rays, int64_t k,
+                       int64_t ld, void* stream);
+
+/* RayTracer._st_interact (pyrayt/_pyrayt.py:394-452) + _RayTraceDataframe.insert (:168-186):
+ * advance hit rays to their hit point, shade, drop dead rays (order preserving), append one
+ * record row per live ray, set generation+1, and (unless generation+1 == generation_limit)
+ * re-launch by ray_offset along the new direction.
+ *   rays_in (13,n) ld_in ; t/surf from prt_propagate ; rays_out (13, >= n) ld_out
+ *   rows_out (15, >= n) ld_rows ; n_live_out: device int64[1]
+ *   workspace: device scratch of prt_interact_workspace_bytes(n) bytes
+ * If every ray is dead nothing is written and *n_live_out = 0 (_pyrayt.py:424-425). */
+int64_t prt_interact_workspace_bytes(int64_t n);
+int prt_interact(prt_scene* scene, int device, const double* rays_in, int64_t n, int64_t ld_in,
+                 const double* t, const int64_t* surf, double* rays_out, int64_t ld_out,
+                 int generation, int generation_limit, double ray_offset, double* rows_out,
+                 int64_t ld_rows, int64_t* n_live_out, void* workspace, void* stream);
+
+/* ---- the whole hot loop -------------------------------------------------------------------
+ * RayTracer.trace() minus source generation and DataFrame construction
+ * (pyrayt/_pyrayt.py:329-339 driving :370-452).  Runs every generation on the device.
+ *   rays (13,n) ld: initial ray set (read only)
+ *   rows_out (15, rows_cap) ld_rows = rows_cap: generation-major record rows
+ *   rows_per_generation: HOST int64[generation_limit], rows recorded by each generation
+ *   workspace: device scratch of prt_trace_workspace_bytes(n) bytes
+ *   flags: PRT_TRACE_* bits
+ * Returns the total number of rows (>= 0) or a negative error.  PRT_ERR_ROWS_CAP if rows_cap
+ * is too small (n * generation_limit rows always suffices).  Synchronises the stream. */
+#define PRT_TRACE_KEEP_ABSORBED 1 /* carry zero-direction (absorbed) rays into the next
+                                     generation exactly like _pyrayt.py:415-428 (Q3) instead of
+                                     dropping them when they are absorbed; the rows are
+                                     identical either way */
+#define PRT_TRACE_UNFUSED 2       /* run the generation as propagate + interact kernels */
+int64_t prt_trace_workspace_bytes(int64_t n);
+int64_t prt_trace(prt_scene* scene, int device, const double* rays, int64_t n, int64_t ld,
+                  int generation_limit, double ray_offset, double* rows_out, int64_t rows_cap,
+                  int64_t* rows_per_generation, void* workspace, int flags, void* stream);
+
+/* statistics of the last prt_trace on this scene (for bench.py's roofline):
+ * out[0] = generations launched, out[1] = sum over generations of rays alive at entry,
+ * out[2] = GPU milliseconds spent in generation kernels (hipEvent, on the trace stream),
+ * out[3] = number of generation-kernel launches. */
+int prt_trace_stats(const prt_scene* scene, double* out4);
+
+/* error codes */
+#define PRT_OK 0
+#define PRT_ERR_ARG (-1)
+#define PRT_ERR_HIP (-2)
+#define PRT_ERR_SCENE (-3)
+#define PRT_ERR_ROWS_CAP (-4)
+#define PRT_ERR_UNTRACABLE (-5) /* a ray hit a PRT_MAT_NONE surface (AttributeError upstream) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRT_H */

@@ -1,0 +1,307 @@
+"""ctypes binding of ``libprt_hip.so`` (C-ABI: ``include/prt.h``) + torch device buffers.
+
+PyTorch-ROCm is plumbing here: it owns device memory and streams; every computation on the
+path happens inside the HIP library.  If the library is missing, or no GPU is visible, the
+functions in this module raise -- there is deliberately no CPU fallback.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import scene as _scene
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libprt_hip.so")
+
+RAY_ROWS = 13
+RECORD_COLS = 15
+DEFAULT_RAY_OFFSET = 1e-6
+
+TRACE_KEEP_ABSORBED = 1
+TRACE_UNFUSED = 2
+
+ERR_ROWS_CAP = -4
+ERR_UNTRACABLE = -5
+
+_lib = None
+
+
+class EngineUnavailable(RuntimeError):
+    pass
+
+
+def _declare(lib):
+    c_int, c_i64, c_p, c_d = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_double
+    sig = {
+        "prt_version": (c_int, []),
+        "prt_last_error": (ctypes.c_char_p, []),
+        "prt_device_count": (c_int, []),
+        "prt_scene_create": (c_int, [c_p, c_int, c_p, c_int, c_p, c_int, c_p, c_int, ctypes.POINTER(c_p)]),
+        "prt_scene_destroy": (None, [c_p]),
+        "prt_scene_component_rows": (c_int, [c_p, c_int]),
+        "prt_intersect": (c_int, [c_p, c_int, c_int, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
+        "prt_propagate": (c_int, [c_p, c_int, c_p, c_i64, c_i64, c_p, c_p, c_p]),
+        "prt_world_normals": (c_int, [c_p, c_int, c_int, c_p, c_i64, c_i64, c_p, c_p]),
+        "prt_material_trace": (c_int, [c_p, c_int, c_int, c_p, c_i64, c_i64, c_p]),
+        "prt_interact_workspace_bytes": (c_i64, [c_i64]),
+        "prt_interact": (c_int, [c_p, c_int, c_p, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_int, c_int,
+                                 c_d, c_p, c_i64, c_p, c_p, c_p]),
+        "prt_trace_workspace_bytes": (c_i64, [c_i64]),
+        "prt_trace": (c_i64, [c_p, c_int, c_p, c_i64, c_i64, c_int, c_d, c_p, c_i64, c_p, c_p,
+                              c_int, c_p]),
+        "prt_trace_stats": (c_int, [c_p, c_p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here = the library does not match prt.h
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+EXPORTED_SYMBOLS = (
+    "prt_version", "prt_last_error", "prt_device_count", "prt_scene_create", "prt_scene_destroy",
+    "prt_scene_component_rows", "prt_intersect", "prt_propagate", "prt_world_normals",
+    "prt_material_trace", "prt_interact_workspace_bytes", "prt_interact",
+    "prt_trace_workspace_bytes", "prt_trace", "prt_trace_stats",
+)
+
+
+def library():
+    """Load (once) and return the HIP library; raise EngineUnavailable if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineUnavailable(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `make -C pyrayt_amd/csrc`). pyrayt_amd has no CPU fallback."
+            )
+        _lib = _declare(ctypes.CDLL(LIB_PATH))
+    return _lib
+
+
+def _check(code):
+    if code < 0:
+        msg = library().prt_last_error().decode("utf-8", "replace")
+        if code == ERR_UNTRACABLE:
+            # the reference fails with AttributeError: the default GoochMaterial has no trace()
+            raise AttributeError(msg or "a ray hit a surface whose material cannot be traced")
+        if code == -1:
+            raise ValueError(msg)
+        raise RuntimeError(f"libprt_hip error {code}: {msg}")
+    return code
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise EngineUnavailable(
+            "no HIP device visible: pyrayt_amd traces on an AMD GPU only (no CPU fallback)"
+        )
+    return torch
+
+
+def _stream_ptr(torch, device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class DeviceScene:
+    """Owns a ``prt_scene*`` built from a SceneSnapshot."""
+
+    def __init__(self, snapshot):
+        lib = library()
+        self.snapshot = snapshot
+        self._handle = ctypes.c_void_p()
+        prims = np.ascontiguousarray(snapshot.prims)
+        nodes = np.ascontiguousarray(snapshot.nodes)
+        roots = np.ascontiguousarray(snapshot.roots)
+        mats = np.ascontiguousarray(snapshot.materials)
+        _check(
+            lib.prt_scene_create(
+                prims.ctypes.data, len(prims), nodes.ctypes.data, len(nodes), roots.ctypes.data,
+                len(roots), mats.ctypes.data, len(mats), ctypes.byref(self._handle),
+            )
+        )
+
+    @classmethod
+    def from_components(cls, components):
+        return cls(_scene.SceneSnapshot(components))
+
+    @property
+    def handle(self):
+        if not self._handle:
+            raise RuntimeError("scene already destroyed")
+        return self._handle
+
+    def component_rows(self, root):
+        return _check(library().prt_scene_component_rows(self.handle, root))
+
+    def close(self):
+        if self._handle:
+            library().prt_scene_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- the hot loop -------------------------------------------------------------------------
+    def trace(self, rays, generation_limit, ray_offset=DEFAULT_RAY_OFFSET, flags=0, rows_cap=None):
+        """Run all generations on the device.
+
+        rays: CUDA float64 tensor (13, n), row-major.  Returns (rows, counts): rows is a CUDA
+        (15, total) tensor view, generation-major; counts the rows recorded per generation."""
+        torch = _torch()
+        lib = library()
+        assert rays.is_cuda and rays.dtype == torch.float64 and rays.dim() == 2
+        assert rays.shape[0] == RAY_ROWS and rays.stride(1) == 1
+        n = rays.shape[1]
+        dev = rays.device
+        limit = int(generation_limit)
+        if n == 0 or limit <= 0:
+            return torch.empty((RECORD_COLS, 0), dtype=torch.float64, device=dev), []
+        cap = int(rows_cap) if rows_cap is not None else n * min(limit, 4)
+        work = torch.empty(int(lib.prt_trace_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        counts = (ctypes.c_int64 * limit)()
+        while True:
+            rows = torch.empty((RECORD_COLS, cap), dtype=torch.float64, device=dev)
+            total = lib.prt_trace(
+                self.handle, dev.index or 0, rays.data_ptr(), n, rays.stride(0), limit,
+                float(ray_offset), rows.data_ptr(), cap, counts, work.data_ptr(), int(flags),
+                _stream_ptr(torch, dev),
+            )
+            if total == ERR_ROWS_CAP and cap < n * limit:
+                cap = min(n * limit, cap * 4)  # rare: more than 4 generations survived
+                continue
+            _check(total)
+            break
+        per_generation = [int(c) for c in counts]
+        while per_generation and per_generation[-1] == 0:
+            per_generation.pop()
+        return rows[:, :total], per_generation
+
+    def trace_stats(self):
+        out = (ctypes.c_double * 4)()
+        _check(library().prt_trace_stats(self.handle, out))
+        return {"generations": int(out[0]), "ray_generations": int(out[1]),
+                "kernel_ms": float(out[2]), "kernel_launches": int(out[3])}
+
+    # --- per-state entry points -----------------------------------------------------------------
+    def propagate(self, rays):
+        torch = _torch()
+        n = rays.shape[1]
+        t = torch.empty(n, dtype=torch.float64, device=rays.device)
+        surf = torch.empty(n, dtype=torch.int64, device=rays.device)
+        if n:
+            _check(library().prt_propagate(self.handle, rays.device.index or 0, rays.data_ptr(), n,
+                                           rays.stride(0), t.data_ptr(), surf.data_ptr(),
+                                           _stream_ptr(torch, rays.device)))
+        return t, surf
+
+    def interact(self, rays, t, surf, generation, generation_limit, ray_offset=DEFAULT_RAY_OFFSET):
+        """Returns (rows (15,k), next rays (13,k)); k == 0 when every ray is dead."""
+        torch = _torch()
+        lib = library()
+        n = rays.shape[1]
+        dev = rays.device
+        nxt = torch.empty((RAY_ROWS, n), dtype=torch.float64, device=dev)
+        rows = torch.empty((RECORD_COLS, n), dtype=torch.float64, device=dev)
+        n_live = torch.zeros(1, dtype=torch.int64, device=dev)
+        if n:
+            work = torch.empty(int(lib.prt_interact_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+            _check(lib.prt_interact(self.handle, dev.index or 0, rays.data_ptr(), n, rays.stride(0),
+                                    t.data_ptr(), surf.data_ptr(), nxt.data_ptr(), nxt.stride(0),
+                                    int(generation), int(generation_limit), float(ray_offset),
+                                    rows.data_ptr(), rows.stride(0), n_live.data_ptr(),
+                                    work.data_ptr(), _stream_ptr(torch, dev)))
+        k = int(n_live.item())
+        if k < 0:
+            _check(k)
+        return rows[:, :k], nxt[:, :k]
+
+    def intersect(self, root, rays8):
+        """rays8: CUDA (8+, n) tensor.  Returns (hits (m,n) float64, ids (m,n) int64)."""
+        torch = _torch()
+        n = rays8.shape[1]
+        m = self.component_rows(root)
+        hits = torch.empty((m, n), dtype=torch.float64, device=rays8.device)
+        ids = torch.empty((m, n), dtype=torch.int64, device=rays8.device)
+        if n:
+            _check(library().prt_intersect(self.handle, rays8.device.index or 0, int(root),
+                                           rays8.data_ptr(), n, rays8.stride(0), hits.data_ptr(),
+                                           ids.data_ptr(), n, _stream_ptr(torch, rays8.device)))
+        return hits, ids
+
+    def world_normals(self, prim, points):
+        torch = _torch()
+        k = points.shape[1]
+        out = torch.empty((4, k), dtype=torch.float64, device=points.device)
+        if k:
+            _check(library().prt_world_normals(self.handle, points.device.index or 0, int(prim),
+                                               points.data_ptr(), k, points.stride(0),
+                                               out.data_ptr(), _stream_ptr(torch, points.device)))
+        return out
+
+    def material_trace(self, prim, rays):
+        torch = _torch()
+        k = rays.shape[1]
+        if k:
+            _check(library().prt_material_trace(self.handle, rays.device.index or 0, int(prim),
+                                                rays.data_ptr(), k, rays.stride(0),
+                                                _stream_ptr(torch, rays.device)))
+        return rays
+
+
+# ---------------------------------------------------------------------------------------------
+# numpy-facing conveniences used by the object API (component.intersect, get_world_normals,
+# Material.trace).  Inputs are host arrays (as in the reference's own tests); they are staged
+# through the device.
+# ---------------------------------------------------------------------------------------------
+def _to_device(array, rows=None):
+    torch = _torch()
+    host = np.ascontiguousarray(np.asarray(array, dtype=np.float64))
+    if rows is not None:
+        host = host.reshape(rows, -1)
+    return torch.from_numpy(host).cuda()
+
+
+def component_intersect(component, rays):
+    rays = np.atleast_3d(np.asarray(rays, dtype=float))
+    ds = DeviceScene.from_components([component])
+    try:
+        hits, ids = ds.intersect(0, _to_device(rays, 8))
+        return hits.cpu().numpy(), ids.cpu().numpy()
+    finally:
+        ds.close()
+
+
+def surface_normals(surface, positions):
+    positions = np.asarray(positions, dtype=float)
+    single = positions.ndim == 1
+    ds = DeviceScene.from_components([surface])
+    try:
+        out = ds.world_normals(0, _to_device(positions.reshape(4, -1))).cpu().numpy()
+        return out[:, 0] if single else out
+    finally:
+        ds.close()
+
+
+def material_trace(material, surface, ray_set):
+    """``material.trace(surface, ray_set)``: shades ``ray_set`` in place (and returns it) using
+    ``material`` on ``surface`` regardless of the surface's own material attribute."""
+    from .g3d.objects import TracerSurface
+
+    if not isinstance(surface, TracerSurface):
+        raise TypeError("material.trace needs a TracerSurface")
+    snap = _scene.SceneSnapshot([surface], material_override=material)
+    ds = DeviceScene(snap)
+    try:
+        dev = _to_device(np.asarray(ray_set), RAY_ROWS)
+        ds.material_trace(0, dev)
+        ray_set[...] = dev.cpu().numpy()
+        return ray_set
+    finally:
+        ds.close()

@@ -1,0 +1,255 @@
+"""Scene-graph objects: transforms, ids, traceable surfaces.
+
+Host-side counterpart of the reference's ``tinygfx/g3d/world_objects.py``.  These classes only
+do the O(#surfaces) bookkeeping the hot path consumes as *inputs* (SURVEY.md section 8 row
+a15): the 4x4 world transform chain and its inverse (``world_objects.py:100,122-129``), the
+process-global id counter (``:26-40``), normal inversion (``:305,319-323``) and world-space
+bounding boxes (``:15-23,348-358``).  The per-ray work -- ``intersect`` (``:360-383``) and
+``get_world_normals`` (``:401-418``) -- is executed by the HIP engine; the methods here just
+hand the call to it.
+"""
+import copy
+from itertools import count
+
+import numpy as np
+
+from . import shapes
+
+_UNITS = {"deg": np.pi / 180.0, "rad": 1.0}
+
+
+class CountedObject:
+    """Every scene object draws its id from one process-global counter
+    (``world_objects.py:26-40``); CSG nodes and sources consume ids too."""
+
+    _ids = count(0)
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._id = next(CountedObject._ids)
+
+    def get_id(self):
+        return self._id
+
+    @staticmethod
+    def reset_ids(start=0):
+        """Restart the global counter (test / fixture helper; the reference restarts it only
+        by starting a fresh interpreter)."""
+        CountedObject._ids = count(start)
+
+
+class WorldObject(CountedObject):
+    """An object with a 4x4 homogeneous object->world transform.
+
+    New transforms are applied on the *left* of the accumulated matrix and the inverse is
+    re-derived with ``np.linalg.inv`` after every change, exactly as the reference does
+    (``world_objects.py:122-129``) so the matrices handed to the device are the same floats.
+    """
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._world = np.identity(4, dtype=float)
+        self._object = np.identity(4, dtype=float)
+
+    # --- matrix access -------------------------------------------------------------------
+    def get_world_transform(self):
+        return copy.copy(self._world)
+
+    def get_object_transform(self):
+        return copy.copy(self._object)
+
+    def to_object_coordinates(self, coordinates):
+        return np.matmul(self._object, coordinates)
+
+    def to_world_coordinates(self, coordinates):
+        return np.matmul(self._world, coordinates)
+
+    def get_position(self):
+        return np.matmul(self._world, shapes.Point(0, 0, 0))
+
+    def get_orientation(self):
+        axis = np.matmul(self._world, shapes.Vector(0, 0, 1))
+        length = np.linalg.norm(axis)
+        if length < 1e-7:
+            raise ValueError(f"Measured Norm of World Vector below tolerance: {length}")
+        return axis / length
+
+    # --- the one mutation point -------------------------------------------------------------
+    def _append_world_transform(self, matrix):
+        self._world = np.matmul(matrix, self._world)
+        if np.linalg.norm(np.matmul(self._world, shapes.Vector(0, 0, 1))) < 1e-7:
+            # world_objects.py:113-117
+            raise ValueError("transform collapses the object's z axis")
+        self._object = np.linalg.inv(self._world)
+
+    def transform(self, matrix):
+        self._append_world_transform(np.asarray(matrix, dtype=float))
+        return self
+
+    # --- translation ------------------------------------------------------------------------
+    def move(self, x=0, y=0, z=0):
+        shift = np.identity(4)
+        shift[:3, 3] = (x, y, z)
+        return self.transform(shift)
+
+    def move_x(self, d):
+        return self.move(x=d)
+
+    def move_y(self, d):
+        return self.move(y=d)
+
+    def move_z(self, d):
+        return self.move(z=d)
+
+    # --- scaling ----------------------------------------------------------------------------
+    def scale(self, x=1, y=1, z=1):
+        if min(x, y, z) < 0:
+            raise ValueError("Negative values for scale operations are prohibited")
+        return self.transform(np.diag((x, y, z, 1)).astype(float))
+
+    def scale_x(self, s):
+        return self.scale(x=s)
+
+    def scale_y(self, s):
+        return self.scale(y=s)
+
+    def scale_z(self, s):
+        return self.scale(z=s)
+
+    def scale_all(self, s):
+        return self.scale(s, s, s)
+
+    # --- rotation ---------------------------------------------------------------------------
+    def _rotation(self, angle, units, i, j):
+        """Rotation in the (i,j) coordinate plane; sign convention of world_objects.py:238-269."""
+        if units not in _UNITS:
+            raise ValueError(f"{units} is not a valid option for angle units")
+        radians = angle * np.pi / 180.0 if units == "deg" else angle
+        c, s = np.cos(radians), np.sin(radians)
+        rot = np.identity(4)
+        rot[i, i] = c
+        rot[j, j] = c
+        rot[i, j] = -s
+        rot[j, i] = s
+        return self.transform(rot)
+
+    def rotate_x(self, angle, units="deg"):
+        return self._rotation(angle, units, 1, 2)
+
+    def rotate_y(self, angle, units="deg"):
+        return self._rotation(angle, units, 2, 0)
+
+    def rotate_z(self, angle, units="deg"):
+        return self._rotation(angle, units, 0, 1)
+
+
+class Intersectable(WorldObject):
+    """Anything a RayTracer can hold as a component (``world_objects.py:298-335``)."""
+
+    _normal_scale = 1
+
+    def invert_normals(self):
+        self._normal_scale = -1
+
+    def reset_normals(self):
+        self._normal_scale = 1
+
+    @property
+    def surface_ids(self):
+        return ((self.get_id(), self),)
+
+    @property
+    def bounding_box(self):
+        raise NotImplementedError
+
+    @property
+    def bounding_volume(self):
+        return self.bounding_box
+
+    def intersect(self, rays):
+        """``component.intersect(rays) -> (hits (m,n), surface ids (m,n))`` executed by the
+        HIP engine (reference: ``world_objects.py:360-383`` / ``csg.py:118-160``)."""
+        from .. import engine
+
+        return engine.component_intersect(self, rays)
+
+
+class _Untracable:
+    """Stand-in for the reference's default ``GoochMaterial`` (``world_objects.py:341``): a
+    surface left with it cannot be traced and a ray hitting it raises AttributeError."""
+
+    def __repr__(self):
+        return "<untracable default material>"
+
+
+BLACK = _Untracable()
+
+
+class TracerSurface(Intersectable):
+    """A primitive shape placed in the world, with a material (``world_objects.py:338-422``)."""
+
+    shape_type = None
+
+    def __init__(self, surface_args, material=BLACK, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._shape = type(self).shape_type(*surface_args)
+        self.material = material
+
+    @property
+    def primitive(self):
+        return self._shape
+
+    @property
+    def bounding_box(self):
+        return shapes.AxisBox.around(np.matmul(self._world, self._shape.bounding_points))
+
+    def get_world_normals(self, positions):
+        """World-space unit normals at (4,n) points; runs on the HIP engine
+        (reference: ``world_objects.py:401-418``)."""
+        from .. import engine
+
+        return engine.surface_normals(self, positions)
+
+
+class Sphere(TracerSurface):
+    shape_type = shapes.SphereShape
+
+    def __init__(self, radius=1, material=BLACK, *args, **kwargs):
+        super().__init__((radius,), material, *args, **kwargs)
+
+
+class Cylinder(TracerSurface):
+    shape_type = shapes.CylinderShape
+
+    def __init__(self, radius=1, min_height=-1, max_height=1, material=BLACK, *args, **kwargs):
+        super().__init__((radius, min_height, max_height), material, *args, **kwargs)
+
+
+class Paraboloid(TracerSurface):
+    shape_type = shapes.ParaboloidShape
+
+    def __init__(self, focus=1, height=1, material=BLACK, *args, **kwargs):
+        super().__init__((focus, height), material, *args, **kwargs)
+
+
+class XYPlane(TracerSurface):
+    shape_type = shapes.PlaneShape
+
+    def __init__(self, width=2, length=2, material=BLACK, *args, **kwargs):
+        super().__init__((width, length), material, *args, **kwargs)
+
+
+class Cuboid(TracerSurface):
+    shape_type = shapes.CubeShape
+
+    def __init__(self, l_corner=(-1, -1, -1), r_corner=(1, 1, 1), material=BLACK, *args, **kwargs):
+        super().__init__((l_corner, r_corner), material, *args, **kwargs)
+
+    @classmethod
+    def from_sides(cls, x=1, y=1, z=1, **kwargs):
+        half = np.array((x, y, z), dtype=float) * 0.5
+        return cls(-half, half, **kwargs)
+
+    @classmethod
+    def from_length(cls, length, **kwargs):
+        return cls.from_sides(length, length, length, **kwargs)

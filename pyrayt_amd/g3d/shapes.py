@@ -1,0 +1,134 @@
+"""Primitive shape records.
+
+Host-side these carry only what the device needs (a kind code and up to six parameters) plus
+the object-space bounding corners used to derive world-space bounding boxes.  All
+intersection / normal arithmetic for these shapes lives in the HIP kernels
+(``pyrayt_amd/csrc``); the reference computes it in numpy at
+``tinygfx/g3d/primitives.py`` (Sphere :220-296, Paraboloid :299-419, Plane :422-498,
+Cube :501-602, Cylinder :621-741).
+"""
+import itertools
+
+import numpy as np
+
+# kind codes, must match include/prt.h PRT_PRIM_*
+SPHERE, CYLINDER, PLANE, CUBE, PARABOLOID = range(5)
+
+
+def bundle_of_rays(n_rays):
+    """(2,4,n) ray block, origins (0,0,0,1) and zero directions (primitives.py:18-28)."""
+    block = np.zeros((2, 4, n_rays))
+    block[0, 3] = 1.0
+    return block
+
+
+def Point(x=0.0, y=0.0, z=0.0):
+    """Homogeneous point (w = 1), cf. primitives.py:85-89."""
+    return np.array((x, y, z, 1.0), dtype=float)
+
+
+def Vector(x=0.0, y=0.0, z=0.0):
+    """Homogeneous vector (w = 0), cf. primitives.py:92-94."""
+    return np.array((x, y, z, 0.0), dtype=float)
+
+
+def box_corners(lo, hi):
+    """The eight homogeneous corner points (4,8) of the box spanned by two corners."""
+    spans = np.sort(np.vstack((np.asarray(lo, float)[:3], np.asarray(hi, float)[:3])), axis=0).T
+    pts = [(x, y, z, 1.0) for x, y, z in itertools.product(*spans)]
+    return np.array(pts, dtype=float).T
+
+
+class AxisBox:
+    """Axis-aligned box given by per-axis (min, max) spans, shape (3,2).
+
+    Plays the role of the reference's ``primitives.Cube`` when it is used as a bounding
+    volume (``world_objects.py:15-23``, ``csg.py:93-116``)."""
+
+    def __init__(self, lo, hi):
+        self.axis_spans = np.sort(
+            np.vstack((np.asarray(lo, float)[:3], np.asarray(hi, float)[:3])), axis=0
+        ).T
+
+    @classmethod
+    def around(cls, points):
+        """Smallest box containing a (4,k) or (3,k) point set (world_objects.py:15-23)."""
+        return cls(np.min(points[:3], axis=1), np.max(points[:3], axis=1))
+
+    @property
+    def bounding_points(self):
+        return box_corners(self.axis_spans[:, 0], self.axis_spans[:, 1])
+
+    def flat(self):
+        """xmin,xmax,ymin,ymax,zmin,zmax."""
+        return [float(v) for v in self.axis_spans.reshape(-1)]
+
+
+class Shape:
+    """kind + params + object-space bounds of one primitive."""
+
+    kind = -1
+
+    def __init__(self, params, lo, hi):
+        self.params = tuple(float(p) for p in params)
+        self.bounding_points = box_corners(lo, hi)
+
+    def packed_params(self):
+        return list(self.params) + [0.0] * (6 - len(self.params))
+
+
+class SphereShape(Shape):
+    kind = SPHERE
+
+    def __init__(self, radius=1):
+        super().__init__((radius,), (-radius,) * 3, (radius,) * 3)
+
+    def get_radius(self):
+        return self.params[0]
+
+
+class CylinderShape(Shape):
+    kind = CYLINDER
+
+    def __init__(self, radius=1, min_height=-1, max_height=1):
+        super().__init__(
+            (radius, min_height, max_height),
+            (-radius, -radius, min_height),
+            (radius, radius, max_height),
+        )
+
+    def get_radius(self):
+        return self.params[0]
+
+
+class PlaneShape(Shape):
+    kind = PLANE
+
+    def __init__(self, width=2, length=2):
+        # the reference pads the flat patch by +-0.01 in z for its bounds (primitives.py:431-434)
+        super().__init__(
+            (width, length), (-width / 2, -length / 2, -0.01), (width / 2, length / 2, 0.01)
+        )
+
+
+class CubeShape(Shape):
+    kind = CUBE
+
+    def __init__(self, min_corner=(-1, -1, -1), max_corner=(1, 1, 1)):
+        box = AxisBox(min_corner, max_corner)
+        self.axis_spans = box.axis_spans
+        super().__init__(box.flat(), box.axis_spans[:, 0], box.axis_spans[:, 1])
+
+
+class ParaboloidShape(Shape):
+    kind = PARABOLOID
+
+    def __init__(self, focus=1, height=1):
+        if focus <= 0 or height <= 0:
+            # same guard as primitives.py:306-307
+            raise ValueError("Focus and height must be positive numbers")
+        rim = np.sqrt(4 * focus * height)
+        super().__init__((focus, height), (-rim, -rim, -0.0), (rim, rim, height))
+
+    def get_focus(self):
+        return self.params[0]

@@ -1,0 +1,55 @@
+"""Shared test helpers: fixture loading, snapshot conversion, frame comparison."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+SCENE_KEYS = (
+    "prim_type", "prim_material", "prim_normal_scale", "prim_surface_id", "prim_params",
+    "prim_minv", "node_op", "node_left", "node_right", "node_prim", "node_aabb", "roots",
+    "mat_kind", "mat_coef",
+)
+
+# parity bar of BASELINE.json's north_star: surface index bit-exact, everything else 1e-6 abs
+ATOL = 1e-6
+
+
+def load(name):
+    with np.load(os.path.join(GOLDEN, name)) as data:
+        return {k: data[k] for k in data.files}
+
+
+def scene_of(fixture, prefix=""):
+    """Oracle-format scene dict out of a fixture (optionally key-prefixed ``name__``)."""
+    return {k: fixture[prefix + k] for k in SCENE_KEYS}
+
+
+def flat_scene(snapshot):
+    """pyrayt_amd.scene.SceneSnapshot -> the oracle's plain-array scene dict."""
+    p, n, m = snapshot.prims, snapshot.nodes, snapshot.materials
+    return {
+        "prim_type": p["type"].astype(np.int32), "prim_material": p["material"].astype(np.int32),
+        "prim_normal_scale": p["normal_scale"].astype(np.int32),
+        "prim_surface_id": p["surface_id"].astype(np.int64),
+        "prim_params": p["params"].reshape(-1, 6).astype(float),
+        "prim_minv": p["minv"].reshape(-1, 16).astype(float),
+        "node_op": n["op"].astype(np.int32), "node_left": n["left"].astype(np.int32),
+        "node_right": n["right"].astype(np.int32), "node_prim": n["prim"].astype(np.int32),
+        "node_aabb": n["aabb"].reshape(-1, 6).astype(float),
+        "roots": snapshot.roots.astype(np.int32),
+        "mat_kind": m["kind"].astype(np.int32), "mat_coef": m["coef"].reshape(-1, 6).astype(float),
+    }
+
+
+def assert_frames_match(got, want, atol=ATOL, what="frame"):
+    """Result frames (R,15): same shape, `surface` (col 5), `generation` and `id` exact, the
+    float columns within atol (NaN == NaN)."""
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, f"{what}: shape {got.shape} != {want.shape}"
+    if got.size == 0:
+        return
+    for col in (0, 4, 5):
+        assert np.array_equal(got[:, col], want[:, col]), f"{what}: exact column {col} differs"
+    assert np.allclose(got, want, rtol=0, atol=atol, equal_nan=True), (
+        f"{what}: max abs diff {np.nanmax(np.abs(got - want))}")

@@ -1,0 +1,147 @@
+"""Host-side scene logic (CPU): transforms, ids, bounding boxes, snapshots, sources, RaySet.
+
+The snapshot built by pyrayt_amd's own scene classes must equal the one extracted from the
+reference's objects (stored in the fixtures) -- same matrices, same cull boxes, same surface
+ids in the same order -- since the snapshot is all the device ever sees of a scene.
+"""
+import numpy as np
+import pytest
+
+import helpers
+import scenes
+from pyrayt_amd import RaySet, components, g3d as cg, materials
+from pyrayt_amd.g3d.objects import CountedObject
+from pyrayt_amd.scene import SceneSnapshot
+
+SCENE_ARGS = {
+    "config1": (1000,), "config2": (2048,), "config3": (2048,), "config4": (256,),
+    "config5": (2048,), "two_mirrors": (10,), "tutorial": (10,), "mirrors_and_stops": (4096,),
+    "stopped_lens": (2048,),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SCENE_ARGS))
+def test_snapshot_equals_reference(name):
+    fx = helpers.load(f"scene_{name}.npz")
+    CountedObject.reset_ids()
+    parts, rays = scenes.SCENES[name](scenes.product_api(), *SCENE_ARGS[name])
+    snap = SceneSnapshot(parts)
+    mine, ref = helpers.flat_scene(snap), helpers.scene_of(fx)
+    for key in ("prim_type", "prim_material", "prim_normal_scale", "prim_surface_id", "node_op",
+                "node_left", "node_right", "node_prim", "roots", "mat_kind"):
+        assert np.array_equal(mine[key], ref[key]), key
+    for key in ("prim_params", "prim_minv", "node_aabb", "mat_coef"):
+        assert np.allclose(mine[key], ref[key], rtol=0, atol=1e-13), key
+    assert np.array_equal([sid for sid, _ in snap.surface_lut], fx["lut_ids"])
+    # the seeded / source-generated input rays are the ones the reference traced
+    assert np.allclose(rays, fx["rays0"], rtol=0, atol=1e-15)
+
+
+def test_ids_are_global_and_increasing():
+    """test/test_tinygfx/test_g3d/test_world_objects.py:11-16 and SURVEY Q9."""
+    CountedObject.reset_ids()
+    lens = components.biconvex_lens(2, 2, 0.25, aperture=1)
+    assert [sid for sid, _ in lens.surface_ids] == [1, 2, 0]  # spheres, then the aperture stock
+    assert lens.get_id() == 4
+    src = components.ConeOfRays(6)
+    assert src.get_id() == 5
+    assert components.baffle((1, 1)).get_id() == 6
+
+
+def test_transform_algebra():
+    """world_objects tests :60-188 -- move / rotate / scale compose on the left and the object
+    matrix is the inverse."""
+    s = cg.Sphere(1).move(1, 2, 3).rotate_z(90).scale(2, 2, 2)
+    assert np.allclose(s.get_position()[:3], (-4, 2, 6))
+    assert np.allclose(s.get_world_transform() @ s.get_object_transform(), np.identity(4))
+    assert np.allclose(cg.Sphere(1).rotate_x(90).get_orientation()[:3], (0, -1, 0))
+    assert np.allclose(cg.Sphere(1).rotate_y(90).get_orientation()[:3], (1, 0, 0))
+    with pytest.raises(ValueError):
+        cg.Sphere(1).scale(-1, 1, 1)
+    with pytest.raises(ValueError):
+        cg.Sphere(1).rotate_x(1, units="grad")
+    with pytest.raises(ValueError):
+        cg.Paraboloid(-1, 1)
+
+
+def test_bounding_boxes():
+    """world_objects tests :307-365 and csg tests :46-55,:105-114,:158-172."""
+    s = cg.Sphere(1).scale(2, 1, 1).move_x(3)
+    assert np.allclose(s.bounding_box.axis_spans, ((1, 5), (-1, 1), (-1, 1)))
+    left, right = cg.Sphere(1), cg.Sphere(1)
+    union = cg.csg.union(left, right)
+    right.move_y(-1)
+    assert np.allclose(union.bounding_box.axis_spans, ((-1, 1), (-2, 1), (-1, 1)))
+    union.move_x(3)
+    assert np.allclose(union.bounding_box.axis_spans, ((2, 4), (-2, 1), (-1, 1)))
+    assert left.get_position()[0] == 3 and right.get_position()[0] == 3
+    a, b = cg.Sphere(1), cg.Sphere(1)
+    inter = cg.csg.intersect(a, b)
+    b.move_x(1)
+    assert np.allclose(inter.bounding_box.axis_spans, ((0, 1), (-1, 1), (-1, 1)))
+    c, d = cg.Sphere(1), cg.Sphere(1).move_y(-1)
+    diff = cg.csg.difference(c, d)
+    d.move_y(-1)
+    assert np.allclose(diff.bounding_box.axis_spans, ((-1, 1), (-1, 1), (-1, 1)))
+    assert d._normal_scale == -1 and c._normal_scale == 1
+
+
+def test_csg_surface_ids_nest():
+    """test_csg.py:15-27."""
+    l, r = cg.Sphere(1), cg.Sphere(1)
+    node = cg.csg.CSGSurface(l, r, cg.csg.Operation.UNION)
+    assert [sid for sid, _ in node.surface_ids] == [l.get_id(), r.get_id()]
+    assert len(cg.csg.CSGSurface(cg.Sphere(1), node, cg.csg.Operation.UNION).surface_ids) == 3
+    with pytest.raises(ValueError):
+        cg.csg.CSGSurface(l, r, 7)
+
+
+def test_sources_match_reference():
+    fx = helpers.load("sources.npz")
+    c = components
+    recipes = {
+        "line": lambda: c.LineOfRays(spacing=0.1, wavelength=0.5).move_x(-0.5).rotate_y(-3),
+        "circle": lambda: c.CircleOfRays(diameter=2.0).move(0.1, 0.2, 0.3),
+        "cone": lambda: c.ConeOfRays(6).move_x(-1.9).rotate_z(10),
+        "wedge": lambda: c.WedgeOfRays(30, wavelength=0.7).rotate_x(45),
+    }
+    for name, make in recipes.items():
+        for n in (1, 7, 100):
+            got = np.asarray(make().generate_rays(n))
+            assert np.allclose(got, fx[f"{name}_{n}"], rtol=0, atol=1e-15), (name, n)
+    # test/test_pyrayt/test_components/test_sources.py:48-58
+    assert np.allclose(c.LineOfRays(1).generate_rays(3).rays[0, 1], (-0.5, 0, 0.5))
+    lamp = c.StaticLamp(1, 1)
+    assert lamp.generate_rays(16) is lamp.generate_rays(16)
+    assert np.allclose(np.linalg.norm(c.Lamp(1, 2, 45).generate_rays(64).rays[1], axis=0), 1)
+
+
+def test_rayset_views():
+    """test/test_pyrayt/test_core.py:14-36."""
+    rs = RaySet(1000)
+    assert rs.rays.shape == (2, 4, 1000) and rs.metadata.shape == (5, 1000)
+    assert np.all(rs.rays[0, 3] == 1) and np.all(rs.intensity == 100) and np.all(rs.index == 1)
+    assert np.allclose(rs.wavelength, 0.633) and np.array_equal(rs.id, np.arange(1000))
+    for j, field in enumerate(RaySet.fields):
+        rs.metadata[j] = j
+        assert np.allclose(getattr(rs, field), j)
+        setattr(rs, field, j + 1)
+        assert np.allclose(rs.metadata[j], j + 1)
+    rs.generation[:10] = 7
+    assert np.allclose(rs.metadata[0, :10], 7)
+
+
+def test_lens_full_thickness():
+    """test/test_pyrayt/test_components/test_components.py:8-38."""
+    f = components._lens_full_thickness
+    assert np.allclose(f(np.inf, np.inf, 1.0, 1.0), (1.0, 0.0))
+    assert np.allclose(f(1.0, -1.0, 1.0, 1.0), (1.0, 0.0))  # biconvex: no extra thickness
+    sag = 1 - np.sqrt(1 - 0.25)
+    assert np.allclose(f(-1.0, 1.0, 1.0, 1.0), (1.0 + 2 * sag, 0.0))
+    assert np.allclose(f(-1.0, np.inf, 1.0, 1.0), (1.0 + sag, -sag))
+
+
+def test_glass_helpers():
+    assert np.isclose(materials.SellmeierRefractor(b1=1, c1=1).index_at(2.0), np.sqrt(7 / 3))
+    assert 60 < materials.glass["BK7"].abbe() < 68  # BK7: ~64.2
+    assert materials.glass["ideal"].index_at(np.array([0.5, 0.6])).tolist() == [1.5, 1.5]
