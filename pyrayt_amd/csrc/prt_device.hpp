@@ -1,0 +1,496 @@
+// prt_device.hpp -- per-ray device arithmetic of the ray-propagation path (gfx950 / CDNA4).
+//
+// One ray per lane.  Everything here is float64 and deliberately *not* contracted into FMAs
+// (the library is built with -ffp-contract=off) so that a lane computes what one column of
+// the reference's numpy expressions computes; the exceptions are the 4x4 transforms, which
+// numpy hands to a BLAS dgemm that accumulates with FMAs -- those use explicit fma() chains.
+//
+// np.isclose(x, 0) == |x| <= 1e-8 ; np.isclose(x, h) == |x - h| <= 1e-8 + 1e-5 |h|.
+//
+// Reference (paths under the PyRayT tree):
+//   tinygfx/g3d/primitives.py  Sphere :241-296  Paraboloid :320-419  Plane :436-498
+//                              Cube :516-602    Cylinder :650-741
+//   tinygfx/g3d/operations.py  binomial_root :28-63  reflect :86-107  refract :110-162
+//   tinygfx/g3d/world_objects.py  intersect :360-383  get_world_normals :401-418
+//   tinygfx/g3d/csg.py         array_csg :13-61  CSGSurface.intersect :118-160
+//   pyrayt/materials.py        :47-50 :58-62 :70-75 :112-118 :136-145
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PRT_BLOCK 256
+#define PRT_INF (__builtin_inf())
+
+// ---- device-side scene ----------------------------------------------------------------------
+// All of it is wave-uniform data: it is fetched with scalar loads into SGPRs (the constant
+// cache), which costs no VGPRs, no LDS bandwidth and no bank conflicts.  LDS is spent on the
+// thing that is genuinely per-lane and dynamically indexed: the CSG hit lists.
+struct DevPrim {
+  double minv[16];
+  double params[6];
+  double coef[6];
+  double surface_id;  // as float64: that is how the result frame stores it
+  int32_t type, mat_kind, normal_scale, pad;
+};
+
+enum { I_LEAF = 0, I_CSG = 1, I_ROOT = 2 };
+enum { OPER_REGA = 0, OPER_REGB = 1, OPER_LDS = 2 };
+enum { CSG_UNION = 1, CSG_INTERSECT = 2, CSG_DIFFERENCE = 3 };
+enum { PRIM_SPHERE = 0, PRIM_CYLINDER = 1, PRIM_PLANE = 2, PRIM_CUBE = 3, PRIM_PARABOLOID = 4 };
+enum { MAT_NONE = 0, MAT_ABSORBER = 1, MAT_MIRROR = 2, MAT_CONST = 3, MAT_SELLMEIER = 4 };
+
+// One step of the linearised (post-order) component program.
+struct DevInstr {
+  int32_t kind;   // I_*
+  int32_t a0;     // LEAF: prim        CSG: operation    ROOT: operand mode
+  int32_t a1;     // LEAF: dst mode    CSG: left mode    ROOT: lds base
+  int32_t a2;     // LEAF: lds base    CSG: left base    ROOT: list length
+  int32_t a3;     //                   CSG: left length
+  int32_t a4;     //                   CSG: right mode
+  int32_t a5;     //                   CSG: right base
+  int32_t a6;     //                   CSG: right length
+  int32_t a7;     //                   CSG: out base
+  int32_t pad[3];
+  double aabb[6]; // CSG: xmin,xmax,ymin,ymax,zmin,zmax world-space cull box
+};
+
+struct Ray8 {
+  double ox, oy, oz, ow, dx, dy, dz, dw;
+};
+
+// a sorted pair of hit parameters with the primitive that produced it
+struct Pair {
+  double t0, t1;
+  int prim;
+};
+
+__device__ __forceinline__ bool near0(double x) { return fabs(x) <= 1e-8; }
+__device__ __forceinline__ bool close_to(double x, double h) {
+  return fabs(x - h) <= 1e-8 + 1e-5 * fabs(h);
+}
+__device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
+__device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
+// NaN only arises from 0/0 for zero-direction rays; numpy's sort moves it behind +inf and the
+// tracer masks it with `> 0`, so mapping it to +inf at the leaf is observationally the same.
+__device__ __forceinline__ double nan_to_inf(double x) { return x == x ? x : PRT_INF; }
+
+// row r of (M . v) with the accumulation order of a dgemm micro-kernel: fma chain from 0
+__device__ __forceinline__ double row_dot(const double* __restrict__ m, int r, double x, double y,
+                                          double z, double w) {
+  double acc = m[4 * r + 0] * x;
+  acc = fma(m[4 * r + 1], y, acc);
+  acc = fma(m[4 * r + 2], z, acc);
+  acc = fma(m[4 * r + 3], w, acc);
+  return acc;
+}
+// row r of (M^T . v)
+__device__ __forceinline__ double col_dot(const double* __restrict__ m, int r, double x, double y,
+                                          double z, double w) {
+  double acc = m[0 + r] * x;
+  acc = fma(m[4 + r], y, acc);
+  acc = fma(m[8 + r], z, acc);
+  acc = fma(m[12 + r], w, acc);
+  return acc;
+}
+
+__device__ __forceinline__ double norm4(double x, double y, double z, double w) {
+  return sqrt(((x * x + y * y) + z * z) + w * w);
+}
+__device__ __forceinline__ double norm3(double x, double y, double z) {
+  return sqrt((x * x + y * y) + z * z);
+}
+
+// ---- quadratic with the reference's degenerate branches (operations.py:28-63) ----------------
+__device__ __forceinline__ void binomial_root(double a, double b, double c, double& p0, double& p1) {
+  const double disc = b * b - 4 * a * c;
+  const bool lin = near0(a);
+  const double s = sqrt(dmax(0.0, disc));
+  const double den = 2 * a + (lin ? 1.0 : 0.0);
+  p0 = (-b + s) / den;
+  p1 = (-b - s) / den;
+  if (!(disc >= 0)) { p0 = PRT_INF; p1 = PRT_INF; }
+  if (lin) {
+    const double root = -c / (b + (b == 0 ? 1.0 : 0.0));
+    p0 = root; p1 = root;
+    if (near0(b)) {
+      p0 = (c <= 0) ? -PRT_INF : PRT_INF;
+      p1 = PRT_INF;
+    }
+  }
+}
+
+// crossing parameters of the planes z = lo and z = hi (primitives.py:683-703 / :372-390)
+__device__ __forceinline__ void z_slab(double oz, double dz, double lo, double hi, double& c0,
+                                       double& c1) {
+  const bool par = near0(dz);
+  const double den = dz + (par ? 1.0 : 0.0);
+  c0 = (lo - oz) / den;
+  c1 = (hi - oz) / den;
+  if (par) {
+    c0 = (oz >= lo && oz <= hi) ? -PRT_INF : PRT_INF;
+    c1 = PRT_INF;
+  }
+}
+
+// [max(lo), min(hi)] of two unsorted pairs; miss unless lo <= hi (primitives.py:705-711)
+__device__ __forceinline__ void overlap(double a0, double a1, double b0, double b1, double& h0,
+                                        double& h1) {
+  const double lo = dmax(dmin(a0, a1), dmin(b0, b1));
+  const double hi = dmin(dmax(a0, a1), dmax(b0, b1));
+  const bool ok = lo <= hi;
+  h0 = ok ? lo : PRT_INF;
+  h1 = ok ? hi : PRT_INF;
+}
+
+// one axis of the cube / plane-patch slab test (primitives.py:531-565 / :454-469)
+__device__ __forceinline__ void axis_slab(double o, double d, double lo, double hi, bool inside,
+                                          double& s_lo, double& s_hi) {
+  const bool z = near0(d);
+  const double den = d + (z ? 1.0 : 0.0);
+  double first = -(o - lo) / den;
+  double second = -(o - hi) / den;
+  if (z) {
+    first = inside ? -PRT_INF : PRT_INF;
+    second = PRT_INF;
+  }
+  s_lo = dmin(first, second);
+  s_hi = dmax(first, second);
+}
+
+// world-space cube test used as the CSG cull predicate (csg.py:126-128): "touches" iff the
+// test yields a finite parameter, i.e. enter < leave with either one finite.
+__device__ __forceinline__ void cube_pair(const double* __restrict__ span, double ox, double oy,
+                                          double oz, double dx, double dy, double dz, double& h0,
+                                          double& h1) {
+  double lx, hx, ly, hy, lz, hz;
+  axis_slab(ox, dx, span[0], span[1], ox <= span[1] && ox >= span[0], lx, hx);
+  axis_slab(oy, dy, span[2], span[3], oy <= span[3] && oy >= span[2], ly, hy);
+  axis_slab(oz, dz, span[4], span[5], oz <= span[5] && oz >= span[4], lz, hz);
+  const double enter = dmax(dmax(lx, ly), lz);
+  const double leave = dmin(dmin(hx, hy), hz);
+  const bool ok = enter < leave;  // strict (primitives.py:578)
+  h0 = ok ? enter : PRT_INF;
+  h1 = ok ? leave : PRT_INF;
+}
+
+__device__ __forceinline__ bool is_finite(double x) { return fabs(x) < PRT_INF; }
+
+__device__ __forceinline__ bool box_touched(const double* __restrict__ span, const Ray8& r) {
+  double h0, h1;
+  cube_pair(span, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, h0, h1);
+  return is_finite(h0) || is_finite(h1);
+}
+
+// ---- TracerSurface.intersect: world -> object, primitive test, ascending pair -----------------
+__device__ __forceinline__ void surface_pair(const DevPrim* __restrict__ p, const Ray8& r,
+                                             double& t0, double& t1) {
+  const double* m = p->minv;
+  const double ox = row_dot(m, 0, r.ox, r.oy, r.oz, r.ow);
+  const double oy = row_dot(m, 1, r.ox, r.oy, r.oz, r.ow);
+  const double oz = row_dot(m, 2, r.ox, r.oy, r.oz, r.ow);
+  const double dx = row_dot(m, 0, r.dx, r.dy, r.dz, r.dw);
+  const double dy = row_dot(m, 1, r.dx, r.dy, r.dz, r.dw);
+  const double dz = row_dot(m, 2, r.dx, r.dy, r.dz, r.dw);
+  const double* q = p->params;
+  double h0, h1;
+  switch (p->type) {
+    case PRIM_SPHERE: {  // primitives.py:241-271 (no guard on a == 0)
+      const double a = (dx * dx + dy * dy) + dz * dz;
+      const double b = 2 * ((dx * ox + dy * oy) + dz * oz);
+      const double c = ((ox * ox + oy * oy) + oz * oz) - q[0] * q[0];
+      const double disc = b * b - 4 * a * c;
+      const double s = sqrt(dmax(0.0, disc));
+      const double den = 2 * a;
+      h0 = (-b + s) / den;
+      h1 = (-b - s) / den;
+      if (!(disc >= 0)) { h0 = PRT_INF; h1 = PRT_INF; }
+    } break;
+    case PRIM_CYLINDER: {  // primitives.py:650-712
+      const double a = dx * dx + dy * dy;
+      const double b = 2 * (dx * ox + dy * oy);
+      const double c = (ox * ox + oy * oy) - q[0] * q[0];
+      double s0, s1, c0, c1;
+      binomial_root(a, b, c, s0, s1);
+      z_slab(oz, dz, q[1], q[2], c0, c1);
+      overlap(s0, s1, c0, c1, h0, h1);
+    } break;
+    case PRIM_PLANE: {  // primitives.py:436-492, the hit is reported twice
+      const double hw = q[0] / 2, hl = q[1] / 2;
+      double lx, hx, ly, hy;
+      axis_slab(ox, dx, hw, -hw, fabs(ox) <= hw, lx, hx);
+      axis_slab(oy, dy, hl, -hl, fabs(oy) <= hl, ly, hy);
+      const double enter = dmax(lx, ly), leave = dmin(hx, hy);
+      const bool skew = near0(dz);
+      double t = -oz / (dz + (skew ? 1.0 : 0.0));
+      if (skew) t = PRT_INF;
+      if (!(t >= enter && t <= leave)) t = PRT_INF;
+      h0 = t; h1 = t;
+    } break;
+    case PRIM_CUBE: {  // primitives.py:516-581
+      cube_pair(q, ox, oy, oz, dx, dy, dz, h0, h1);
+    } break;
+    default: {  // PRIM_PARABOLOID, primitives.py:320-399
+      const double f4 = 4 * q[0];
+      const double a = dx * dx + dy * dy;
+      const double b = 2 * (ox * dx + oy * dy) - f4 * dz;
+      const double c = (ox * ox + oy * oy) - f4 * oz;
+      const double disc = b * b - 4 * a * c;
+      const bool lin = near0(a);
+      const double s = sqrt(dmax(0.0, disc));
+      const double den = 2 * a + (lin ? 1.0 : 0.0);
+      double p0 = (-b + s) / den, p1 = (-b - s) / den;
+      if (!(disc >= 0)) { p0 = PRT_INF; p1 = PRT_INF; }
+      if (lin) {
+        p0 = -c / (b + (near0(b) ? 1.0 : 0.0));
+        p1 = (dz >= 0) ? PRT_INF : -PRT_INF;
+      }
+      double c0, c1;
+      z_slab(oz, dz, 0.0, q[1], c0, c1);
+      overlap(p0, p1, c0, c1, h0, h1);
+    } break;
+  }
+  h0 = nan_to_inf(h0);
+  h1 = nan_to_inf(h1);
+  t0 = dmin(h0, h1);
+  t1 = dmax(h0, h1);
+}
+
+// ---- TracerSurface.get_world_normals (world_objects.py:401-418) -------------------------------
+// p = world-space point (4 comps).  Returns the world-space unit normal times normal_scale.
+__device__ __forceinline__ void world_normal(const DevPrim* __restrict__ p, double px, double py,
+                                             double pz, double pw, double& nx, double& ny,
+                                             double& nz) {
+  const double* m = p->minv;
+  const double lx = row_dot(m, 0, px, py, pz, pw);
+  const double ly = row_dot(m, 1, px, py, pz, pw);
+  const double lz = row_dot(m, 2, px, py, pz, pw);
+  const double* q = p->params;
+  double ax, ay, az;  // object-space normal (w = 0)
+  bool normalise = true;
+  switch (p->type) {
+    case PRIM_SPHERE:  // primitives.py:291-293
+      ax = lx; ay = ly; az = lz;
+      break;
+    case PRIM_CYLINDER:  // :722-738
+      ax = lx; ay = ly; az = 0.0;
+      if (close_to(lz, q[1])) { ax = 0.0; ay = 0.0; az = -1.0; }
+      if (close_to(lz, q[2])) { ax = 0.0; ay = 0.0; az = 1.0; }
+      break;
+    case PRIM_PLANE:  // :496-498
+      ax = 0.0; ay = 0.0; az = 1.0;
+      normalise = false;
+      break;
+    case PRIM_CUBE:  // :593-599 (a point on no face gives 0/0 = NaN, as upstream)
+      ax = close_to(lx, q[1]) ? 1.0 : (close_to(lx, q[0]) ? -1.0 : 0.0);
+      ay = close_to(ly, q[3]) ? 1.0 : (close_to(ly, q[2]) ? -1.0 : 0.0);
+      az = close_to(lz, q[5]) ? 1.0 : (close_to(lz, q[4]) ? -1.0 : 0.0);
+      break;
+    default:  // PRIM_PARABOLOID :405-418
+      ax = lx; ay = ly; az = -2 * q[0];
+      if (close_to(lz, q[1])) { ax = 0.0; ay = 0.0; az = 1.0; }
+      break;
+  }
+  if (normalise) {
+    const double len = norm4(ax, ay, az, 0.0);
+    ax /= len; ay /= len; az /= len;
+  }
+  double wx = col_dot(m, 0, ax, ay, az, 0.0);
+  double wy = col_dot(m, 1, ax, ay, az, 0.0);
+  double wz = col_dot(m, 2, ax, ay, az, 0.0);
+  const double len = norm4(wx, wy, wz, 0.0);
+  const double sgn = (double)p->normal_scale;
+  nx = (wx / len) * sgn;
+  ny = (wy / len) * sgn;
+  nz = (wz / len) * sgn;
+}
+
+// ---- materials --------------------------------------------------------------------------------
+__device__ __forceinline__ double glass_index(const DevPrim* __restrict__ p, double wavelength) {
+  if (p->mat_kind == MAT_CONST) return p->coef[0];  // materials.py:112-118
+  const double* k = p->coef;                          // materials.py:136-145
+  const double w2 = wavelength * wavelength;
+  return sqrt(((1 + (k[0] * w2) / (w2 - k[3])) + (k[1] * w2) / (w2 - k[4])) +
+              (k[2] * w2) / (w2 - k[5]));
+}
+
+// material.trace for a ray whose origin (px..pw) already sits on the surface.
+// d (4 comps) and index are updated in place.  Returns false for an untracable material.
+__device__ __forceinline__ bool shade(const DevPrim* __restrict__ p, double px, double py,
+                                      double pz, double pw, double& dx, double& dy, double& dz,
+                                      double& dw, double wavelength, double& index) {
+  const int kind = p->mat_kind;
+  if (kind == MAT_NONE) return false;
+  if (kind == MAT_ABSORBER) {  // materials.py:47-50
+    dx = 0.0; dy = 0.0; dz = 0.0; dw = 0.0;
+    return true;
+  }
+  double nx, ny, nz;
+  world_normal(p, px, py, pz, pw, nx, ny, nz);
+  const double nw = 0.0 * (double)p->normal_scale;
+  if (kind == MAT_MIRROR) {  // operations.py:104-107: v - (2 n) (v.n)
+    const double dot = ((dx * nx + dy * ny) + dz * nz) + dw * nw;
+    dx = dx - (2 * nx) * dot;
+    dy = dy - (2 * ny) * dot;
+    dz = dz - (2 * nz) * dot;
+    dw = dw - (2 * nw) * dot;
+    return true;
+  }
+  // glass: operations.py:110-162
+  const double n_mat = glass_index(p, wavelength);
+  const double len = norm4(dx, dy, dz, dw);
+  const double vx = dx / len, vy = dy / len, vz = dz / len, vw = dw / len;
+  const double cos_p = ((vx * nx + vy * ny) + vz * nz) + vw * nw;
+  const double cos_n = ((vx * -nx + vy * -ny) + vz * -nz) + vw * -nw;
+  const bool leaving = cos_p > 0;
+  const double n2 = leaving ? 1.0 : n_mat;  // n_global = 1 always
+  const double mx = leaving ? -nx : nx, my = leaving ? -ny : ny, mz = leaving ? -nz : nz,
+               mw = leaving ? -nw : nw;
+  const double n1 = index;
+  const double r = n1 / n2;
+  const double cos1 = leaving ? cos_p : cos_n;
+  const double radicand = 1 - (r * r) * (1 - cos1 * cos1);
+  const double cos2 = sqrt(dmax(0.0, radicand));
+  double ux, uy, uz, uw;
+  if (radicand > 0) {
+    const double k = r * cos1 - cos2;
+    ux = r * vx + k * mx; uy = r * vy + k * my; uz = r * vz + k * mz; uw = r * vw + k * mw;
+  } else {  // total internal reflection
+    const double k = 2 * cos1;
+    ux = vx + k * mx; uy = vy + k * my; uz = vz + k * mz; uw = vw + k * mw;
+  }
+  const double ulen = norm4(ux, uy, uz, uw);
+  dx = ux / ulen; dy = uy / ulen; dz = uz / ulen; dw = uw / ulen;
+  index = (radicand > 0) ? n2 : n1;
+  return true;
+}
+
+// ---- per-lane hit lists in LDS -------------------------------------------------------------------
+// Slot s of lane `tid` lives at t[s * PRT_BLOCK + tid] / id[s * PRT_BLOCK + tid]: a lane's
+// slots are PRT_BLOCK elements apart, so whatever (per-lane, data dependent) slot index the
+// lanes of a wave use, lane l always touches bank (2l mod 64): conflict free by construction.
+struct LaneLists {
+  double* t;
+  int* id;
+  __device__ __forceinline__ double get_t(int slot) const { return t[slot * PRT_BLOCK]; }
+  __device__ __forceinline__ int get_id(int slot) const { return id[slot * PRT_BLOCK]; }
+  __device__ __forceinline__ void put(int slot, double v, int i) const {
+    t[slot * PRT_BLOCK] = v;
+    id[slot * PRT_BLOCK] = i;
+  }
+};
+
+// an operand of a CSG step: either a register pair (a leaf just evaluated) or a list in LDS
+struct Operand {
+  int mode, base, len;
+};
+
+__device__ __forceinline__ double operand_t(const Operand& o, const LaneLists& l, const Pair& a,
+                                            const Pair& b, int i) {
+  if (o.mode == OPER_LDS) return l.get_t(o.base + i);
+  const Pair& p = (o.mode == OPER_REGA) ? a : b;
+  return i == 0 ? p.t0 : p.t1;
+}
+__device__ __forceinline__ int operand_id(const Operand& o, const LaneLists& l, const Pair& a,
+                                          const Pair& b, int i) {
+  if (o.mode == OPER_LDS) return l.get_id(o.base + i);
+  return (o.mode == OPER_REGA) ? a.prim : b.prim;
+}
+
+// array_csg + the id bookkeeping of CSGSurface.intersect (csg.py:13-61, 137-149) for one lane:
+// stable two-pointer merge of two ascending lists (ties: left first), +-1 by source-position
+// parity (right child flipped for DIFFERENCE), running depth, keep rule with the np.roll
+// wrap-around, survivors compacted to the front of the output list in order, rest = +inf.
+// `touched` is the node's cull predicate: an untouched ray gets an all-inf list.
+// The output may start len(right) slots below the left list (see scene compiler): position
+// out+k is written only after left[k - len(right)] has been read.
+__device__ __forceinline__ void csg_merge(int op, const Operand& L, const Operand& R, int out_base,
+                                          bool touched, const LaneLists& lists, const Pair& ra,
+                                          const Pair& rb) {
+  const int total = L.len + R.len;
+  int i = 0, j = 0, outn = 0;
+  int depth = (op == CSG_DIFFERENCE) ? 1 : 0;
+  int prev = depth;  // depth of the last merged entry: the totals always cancel
+  double a = operand_t(L, lists, ra, rb, 0);
+  double b = operand_t(R, lists, ra, rb, 0);
+  for (int s = 0; s < total; ++s) {
+    const bool take_left = (i < L.len) && ((j >= R.len) || (a <= b));
+    const double v = take_left ? a : b;
+    const int pos = take_left ? i : j;
+    int step = (pos & 1) ? -1 : 1;
+    if (op == CSG_DIFFERENCE && !take_left) step = -step;
+    depth += step;
+    const bool keep = (op == CSG_UNION) ? ((depth != 0) != (prev != 0)) : (depth == 2 || prev == 2);
+    prev = depth;
+    int id = -1;
+    if (keep && touched && v < PRT_INF) id = operand_id(take_left ? L : R, lists, ra, rb, pos);
+    if (take_left) {
+      ++i;
+      a = (i < L.len) ? operand_t(L, lists, ra, rb, i) : PRT_INF;
+    } else {
+      ++j;
+      b = (j < R.len) ? operand_t(R, lists, ra, rb, j) : PRT_INF;
+    }
+    if (id >= 0) {
+      lists.put(out_base + outn, v, id);
+      ++outn;
+    }
+  }
+  for (int k = outn; k < total; ++k) lists.put(out_base + k, PRT_INF, -1);
+}
+
+// nearest positive entry of an ascending list = its first positive one (_pyrayt.py:380-383)
+__device__ __forceinline__ void first_positive(const Operand& o, const LaneLists& lists,
+                                               const Pair& ra, const Pair& rb, double& t, int& prim) {
+  t = PRT_INF;
+  prim = -1;
+  for (int k = o.len - 1; k >= 0; --k) {
+    const double v = operand_t(o, lists, ra, rb, k);
+    if (v > 0 && v < PRT_INF) {
+      t = v;
+      prim = operand_id(o, lists, ra, rb, k);
+    }
+  }
+}
+
+// Run the scene program for one ray: nearest positive hit over all components with the
+// strict '<' running minimum of _pyrayt.py:384-386.  `prims`/`code` are wave-uniform.
+__device__ __forceinline__ void nearest_hit(const DevPrim* __restrict__ prims,
+                                            const DevInstr* __restrict__ code, int n_instr,
+                                            const Ray8& ray, const LaneLists& lists, double& best_t,
+                                            int& best_prim) {
+  best_t = PRT_INF;
+  best_prim = -1;
+  Pair ra = {PRT_INF, PRT_INF, -1}, rb = {PRT_INF, PRT_INF, -1};
+  for (int pc = 0; pc < n_instr; ++pc) {
+    const DevInstr* __restrict__ in = code + pc;
+    const int kind = in->kind;
+    if (kind == I_LEAF) {
+      const int p = in->a0;
+      double t0, t1;
+      surface_pair(prims + p, ray, t0, t1);
+      const int dst = in->a1;
+      if (dst == OPER_REGA) {
+        ra.t0 = t0; ra.t1 = t1; ra.prim = p;
+      } else if (dst == OPER_REGB) {
+        rb.t0 = t0; rb.t1 = t1; rb.prim = p;
+      } else {
+        lists.put(in->a2, t0, p);
+        lists.put(in->a2 + 1, t1, p);
+      }
+    } else if (kind == I_CSG) {
+      const Operand L = {in->a1, in->a2, in->a3};
+      const Operand R = {in->a4, in->a5, in->a6};
+      const bool touched = box_touched(in->aabb, ray);
+      csg_merge(in->a0, L, R, in->a7, touched, lists, ra, rb);
+    } else {  // I_ROOT
+      const Operand o = {in->a0, in->a1, in->a2};
+      double t;
+      int prim;
+      first_positive(o, lists, ra, rb, t, prim);
+      if (t < best_t) {
+        best_t = t;
+        best_prim = prim;
+      }
+    }
+  }
+}

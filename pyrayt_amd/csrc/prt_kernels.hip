@@ -1,0 +1,922 @@
+// prt_kernels.hip -- HIP kernels (gfx950 / CDNA4) + the C-ABI of include/prt.h.
+//
+// Data layout in HBM
+//   ray set      (13, n) float64 row-major = PyRayT's RaySet verbatim (pyrayt/_pyrayt.py:13-44):
+//                one contiguous row per field -> lane i of a wave reads element i of every
+//                row: each of the 13 loads is a fully coalesced 512 B wave transaction.
+//   record rows  (15, cap) float64 row-major: one contiguous row per DataFrame column
+//                (_pyrayt.py:154-165); generation g appends its rows at column row_base(g).
+//   scene        DevPrim[] + DevInstr[]: wave-uniform, fetched through the scalar cache.
+//   per-lane CSG hit lists live in LDS (see prt_device.hpp), never in HBM.
+//
+// Kernels (one ray per lane, 256-thread workgroups, 64-wide waves):
+//   k_hit        nearest positive hit of every ray: world->object transform, analytic
+//                primitive tests, CSG interval algebra, running argmin     [_st_propagate]
+//   k_scan       exclusive scan of the per-workgroup live / carried counts
+//   k_shade      hit point, world normal, absorb / reflect / refract, order-preserving
+//                compaction (wave ballot + popcount, LDS across waves), record + next state
+//                                                                          [_st_interact + insert]
+//   k_intersect / k_normals / k_material_trace   the per-object entry points
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/prt.h"
+#include "prt_device.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_error;
+
+static int fail(int code, const std::string& msg) {
+  g_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(PRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// scene
+// ------------------------------------------------------------------------------------------------
+struct SceneDev {
+  const DevPrim* prims;
+  const DevInstr* code;
+  int n_instr;
+  int lds_slots;
+};
+
+struct Program {
+  std::vector<DevInstr> code;
+  int lds_slots = 0;
+};
+
+struct DeviceCopy {
+  DevPrim* prims = nullptr;
+  DevInstr* trace_code = nullptr;               // all components, each ending in I_ROOT
+  std::vector<DevInstr*> component_code;        // one program per component, no I_ROOT
+  int64_t* host_pinned = nullptr;               // 8 x int64 pinned staging
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct prt_scene {
+  std::vector<prt_prim> prims;
+  std::vector<prt_node> nodes;
+  std::vector<int32_t> roots;
+  std::vector<prt_material> mats;
+  std::vector<DevPrim> dev_prims;
+  Program trace_program;
+  std::vector<Program> component_programs;
+  std::vector<Operand> component_result;        // where each component program leaves its list
+  std::vector<DeviceCopy> per_device;
+  bool has_untracable = false;
+  double stats[4] = {0, 0, 0, 0};
+};
+
+static int leaves_under(const prt_scene* s, int node) {
+  const prt_node& n = s->nodes[node];
+  if (n.op == PRT_NODE_LEAF) return 1;
+  return leaves_under(s, n.left) + leaves_under(s, n.right);
+}
+
+// Linearise one component (post-order) and place its hit lists in LDS.
+//
+// Slots are handed out downwards from a ceiling (slot numbers are negative while compiling and
+// shifted afterwards).  A leaf that feeds the CSG step right after it stays in registers
+// (REGA / REGB); every CSG result goes to LDS.  With a register operand of length 2 and the
+// other operand at [b, b+m) the result is written to [b-2, b+m): the merge writes slot
+// b-2+k only after it has consumed k-2 entries of that operand, so it never overwrites an
+// unread entry, and a chain of k leaves needs just 2k slots.  Two LDS operands keep the right
+// one a further len(right) slots down so the same argument holds for the left one.
+struct Compiler {
+  const prt_scene* s;
+  std::vector<DevInstr>& out;
+  int lowest = 0;
+
+  static DevInstr blank(int kind) {
+    DevInstr in;
+    std::memset(&in, 0, sizeof(in));
+    in.kind = kind;
+    return in;
+  }
+
+  Operand leaf(int node, int mode, int ceiling) {
+    DevInstr in = blank(I_LEAF);
+    in.a0 = s->nodes[node].prim;
+    in.a1 = mode;
+    Operand o = {mode, 0, 2};
+    if (mode == OPER_LDS) {
+      o.base = ceiling - 2;
+      in.a2 = o.base;
+      lowest = std::min(lowest, o.base);
+    }
+    out.push_back(in);
+    return o;
+  }
+
+  Operand emit(int node, int ceiling) {
+    const prt_node& n = s->nodes[node];
+    if (n.op == PRT_NODE_LEAF) return leaf(node, OPER_LDS, ceiling);
+    const bool l_leaf = s->nodes[n.left].op == PRT_NODE_LEAF;
+    const bool r_leaf = s->nodes[n.right].op == PRT_NODE_LEAF;
+    Operand L, R;
+    int base;
+    if (l_leaf && r_leaf) {
+      L = leaf(n.left, OPER_REGA, 0);
+      R = leaf(n.right, OPER_REGB, 0);
+      base = ceiling - 4;
+    } else if (r_leaf) {
+      L = emit(n.left, ceiling);
+      R = leaf(n.right, OPER_REGB, 0);
+      base = L.base - 2;
+    } else if (l_leaf) {
+      R = emit(n.right, ceiling);  // evaluation order of pure children is free
+      L = leaf(n.left, OPER_REGA, 0);
+      base = R.base - 2;
+    } else {
+      L = emit(n.left, ceiling);
+      const int m_r = 2 * leaves_under(s, n.right);
+      R = emit(n.right, L.base - m_r);
+      base = L.base - m_r;
+    }
+    DevInstr in = blank(I_CSG);
+    in.a0 = n.op;
+    in.a1 = L.mode; in.a2 = L.base; in.a3 = L.len;
+    in.a4 = R.mode; in.a5 = R.base; in.a6 = R.len;
+    in.a7 = base;
+    for (int k = 0; k < 6; ++k) in.aabb[k] = n.aabb[k];
+    out.push_back(in);
+    lowest = std::min(lowest, base);
+    return Operand{OPER_LDS, base, L.len + R.len};
+  }
+};
+
+static void shift_slots(std::vector<DevInstr>& code, size_t from, int shift) {
+  for (size_t k = from; k < code.size(); ++k) {
+    DevInstr& in = code[k];
+    if (in.kind == I_LEAF && in.a1 == OPER_LDS) in.a2 += shift;
+    if (in.kind == I_CSG) {
+      if (in.a1 == OPER_LDS) in.a2 += shift;
+      if (in.a4 == OPER_LDS) in.a5 += shift;
+      in.a7 += shift;
+    }
+    if (in.kind == I_ROOT && in.a0 == OPER_LDS) in.a1 += shift;
+  }
+}
+
+// compile component `root_node`; returns where its result list ends up
+static Operand compile_component(const prt_scene* s, int root_node, std::vector<DevInstr>& code,
+                                 bool with_root, int* slots) {
+  const size_t from = code.size();
+  Compiler c{s, code};
+  Operand res;
+  if (s->nodes[root_node].op == PRT_NODE_LEAF)
+    res = c.leaf(root_node, OPER_REGA, 0);
+  else
+    res = c.emit(root_node, 0);
+  if (with_root) {
+    DevInstr in = Compiler::blank(I_ROOT);
+    in.a0 = res.mode; in.a1 = res.base; in.a2 = res.len;
+    code.push_back(in);
+  }
+  const int shift = -c.lowest;
+  shift_slots(code, from, shift);
+  if (res.mode == OPER_LDS) res.base += shift;
+  *slots = std::max(*slots, shift);
+  return res;
+}
+
+static int validate_tree(const prt_scene* s, int node, int depth, std::vector<char>& seen) {
+  if (node < 0 || node >= (int)s->nodes.size() || depth > 64 || seen[node]) return PRT_ERR_SCENE;
+  seen[node] = 1;
+  const prt_node& n = s->nodes[node];
+  if (n.op == PRT_NODE_LEAF) {
+    if (n.prim < 0 || n.prim >= (int)s->prims.size()) return PRT_ERR_SCENE;
+    return PRT_OK;
+  }
+  if (n.op < PRT_NODE_UNION || n.op > PRT_NODE_DIFFERENCE) return PRT_ERR_SCENE;
+  int rc = validate_tree(s, n.left, depth + 1, seen);
+  if (rc) return rc;
+  return validate_tree(s, n.right, depth + 1, seen);
+}
+
+static const size_t kMaxLdsBytes = 64 * 1024;  // keep >= 2 workgroups per CU
+
+extern "C" int prt_scene_create(const prt_prim* prims, int n_prims, const prt_node* nodes,
+                                int n_nodes, const int32_t* roots, int n_roots,
+                                const prt_material* mats, int n_mats, prt_scene** out) {
+  if (!out) return fail(PRT_ERR_ARG, "out is null");
+  *out = nullptr;
+  if (n_prims < 0 || n_nodes < 0 || n_roots < 0 || n_mats < 0 ||
+      (n_prims && !prims) || (n_nodes && !nodes) || (n_roots && !roots) || (n_mats && !mats))
+    return fail(PRT_ERR_ARG, "null array with non-zero count");
+  prt_scene* s = new prt_scene();
+  s->prims.assign(prims, prims + n_prims);
+  s->nodes.assign(nodes, nodes + n_nodes);
+  s->roots.assign(roots, roots + n_roots);
+  s->mats.assign(mats, mats + n_mats);
+  std::vector<char> seen(n_nodes, 0);
+  for (int r : s->roots) {
+    if (validate_tree(s, r, 0, seen) != PRT_OK) {
+      delete s;
+      return fail(PRT_ERR_SCENE, "malformed component tree (bad index, cycle, shared node or op)");
+    }
+  }
+  for (const prt_prim& p : s->prims) {
+    if (p.type < PRT_PRIM_SPHERE || p.type > PRT_PRIM_PARABOLOID || p.material < 0 ||
+        p.material >= n_mats) {
+      delete s;
+      return fail(PRT_ERR_SCENE, "primitive with unknown type or material index");
+    }
+    const prt_material& m = s->mats[p.material];
+    if (m.kind < PRT_MAT_NONE || m.kind > PRT_MAT_SELLMEIER) {
+      delete s;
+      return fail(PRT_ERR_SCENE, "unknown material kind");
+    }
+    DevPrim d;
+    std::memset(&d, 0, sizeof(d));
+    std::memcpy(d.minv, p.minv, sizeof(d.minv));
+    std::memcpy(d.params, p.params, sizeof(d.params));
+    std::memcpy(d.coef, m.coef, sizeof(d.coef));
+    d.surface_id = (double)p.surface_id;
+    d.type = p.type;
+    d.mat_kind = m.kind;
+    d.normal_scale = p.normal_scale < 0 ? -1 : 1;
+    if (m.kind == PRT_MAT_NONE) s->has_untracable = true;
+    s->dev_prims.push_back(d);
+  }
+  for (int r : s->roots) {
+    compile_component(s, r, s->trace_program.code, true, &s->trace_program.lds_slots);
+    Program p;
+    Operand res = compile_component(s, r, p.code, false, &p.lds_slots);
+    s->component_programs.push_back(p);
+    s->component_result.push_back(res);
+  }
+  const size_t lds = (size_t)s->trace_program.lds_slots * PRT_BLOCK * 12;
+  if (lds > kMaxLdsBytes) {
+    delete s;
+    return fail(PRT_ERR_SCENE, "a component has too many surfaces for the per-lane LDS hit lists");
+  }
+  *out = s;
+  return PRT_OK;
+}
+
+extern "C" void prt_scene_destroy(prt_scene* s) {
+  if (!s) return;
+  for (size_t d = 0; d < s->per_device.size(); ++d) {
+    DeviceCopy& c = s->per_device[d];
+    if (!c.prims && !c.trace_code) continue;
+    (void)hipSetDevice((int)d);
+    (void)hipFree(c.prims);
+    (void)hipFree(c.trace_code);
+    for (DevInstr* p : c.component_code) (void)hipFree(p);
+    if (c.host_pinned) (void)hipHostFree(c.host_pinned);
+    if (c.ev0) (void)hipEventDestroy(c.ev0);
+    if (c.ev1) (void)hipEventDestroy(c.ev1);
+  }
+  delete s;
+}
+
+extern "C" int prt_scene_component_rows(const prt_scene* s, int root) {
+  if (!s || root < 0 || root >= (int)s->roots.size()) return fail(PRT_ERR_ARG, "bad component index");
+  return 2 * leaves_under(s, s->roots[root]);
+}
+
+template <typename T>
+static int upload(T** dst, const std::vector<T>& src) {
+  *dst = nullptr;
+  const size_t bytes = std::max<size_t>(1, src.size()) * sizeof(T);
+  HIP_TRY(hipMalloc((void**)dst, bytes));
+  if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return PRT_OK;
+}
+
+// make sure the scene tables exist on `device` and make it current
+static int on_device(prt_scene* s, int device, DeviceCopy** out) {
+  if (!s) return fail(PRT_ERR_ARG, "scene is null");
+  int count = 0;
+  HIP_TRY(hipGetDeviceCount(&count));
+  if (device < 0 || device >= count) return fail(PRT_ERR_ARG, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  if ((int)s->per_device.size() <= device) s->per_device.resize(device + 1);
+  DeviceCopy& c = s->per_device[device];
+  if (!c.prims) {
+    int rc = upload(&c.prims, s->dev_prims);
+    if (rc) return rc;
+    rc = upload(&c.trace_code, s->trace_program.code);
+    if (rc) return rc;
+    for (const Program& p : s->component_programs) {
+      DevInstr* code = nullptr;
+      rc = upload(&code, p.code);
+      if (rc) return rc;
+      c.component_code.push_back(code);
+    }
+    HIP_TRY(hipHostMalloc((void**)&c.host_pinned, 8 * sizeof(int64_t), hipHostMallocDefault));
+    HIP_TRY(hipEventCreate(&c.ev0));
+    HIP_TRY(hipEventCreate(&c.ev1));
+  }
+  *out = &c;
+  return PRT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+extern __shared__ double lds_dyn[];
+
+__device__ __forceinline__ LaneLists lane_lists(int slots) {
+  LaneLists l;
+  l.t = lds_dyn + threadIdx.x;
+  l.id = reinterpret_cast<int*>(lds_dyn + (size_t)slots * PRT_BLOCK) + threadIdx.x;
+  return l;
+}
+
+__device__ __forceinline__ Ray8 load_ray8(const double* __restrict__ rays, int64_t ld, int64_t i) {
+  Ray8 r;
+  r.ox = rays[0 * ld + i]; r.oy = rays[1 * ld + i]; r.oz = rays[2 * ld + i]; r.ow = rays[3 * ld + i];
+  r.dx = rays[4 * ld + i]; r.dy = rays[5 * ld + i]; r.dz = rays[6 * ld + i]; r.dw = rays[7 * ld + i];
+  return r;
+}
+
+// control block of a trace, in device memory
+struct TraceCtrl {
+  int64_t n_cur;      // rays alive at the entry of the current generation
+  int64_t n_live;     // ... of which are recorded this generation
+  int64_t n_carry;    // ... of which go on to the next generation
+  int64_t row_base;   // first record column of the current generation
+  int64_t rows_cap;
+  int32_t error;      // PRT_ERR_* raised on the device
+  int32_t pad;
+};
+
+// dead-ray rule of _pyrayt.py:415-420: absorbed (|d| ~ 0 before the interaction) or no hit;
+// the intensity threshold is a no-op upstream (Q2).
+__device__ __forceinline__ bool is_live(const Ray8& r, int prim) {
+  return !(near0(norm4(r.dx, r.dy, r.dz, r.dw)) || prim < 0);
+}
+
+// prt_interact receives surface ids from the caller: map one back to its primitive (-1 = none)
+__device__ __forceinline__ int prim_of_surface(const DevPrim* __restrict__ prims, int n_prims,
+                                               int64_t sid) {
+  int prim = -1;
+  for (int p = 0; p < n_prims; ++p)
+    if (sid >= 0 && (int64_t)prims[p].surface_id == sid) prim = p;
+  return prim;
+}
+
+// [_st_propagate] nearest hit + per-workgroup counts of live / carried rays.
+// prt_propagate uses the same kernel with counts == nullptr and surf_out != nullptr.
+__global__ void __launch_bounds__(PRT_BLOCK)
+k_hit(SceneDev scene, const double* __restrict__ rays, int64_t ld, const TraceCtrl* __restrict__ ctrl,
+      int64_t n_fixed, double* __restrict__ hit_t, int32_t* __restrict__ hit_prim,
+      int64_t* __restrict__ surf_out, int32_t* __restrict__ block_counts, int keep_absorbed) {
+  const int64_t n = ctrl ? ctrl->n_cur : n_fixed;
+  const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+  const LaneLists lists = lane_lists(scene.lds_slots);
+  bool live = false, carry = false;
+  if (i < n) {
+    const Ray8 r = load_ray8(rays, ld, i);
+    double t;
+    int prim;
+    nearest_hit(scene.prims, scene.code, scene.n_instr, r, lists, t, prim);
+    hit_t[i] = t;
+    if (hit_prim) hit_prim[i] = prim;
+    if (surf_out) surf_out[i] = prim >= 0 ? (int64_t)scene.prims[prim].surface_id : -1;
+    live = is_live(r, prim);
+    carry = live && (keep_absorbed || scene.prims[prim].mat_kind != MAT_ABSORBER);
+  }
+  if (block_counts) {
+    __shared__ int s_live, s_carry;
+    if (threadIdx.x == 0) { s_live = 0; s_carry = 0; }
+    __syncthreads();
+    const int w_live = __popcll(__ballot(live));
+    const int w_carry = __popcll(__ballot(carry));
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&s_live, w_live);
+      atomicAdd(&s_carry, w_carry);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      block_counts[2 * blockIdx.x + 0] = s_live;
+      block_counts[2 * blockIdx.x + 1] = s_carry;
+    }
+  }
+}
+
+// exclusive scan of the (live, carry) workgroup counts; one workgroup, grid-stride chunks
+__global__ void __launch_bounds__(1024)
+k_scan(const int32_t* __restrict__ block_counts, int64_t* __restrict__ block_offsets,
+       TraceCtrl* __restrict__ ctrl) {
+  __shared__ int64_t s_part[2][1024];
+  __shared__ int64_t s_run[2];
+  const int64_t n_blocks = (ctrl->n_cur + PRT_BLOCK - 1) / PRT_BLOCK;
+  if (threadIdx.x == 0) { s_run[0] = 0; s_run[1] = 0; }
+  __syncthreads();
+  for (int64_t base = 0; base < n_blocks; base += 1024) {
+    const int64_t b = base + threadIdx.x;
+    int64_t v0 = 0, v1 = 0;
+    if (b < n_blocks) { v0 = block_counts[2 * b]; v1 = block_counts[2 * b + 1]; }
+    s_part[0][threadIdx.x] = v0;
+    s_part[1][threadIdx.x] = v1;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+      int64_t a0 = 0, a1 = 0;
+      if ((int)threadIdx.x >= off) {
+        a0 = s_part[0][threadIdx.x - off];
+        a1 = s_part[1][threadIdx.x - off];
+      }
+      __syncthreads();
+      s_part[0][threadIdx.x] += a0;
+      s_part[1][threadIdx.x] += a1;
+      __syncthreads();
+    }
+    if (b < n_blocks) {
+      block_offsets[2 * b] = s_run[0] + s_part[0][threadIdx.x] - v0;
+      block_offsets[2 * b + 1] = s_run[1] + s_part[1][threadIdx.x] - v1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) {
+      s_run[0] += s_part[0][1023];
+      s_run[1] += s_part[1][1023];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    ctrl->n_live = s_run[0];
+    ctrl->n_carry = s_run[1];
+    if (ctrl->row_base + s_run[0] > ctrl->rows_cap) ctrl->error = PRT_ERR_ROWS_CAP;
+  }
+}
+
+// exclusive rank of this lane among the flagged lanes of its workgroup
+__device__ __forceinline__ int block_rank(bool flag, int* s_wave /*[4]*/) {
+  const unsigned long long mask = __ballot(flag);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int before = __popcll(mask & ((1ull << lane) - 1ull));
+  if (lane == 0) s_wave[wave] = __popcll(mask);
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += s_wave[w];
+  __syncthreads();
+  return base + before;
+}
+
+// [_st_interact + _RayTraceDataframe.insert]
+__global__ void __launch_bounds__(PRT_BLOCK)
+k_shade(SceneDev scene, const double* __restrict__ rays, int64_t ld, const TraceCtrl* __restrict__ ctrl_in,
+        int64_t n_fixed, const double* __restrict__ hit_t, const int32_t* __restrict__ hit_prim,
+        const int64_t* __restrict__ hit_surf, const int64_t* __restrict__ block_offsets,
+        double* __restrict__ next, int64_t ld_next, double* __restrict__ rows, int64_t ld_rows,
+        int64_t row_base_fixed, double next_generation, int relaunch, double ray_offset,
+        int keep_absorbed, TraceCtrl* __restrict__ ctrl) {
+  __shared__ int s_wave[4];
+  const int64_t n = ctrl_in ? ctrl_in->n_cur : n_fixed;
+  if (ctrl_in && (ctrl_in->error != 0 || ctrl_in->n_live == 0)) return;  // uniform
+  const int64_t row_base = ctrl_in ? ctrl_in->row_base : row_base_fixed;
+  const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+  const bool in_range = i < n;
+  Ray8 r = {0, 0, 0, 1, 0, 0, 0, 0};
+  double t = PRT_INF;
+  int prim = -1;
+  if (in_range) {
+    r = load_ray8(rays, ld, i);
+    t = hit_t[i];
+    if (hit_prim) {
+      prim = hit_prim[i];
+    } else {  // prt_interact (n_instr carries the primitive count on this path)
+      prim = prim_of_surface(scene.prims, scene.n_instr, hit_surf[i]);
+    }
+  }
+  const bool live = in_range && is_live(r, prim);
+  const bool carry = live && (keep_absorbed || scene.prims[prim].mat_kind != MAT_ABSORBER);
+  const int live_rank = block_rank(live, s_wave);
+  const int carry_rank = block_rank(carry, s_wave);
+  if (!live) return;
+
+  const double generation = rays[8 * ld + i];
+  const double intensity = rays[9 * ld + i];
+  const double wavelength = rays[10 * ld + i];
+  const double index_in = rays[11 * ld + i];
+  const double id = rays[12 * ld + i];
+
+  // advance to the hit point: o += d * t, all four homogeneous components (_pyrayt.py:404-407)
+  const double px = r.ox + r.dx * t, py = r.oy + r.dy * t, pz = r.oz + r.dz * t,
+               pw = r.ow + r.dw * t;
+  double dx = r.dx, dy = r.dy, dz = r.dz, dw = r.dw, index = index_in, surface_id = -1.0;
+  // material dispatch: the primitive table is wave-uniform data, so lanes that hit the same
+  // surface shade together and the loop runs once per distinct surface hit in the wave
+  unsigned long long todo = __ballot(true);
+  bool ok = true;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int cur = __shfl(prim, leader);
+    if (prim == cur) {
+      const DevPrim* __restrict__ p = scene.prims + cur;
+      ok = shade(p, px, py, pz, pw, dx, dy, dz, dw, wavelength, index);
+      surface_id = p->surface_id;
+    }
+    todo &= ~__ballot(prim == cur);
+  }
+  if (!ok) atomicExch(&ctrl->error, PRT_ERR_UNTRACABLE);
+
+  // record row (_pyrayt.py:168-186): pre-hit metadata, surface, start, end, unit tilt
+  const int64_t row = row_base + block_offsets[2 * blockIdx.x] + live_rank;
+  const double tilt = norm3(r.dx, r.dy, r.dz);
+  rows[PRT_COL_GENERATION * ld_rows + row] = generation;
+  rows[PRT_COL_INTENSITY * ld_rows + row] = intensity;
+  rows[PRT_COL_WAVELENGTH * ld_rows + row] = wavelength;
+  rows[PRT_COL_INDEX * ld_rows + row] = index_in;
+  rows[PRT_COL_ID * ld_rows + row] = id;
+  rows[PRT_COL_SURFACE * ld_rows + row] = surface_id;
+  rows[PRT_COL_X0 * ld_rows + row] = r.ox;
+  rows[PRT_COL_Y0 * ld_rows + row] = r.oy;
+  rows[PRT_COL_Z0 * ld_rows + row] = r.oz;
+  rows[PRT_COL_X1 * ld_rows + row] = px;
+  rows[PRT_COL_Y1 * ld_rows + row] = py;
+  rows[PRT_COL_Z1 * ld_rows + row] = pz;
+  rows[PRT_COL_XTILT * ld_rows + row] = r.dx / tilt;
+  rows[PRT_COL_YTILT * ld_rows + row] = r.dy / tilt;
+  rows[PRT_COL_ZTILT * ld_rows + row] = r.dz / tilt;
+
+  if (!carry) return;
+  // next state (_pyrayt.py:437-449): generation + 1, re-launch 1e-6 along the new direction
+  const int64_t j = block_offsets[2 * blockIdx.x + 1] + carry_rank;
+  double qx = px, qy = py, qz = pz, qw = pw;
+  if (relaunch) {
+    qx = px + ray_offset * dx; qy = py + ray_offset * dy; qz = pz + ray_offset * dz;
+    qw = pw + ray_offset * dw;
+  }
+  next[0 * ld_next + j] = qx;
+  next[1 * ld_next + j] = qy;
+  next[2 * ld_next + j] = qz;
+  next[3 * ld_next + j] = qw;
+  next[4 * ld_next + j] = dx;
+  next[5 * ld_next + j] = dy;
+  next[6 * ld_next + j] = dz;
+  next[7 * ld_next + j] = dw;
+  next[8 * ld_next + j] = next_generation;
+  next[9 * ld_next + j] = intensity;
+  next[10 * ld_next + j] = wavelength;
+  next[11 * ld_next + j] = index;
+  next[12 * ld_next + j] = id;
+}
+
+// end of a generation: roll the control block forward
+__global__ void k_advance(TraceCtrl* ctrl, int64_t* __restrict__ rows_per_generation, int generation) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const bool bad = ctrl->error != 0;
+    const int64_t live = bad ? 0 : ctrl->n_live;
+    rows_per_generation[generation] = live;
+    ctrl->row_base += live;
+    ctrl->n_cur = (live == 0) ? 0 : ctrl->n_carry;
+    ctrl->n_live = 0;
+    ctrl->n_carry = 0;
+  }
+}
+
+// component.intersect(): run one component's program and spill its list
+__global__ void __launch_bounds__(PRT_BLOCK)
+k_intersect(SceneDev scene, Operand result, const double* __restrict__ rays, int64_t ld, int64_t n,
+            double* __restrict__ hits, int64_t* __restrict__ ids, int64_t ld_out) {
+  const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const LaneLists lists = lane_lists(scene.lds_slots);
+  const Ray8 r = load_ray8(rays, ld, i);
+  // reuse the interpreter: without an I_ROOT it only builds the lists
+  Pair ra = {PRT_INF, PRT_INF, -1}, rb = {PRT_INF, PRT_INF, -1};
+  for (int pc = 0; pc < scene.n_instr; ++pc) {
+    const DevInstr* __restrict__ in = scene.code + pc;
+    if (in->kind == I_LEAF) {
+      double t0, t1;
+      surface_pair(scene.prims + in->a0, r, t0, t1);
+      if (in->a1 == OPER_REGA) { ra.t0 = t0; ra.t1 = t1; ra.prim = in->a0; }
+      else if (in->a1 == OPER_REGB) { rb.t0 = t0; rb.t1 = t1; rb.prim = in->a0; }
+      else { lists.put(in->a2, t0, in->a0); lists.put(in->a2 + 1, t1, in->a0); }
+    } else if (in->kind == I_CSG) {
+      const Operand L = {in->a1, in->a2, in->a3};
+      const Operand R = {in->a4, in->a5, in->a6};
+      csg_merge(in->a0, L, R, in->a7, box_touched(in->aabb, r), lists, ra, rb);
+    }
+  }
+  for (int k = 0; k < result.len; ++k) {
+    const double v = operand_t(result, lists, ra, rb, k);
+    const int p = operand_id(result, lists, ra, rb, k);
+    hits[k * ld_out + i] = v;
+    ids[k * ld_out + i] = (is_finite(v) && p >= 0) ? (int64_t)scene.prims[p].surface_id : -1;
+  }
+}
+
+__global__ void __launch_bounds__(PRT_BLOCK)
+k_normals(const DevPrim* __restrict__ prim, const double* __restrict__ pts, int64_t ld, int64_t k,
+          double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+  if (i >= k) return;
+  double nx, ny, nz;
+  world_normal(prim, pts[i], pts[ld + i], pts[2 * ld + i], pts[3 * ld + i], nx, ny, nz);
+  out[i] = nx;
+  out[ld + i] = ny;
+  out[2 * ld + i] = nz;
+  out[3 * ld + i] = 0.0 * (double)prim->normal_scale;
+}
+
+__global__ void __launch_bounds__(PRT_BLOCK)
+k_material_trace(const DevPrim* __restrict__ prim, double* __restrict__ rays, int64_t ld, int64_t k) {
+  const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+  if (i >= k) return;
+  const Ray8 r = load_ray8(rays, ld, i);
+  double dx = r.dx, dy = r.dy, dz = r.dz, dw = r.dw, index = rays[11 * ld + i];
+  shade(prim, r.ox, r.oy, r.oz, r.ow, dx, dy, dz, dw, rays[10 * ld + i], index);
+  rays[4 * ld + i] = dx;
+  rays[5 * ld + i] = dy;
+  rays[6 * ld + i] = dz;
+  rays[7 * ld + i] = dw;
+  rays[11 * ld + i] = index;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" int prt_version(void) { return PRT_VERSION; }
+extern "C" const char* prt_last_error(void) { return g_error.c_str(); }
+extern "C" int prt_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+  return count;
+}
+
+static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + PRT_BLOCK - 1) / PRT_BLOCK); }
+static inline size_t lds_bytes(int slots) { return (size_t)slots * PRT_BLOCK * 12; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static SceneDev trace_scene_dev(const prt_scene* s, const DeviceCopy* c) {
+  return SceneDev{c->prims, c->trace_code, (int)s->trace_program.code.size(), s->trace_program.lds_slots};
+}
+
+extern "C" int prt_intersect(prt_scene* s, int device, int root, const double* rays, int64_t n,
+                             int64_t ld, double* hits_out, int64_t* ids_out, int64_t ld_out,
+                             void* stream) {
+  DeviceCopy* c;
+  int rc = on_device(s, device, &c);
+  if (rc) return rc;
+  if (root < 0 || root >= (int)s->roots.size()) return fail(PRT_ERR_ARG, "bad component index");
+  if (n < 0 || ld < n || ld_out < n || (n && (!rays || !hits_out || !ids_out)))
+    return fail(PRT_ERR_ARG, "bad ray / output buffers");
+  if (n == 0) return PRT_OK;
+  const Program& p = s->component_programs[root];
+  SceneDev sd{c->prims, c->component_code[root], (int)p.code.size(), p.lds_slots};
+  hipLaunchKernelGGL(k_intersect, dim3(blocks_for(n)), dim3(PRT_BLOCK), lds_bytes(p.lds_slots),
+                     (hipStream_t)stream, sd, s->component_result[root], rays, ld, n, hits_out,
+                     ids_out, ld_out);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}
+
+extern "C" int prt_propagate(prt_scene* s, int device, const double* rays, int64_t n, int64_t ld,
+                             double* t_out, int64_t* surf_out, void* stream) {
+  DeviceCopy* c;
+  int rc = on_device(s, device, &c);
+  if (rc) return rc;
+  if (n < 0 || ld < n || (n && (!rays || !t_out || !surf_out)))
+    return fail(PRT_ERR_ARG, "bad ray / output buffers");
+  if (n == 0) return PRT_OK;
+  SceneDev sd = trace_scene_dev(s, c);
+  hipLaunchKernelGGL(k_hit, dim3(blocks_for(n)), dim3(PRT_BLOCK), lds_bytes(sd.lds_slots),
+                     (hipStream_t)stream, sd, rays, ld, (const TraceCtrl*)nullptr, n, t_out,
+                     (int32_t*)nullptr, surf_out, (int32_t*)nullptr, 1);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}
+
+extern "C" int prt_world_normals(prt_scene* s, int device, int prim, const double* points,
+                                 int64_t k, int64_t ld, double* normals_out, void* stream) {
+  DeviceCopy* c;
+  int rc = on_device(s, device, &c);
+  if (rc) return rc;
+  if (prim < 0 || prim >= (int)s->prims.size()) return fail(PRT_ERR_ARG, "bad primitive index");
+  if (k < 0 || ld < k || (k && (!points || !normals_out))) return fail(PRT_ERR_ARG, "bad buffers");
+  if (k == 0) return PRT_OK;
+  hipLaunchKernelGGL(k_normals, dim3(blocks_for(k)), dim3(PRT_BLOCK), 0, (hipStream_t)stream,
+                     c->prims + prim, points, ld, k, normals_out);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}
+
+extern "C" int prt_material_trace(prt_scene* s, int device, int prim, double* rays, int64_t k,
+                                  int64_t ld, void* stream) {
+  DeviceCopy* c;
+  int rc = on_device(s, device, &c);
+  if (rc) return rc;
+  if (prim < 0 || prim >= (int)s->prims.size()) return fail(PRT_ERR_ARG, "bad primitive index");
+  if (s->dev_prims[prim].mat_kind == MAT_NONE)
+    return fail(PRT_ERR_UNTRACABLE, "surface " + std::to_string(s->prims[prim].surface_id) +
+                                        " has a material without trace()");
+  if (k < 0 || ld < k || (k && !rays)) return fail(PRT_ERR_ARG, "bad buffers");
+  if (k == 0) return PRT_OK;
+  hipLaunchKernelGGL(k_material_trace, dim3(blocks_for(k)), dim3(PRT_BLOCK), 0,
+                     (hipStream_t)stream, c->prims + prim, rays, ld, k);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}
+
+// workspace of prt_interact: ctrl | block counts (2 x int32) | block offsets (2 x int64) | hit_t
+struct InteractLayout {
+  size_t ctrl, counts, offsets, total;
+};
+static InteractLayout interact_layout(int64_t n) {
+  const size_t nb = blocks_for(n) + 1;
+  InteractLayout l;
+  l.ctrl = 0;
+  l.counts = align_up(sizeof(TraceCtrl), 256);
+  l.offsets = l.counts + align_up(nb * 2 * sizeof(int32_t), 256);
+  l.total = l.offsets + align_up(nb * 2 * sizeof(int64_t), 256);
+  return l;
+}
+
+extern "C" int64_t prt_interact_workspace_bytes(int64_t n) {
+  return (int64_t)interact_layout(n < 0 ? 0 : n).total;
+}
+
+// live / carried counts for prt_interact, where the hits come from the caller
+__global__ void __launch_bounds__(PRT_BLOCK)
+k_count(SceneDev scene, int n_prims, const double* __restrict__ rays, int64_t ld, int64_t n,
+        const int64_t* __restrict__ surf, int32_t* __restrict__ block_counts) {
+  const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+  bool live = false;
+  if (i < n) {
+    const Ray8 r = load_ray8(rays, ld, i);
+    live = is_live(r, prim_of_surface(scene.prims, n_prims, surf[i]));
+  }
+  __shared__ int s_live;
+  if (threadIdx.x == 0) s_live = 0;
+  __syncthreads();
+  const int w = __popcll(__ballot(live));
+  if ((threadIdx.x & 63) == 0) atomicAdd(&s_live, w);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    block_counts[2 * blockIdx.x] = s_live;
+    block_counts[2 * blockIdx.x + 1] = s_live;  // the stepwise API keeps absorbed rays (Q3)
+  }
+}
+
+__global__ void k_ctrl_init(TraceCtrl* ctrl, int64_t n, int64_t rows_cap) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    ctrl->n_cur = n; ctrl->n_live = 0; ctrl->n_carry = 0; ctrl->row_base = 0;
+    ctrl->rows_cap = rows_cap; ctrl->error = 0; ctrl->pad = 0;
+  }
+}
+
+__global__ void k_interact_finish(const TraceCtrl* ctrl, int64_t* n_live_out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    *n_live_out = ctrl->error ? (int64_t)ctrl->error : ctrl->n_live;
+}
+
+extern "C" int prt_interact(prt_scene* s, int device, const double* rays_in, int64_t n,
+                            int64_t ld_in, const double* t, const int64_t* surf, double* rays_out,
+                            int64_t ld_out, int generation, int generation_limit, double ray_offset,
+                            double* rows_out, int64_t ld_rows, int64_t* n_live_out, void* workspace,
+                            void* stream) {
+  DeviceCopy* c;
+  int rc = on_device(s, device, &c);
+  if (rc) return rc;
+  if (n < 0 || ld_in < n || ld_out < n || ld_rows < n || !n_live_out || !workspace ||
+      (n && (!rays_in || !t || !surf || !rays_out || !rows_out)))
+    return fail(PRT_ERR_ARG, "bad buffers");
+  hipStream_t st = (hipStream_t)stream;
+  const InteractLayout l = interact_layout(n);
+  char* w = (char*)workspace;
+  TraceCtrl* ctrl = (TraceCtrl*)(w + l.ctrl);
+  int32_t* counts = (int32_t*)(w + l.counts);
+  int64_t* offsets = (int64_t*)(w + l.offsets);
+  hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, st, ctrl, n, ld_rows);
+  if (n > 0) {
+    SceneDev sd{c->prims, nullptr, (int)s->prims.size(), 0};
+    hipLaunchKernelGGL(k_count, dim3(blocks_for(n)), dim3(PRT_BLOCK), 0, st, sd,
+                       (int)s->prims.size(), rays_in, ld_in, n, surf, counts);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, counts, offsets, ctrl);
+    const int relaunch = (generation + 1 != generation_limit) ? 1 : 0;
+    hipLaunchKernelGGL(k_shade, dim3(blocks_for(n)), dim3(PRT_BLOCK), 0, st, sd, rays_in, ld_in,
+                       (const TraceCtrl*)ctrl, n, t, (const int32_t*)nullptr, surf,
+                       (const int64_t*)offsets, rays_out, ld_out, rows_out, ld_rows, (int64_t)0,
+                       (double)(generation + 1), relaunch, ray_offset, 1, ctrl);
+  }
+  hipLaunchKernelGGL(k_interact_finish, dim3(1), dim3(1), 0, st, (const TraceCtrl*)ctrl, n_live_out);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}
+
+// workspace of prt_trace:
+//   ctrl | rows_per_generation (device, 1024 x int64) | block counts | block offsets
+//   | hit_t (n f64) | hit_prim (n i32) | ray buffer A (13 n) | ray buffer B (13 n)
+static const int kMaxGenerationSlots = 1024;
+struct TraceLayout {
+  size_t ctrl, gen_rows, counts, offsets, hit_t, hit_prim, rays_a, rays_b, total;
+};
+static TraceLayout trace_layout(int64_t n) {
+  const size_t nb = blocks_for(n) + 1;
+  const size_t nn = (size_t)(n < 1 ? 1 : n);
+  TraceLayout l;
+  l.ctrl = 0;
+  l.gen_rows = align_up(sizeof(TraceCtrl), 256);
+  l.counts = l.gen_rows + align_up(kMaxGenerationSlots * sizeof(int64_t), 256);
+  l.offsets = l.counts + align_up(nb * 2 * sizeof(int32_t), 256);
+  l.hit_t = l.offsets + align_up(nb * 2 * sizeof(int64_t), 256);
+  l.hit_prim = l.hit_t + align_up(nn * sizeof(double), 256);
+  l.rays_a = l.hit_prim + align_up(nn * sizeof(int32_t), 256);
+  l.rays_b = l.rays_a + align_up(nn * PRT_RAY_ROWS * sizeof(double), 256);
+  l.total = l.rays_b + align_up(nn * PRT_RAY_ROWS * sizeof(double), 256);
+  return l;
+}
+
+extern "C" int64_t prt_trace_workspace_bytes(int64_t n) {
+  return (int64_t)trace_layout(n < 0 ? 0 : n).total;
+}
+
+extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64_t n, int64_t ld,
+                             int generation_limit, double ray_offset, double* rows_out,
+                             int64_t rows_cap, int64_t* rows_per_generation, void* workspace,
+                             int flags, void* stream) {
+  DeviceCopy* c;
+  int rc = on_device(s, device, &c);
+  if (rc) return rc;
+  if (n < 0 || ld < n || generation_limit < 0 || rows_cap < 0 || !rows_per_generation ||
+      !workspace || (n && !rays) || (rows_cap && !rows_out))
+    return fail(PRT_ERR_ARG, "bad buffers");
+  for (int g = 0; g < generation_limit; ++g) rows_per_generation[g] = 0;
+  s->stats[0] = s->stats[1] = s->stats[2] = s->stats[3] = 0;
+  if (n == 0 || generation_limit == 0) return 0;
+
+  hipStream_t st = (hipStream_t)stream;
+  const TraceLayout l = trace_layout(n);
+  char* w = (char*)workspace;
+  TraceCtrl* ctrl = (TraceCtrl*)(w + l.ctrl);
+  int64_t* gen_rows = (int64_t*)(w + l.gen_rows);
+  int32_t* counts = (int32_t*)(w + l.counts);
+  int64_t* offsets = (int64_t*)(w + l.offsets);
+  double* hit_t = (double*)(w + l.hit_t);
+  int32_t* hit_prim = (int32_t*)(w + l.hit_prim);
+  double* buf[2] = {(double*)(w + l.rays_a), (double*)(w + l.rays_b)};
+  const int keep_absorbed = (flags & PRT_TRACE_KEEP_ABSORBED) ? 1 : 0;
+
+  SceneDev sd = trace_scene_dev(s, c);
+  const size_t lds = lds_bytes(sd.lds_slots);
+  hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, st, ctrl, n, rows_cap);
+
+  const double* src = rays;
+  int64_t src_ld = ld;
+  int64_t n_cur = n, total_rows = 0;
+  int error = 0;
+  for (int g = 0; g < generation_limit && n_cur > 0; ++g) {
+    double* dst = buf[g & 1];
+    const unsigned nb = blocks_for(n_cur);
+    const int relaunch = (g + 1 != generation_limit) ? 1 : 0;
+    HIP_TRY(hipEventRecord(c->ev0, st));
+    hipLaunchKernelGGL(k_hit, dim3(nb), dim3(PRT_BLOCK), lds, st, sd, src, src_ld,
+                       (const TraceCtrl*)ctrl, (int64_t)0, hit_t, hit_prim, (int64_t*)nullptr,
+                       counts, keep_absorbed);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, (const int32_t*)counts, offsets, ctrl);
+    hipLaunchKernelGGL(k_shade, dim3(nb), dim3(PRT_BLOCK), 0, st, sd, src, src_ld,
+                       (const TraceCtrl*)ctrl, (int64_t)0, (const double*)hit_t,
+                       (const int32_t*)hit_prim, (const int64_t*)nullptr, (const int64_t*)offsets,
+                       dst, n, rows_out, rows_cap, (int64_t)0, (double)(g + 1), relaunch,
+                       ray_offset, keep_absorbed, ctrl);
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, st, ctrl, gen_rows, g);
+    HIP_TRY(hipEventRecord(c->ev1, st));
+    // the host needs the new ray count to size the next launch
+    HIP_TRY(hipMemcpyAsync(c->host_pinned, ctrl, sizeof(TraceCtrl), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(c->host_pinned + 6, gen_rows + g, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    const TraceCtrl* h = (const TraceCtrl*)c->host_pinned;
+    s->stats[0] += 1;
+    s->stats[1] += (double)n_cur;
+    s->stats[2] += ms;
+    s->stats[3] += 4;
+    if (h->error) { error = h->error; break; }
+    const int64_t live = c->host_pinned[6];
+    rows_per_generation[g] = live;
+    total_rows += live;
+    n_cur = h->n_cur;
+    src = dst;
+    src_ld = n;
+  }
+  if (error == PRT_ERR_ROWS_CAP) return fail(PRT_ERR_ROWS_CAP, "rows_cap too small");
+  if (error == PRT_ERR_UNTRACABLE)
+    return fail(PRT_ERR_UNTRACABLE, "a ray hit a surface whose material has no trace()");
+  if (error) return fail(error, "device error during trace");
+  return total_rows;
+}
+
+extern "C" int prt_trace_stats(const prt_scene* s, double* out4) {
+  if (!s || !out4) return fail(PRT_ERR_ARG, "null argument");
+  for (int k = 0; k < 4; ++k) out4[k] = s->stats[k];
+  return PRT_OK;
+}
