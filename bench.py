@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- ray-surface intersections/sec on the north-star workload (BASELINE.json config 2).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One *step* = one pass of the hot path (every generation: intersect + nearest hit + shade +
+compaction + record rows) over one batch of 1,000,000 rays per GPU that is already resident
+in HBM.  The metric counts result rows (one row = one ray segment resolved to its nearest
+surface and shaded), aggregated over all ranks, divided by the max-over-ranks wall time of
+the K timed steps (barrier + synchronize on both sides).
+
+Scaling is weak: every rank traces its own 1M-ray contiguous id range of an N x 1M-ray job
+(rays are independent, the trace needs no collective).  The re-assembly of the result frame
+(one RCCL all-gather, pyrayt_amd.distributed) is exercised and timed separately after the
+timed region and reported under "gather" -- it is not part of `value`.
+
+rank 0 prints ONE JSON line.  `roofline` is for the generation kernel(s): algorithmic bytes
+(328 B per ray alive at generation entry) over the HIP-event time of
+those launches measured inside the library on the launch stream.  `cpu_baseline` is the numpy
+oracle (a port of the reference's path, validated against it) timed on this host, rank 0, N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+RAYS_PER_GPU = 1_000_000
+GENERATION_LIMIT = 10
+BYTES_PER_RAY_GENERATION = 328  # 104 B state read + 104 B state write + 120 B record row
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=RAYS_PER_GPU, help="rays per GPU")
+    ap.add_argument("--flags", type=int, default=0, help="PRT_TRACE_* flags")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=1_000_000,
+                    help="rays of the same workload timed on the CPU oracle")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+
+    import scenes
+    from pyrayt_amd import distributed as pdist
+    from pyrayt_amd import engine
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world:
+        if rank == 0 and distributed:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        if not distributed and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    # the workload: config 2, this rank's contiguous id range of a (world x rays) job
+    n = args.rays
+    CountedObject.reset_ids()
+    parts, rays = scenes.config2(scenes.product_api(), n, seed=1234 + rank)
+    rays[12] += rank * n
+    snap = SceneSnapshot(parts)
+    scene = engine.DeviceScene(snap)
+    rays_dev = torch.from_numpy(rays).to(device)
+
+    def step():
+        return scene.trace(rays_dev, GENERATION_LIMIT, flags=args.flags)
+
+    for _ in range(args.warmup):
+        rows, counts = step()
+    torch.cuda.synchronize(device)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    kernel_ms = launches = ray_generations = 0.0
+    for _ in range(args.steps):
+        rows, counts = step()
+        st = scene.trace_stats()
+        kernel_ms += st["kernel_ms"]
+        launches += st["kernel_launches"]
+        ray_generations += st["ray_generations"]
+    torch.cuda.synchronize(device)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+
+    rows_per_step = int(rows.shape[1])
+    if distributed:
+        agg = torch.tensor([elapsed, float(rows_per_step)], dtype=torch.float64, device=device)
+        tmax = agg.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        total_rows_per_step = float(agg[1])
+    else:
+        total_rows_per_step = float(rows_per_step)
+
+    # frame re-assembly (not in the timed region): one all-gather, checked for row count
+    gather = None
+    if distributed:
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        g0 = time.perf_counter()
+        full, full_counts = pdist.assemble_rows(rows, counts, GENERATION_LIMIT, dist.group.WORLD, "all")
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        gather_s = time.perf_counter() - g0
+        assert full.shape[1] == int(total_rows_per_step)
+        gather = {"ms": gather_s * 1e3, "rows": int(full.shape[1]),
+                  "GB_into_each_gpu": full.shape[1] * 120 * (world - 1) / world / 1e9}
+
+    # PCIe-inclusive end-to-end trace() on rank 0 (H2D rays, trace, D2H rows, DataFrame)
+    end_to_end = None
+    if rank == 0:
+        from pyrayt_amd.tracer import rows_to_frame
+
+        torch.cuda.synchronize(device)
+        e0 = time.perf_counter()
+        up = torch.from_numpy(rays).to(device)
+        r2, _ = scene.trace(up, GENERATION_LIMIT, flags=args.flags)
+        frame = rows_to_frame(r2)
+        e1 = time.perf_counter()
+        end_to_end = {"ms": (e1 - e0) * 1e3, "rows_per_s": frame.shape[0] / (e1 - e0)}
+
+    if rank != 0:
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    value = total_rows_per_step * args.steps / elapsed
+    algorithmic_bytes = ray_generations * BYTES_PER_RAY_GENERATION
+    achieved = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    line = {
+        "metric": "ray-surface intersections/sec, 1M-ray biconvex lens",
+        "value": value,
+        "unit": "intersections/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE config 2: biconvex_lens(2,2,0.25,aperture=1) + detector baffle, "
+                        f"{n} rays per GPU from a seeded 6 degree cone at -f, generation_limit "
+                        f"{GENERATION_LIMIT}, rays resident in HBM",
+            "rays_per_gpu": n,
+            "rows_per_step_per_gpu": rows_per_step,
+            "rows_per_generation": counts,
+            "trace_flags": args.flags,
+            "parallelism": f"ray data-parallel x{world}, no collective in the timed region",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": "generation pipeline (see profiles/)",
+            "algorithmic_bytes_per_launch": algorithmic_bytes / launches if launches else 0,
+            "avg_launch_ms": kernel_ms / launches if launches else 0,
+            "kernel_ms_per_step": kernel_ms / args.steps,
+        },
+        "end_to_end_trace": end_to_end,
+    }
+    if gather:
+        line["gather"] = gather
+
+    if not args.no_cpu_baseline and world == 1:
+        from oracle import prt_oracle
+        import helpers
+
+        m = min(args.cpu_rays, n)
+        sample = np.ascontiguousarray(rays[:, :m])
+        flat = helpers.flat_scene(snap)
+        c0 = time.perf_counter()
+        frame, _ = prt_oracle.trace(flat, sample, GENERATION_LIMIT)
+        cpu_s = time.perf_counter() - c0
+        line["cpu_baseline"] = {
+            "value": frame.shape[0] / cpu_s,
+            "unit": "intersections/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": f"numpy oracle (oracle/prt_oracle.py) on the first {m} rays of the same "
+                      f"workload, {frame.shape[0]} rows in {cpu_s:.1f} s, single process like "
+                      f"the reference; host has {os.cpu_count()} logical CPUs",
+        }
+    print(json.dumps(line), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -365,17 +365,25 @@ __device__ __forceinline__ bool shade(const DevPrim* __restrict__ p, double px, 
 }
 
 // ---- per-lane hit lists in LDS -------------------------------------------------------------------
-// Slot s of lane `tid` lives at t[s * PRT_BLOCK + tid] / id[s * PRT_BLOCK + tid]: a lane's
-// slots are PRT_BLOCK elements apart, so whatever (per-lane, data dependent) slot index the
-// lanes of a wave use, lane l always touches bank (2l mod 64): conflict free by construction.
+// Slot s of lane `tid` lives at lds_dyn[s * PRT_BLOCK + tid] (float64 parameter) and, behind
+// the `slots` parameter rows, at the same position of an int32 array (primitive index): a
+// lane's slots are PRT_BLOCK elements apart, so whatever (per-lane, data dependent) slot index
+// the lanes of a wave use, lane l always touches bank (2l mod 64): conflict free by
+// construction.  Accesses go through the __shared__ array itself so that they compile to
+// ds_read/ds_write (a pointer kept in a struct degrades them to flat_load/flat_store).
+extern __shared__ double lds_dyn[];
+
 struct LaneLists {
-  double* t;
-  int* id;
-  __device__ __forceinline__ double get_t(int slot) const { return t[slot * PRT_BLOCK]; }
-  __device__ __forceinline__ int get_id(int slot) const { return id[slot * PRT_BLOCK]; }
+  int slots;  // number of slots (rows) per lane
+  __device__ __forceinline__ double get_t(int slot) const {
+    return lds_dyn[slot * PRT_BLOCK + threadIdx.x];
+  }
+  __device__ __forceinline__ int get_id(int slot) const {
+    return reinterpret_cast<const int*>(lds_dyn + slots * PRT_BLOCK)[slot * PRT_BLOCK + threadIdx.x];
+  }
   __device__ __forceinline__ void put(int slot, double v, int i) const {
-    t[slot * PRT_BLOCK] = v;
-    id[slot * PRT_BLOCK] = i;
+    lds_dyn[slot * PRT_BLOCK + threadIdx.x] = v;
+    reinterpret_cast<int*>(lds_dyn + slots * PRT_BLOCK)[slot * PRT_BLOCK + threadIdx.x] = i;
   }
 };
 
@@ -387,8 +395,9 @@ struct Operand {
 __device__ __forceinline__ double operand_t(const Operand& o, const LaneLists& l, const Pair& a,
                                             const Pair& b, int i) {
   if (o.mode == OPER_LDS) return l.get_t(o.base + i);
-  const Pair& p = (o.mode == OPER_REGA) ? a : b;
-  return i == 0 ? p.t0 : p.t1;
+  const double first = (o.mode == OPER_REGA) ? a.t0 : b.t0;
+  const double second = (o.mode == OPER_REGA) ? a.t1 : b.t1;
+  return i == 0 ? first : second;
 }
 __device__ __forceinline__ int operand_id(const Operand& o, const LaneLists& l, const Pair& a,
                                           const Pair& b, int i) {

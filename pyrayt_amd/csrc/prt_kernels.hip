@@ -64,6 +64,7 @@ struct DeviceCopy {
   DevInstr* trace_code = nullptr;               // all components, each ending in I_ROOT
   std::vector<DevInstr*> component_code;        // one program per component, no I_ROOT
   int64_t* host_pinned = nullptr;               // 8 x int64 pinned staging
+  struct GenCtrl* host_gen = nullptr;           // pinned read-back of one batch of slots
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -279,6 +280,7 @@ extern "C" void prt_scene_destroy(prt_scene* s) {
     (void)hipFree(c.trace_code);
     for (DevInstr* p : c.component_code) (void)hipFree(p);
     if (c.host_pinned) (void)hipHostFree(c.host_pinned);
+    if (c.host_gen) (void)hipHostFree(c.host_gen);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
   }
@@ -320,6 +322,7 @@ static int on_device(prt_scene* s, int device, DeviceCopy** out) {
       c.component_code.push_back(code);
     }
     HIP_TRY(hipHostMalloc((void**)&c.host_pinned, 8 * sizeof(int64_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&c.host_gen, 16 * 64, hipHostMallocDefault));
     HIP_TRY(hipEventCreate(&c.ev0));
     HIP_TRY(hipEventCreate(&c.ev1));
   }
@@ -330,14 +333,7 @@ static int on_device(prt_scene* s, int device, DeviceCopy** out) {
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-extern __shared__ double lds_dyn[];
-
-__device__ __forceinline__ LaneLists lane_lists(int slots) {
-  LaneLists l;
-  l.t = lds_dyn + threadIdx.x;
-  l.id = reinterpret_cast<int*>(lds_dyn + (size_t)slots * PRT_BLOCK) + threadIdx.x;
-  return l;
-}
+__device__ __forceinline__ LaneLists lane_lists(int slots) { return LaneLists{slots}; }
 
 __device__ __forceinline__ Ray8 load_ray8(const double* __restrict__ rays, int64_t ld, int64_t i) {
   Ray8 r;
@@ -469,6 +465,83 @@ __device__ __forceinline__ int block_rank(bool flag, int* s_wave /*[4]*/) {
   return base + before;
 }
 
+// One live ray through INTERACT (_pyrayt.py:394-452) and the record writer (:168-186):
+// advance to the hit point, shade by the material of the primitive hit, write the record row
+// at column `row` and -- if the ray goes on -- its next state at column `j`.
+// Returns false if the surface hit has an untracable material.
+__device__ __forceinline__ bool interact_lane(const SceneDev& scene, const double* __restrict__ rays,
+                                              int64_t ld, int64_t i, const Ray8& r, double t, int prim,
+                                              bool carry, int64_t row, int64_t j,
+                                              double* __restrict__ next, int64_t ld_next,
+                                              double* __restrict__ rows, int64_t ld_rows,
+                                              double next_generation, int relaunch, double ray_offset) {
+  const double generation = rays[8 * ld + i];
+  const double intensity = rays[9 * ld + i];
+  const double wavelength = rays[10 * ld + i];
+  const double index_in = rays[11 * ld + i];
+  const double id = rays[12 * ld + i];
+
+  // advance to the hit point: o += d * t, all four homogeneous components (_pyrayt.py:404-407)
+  const double px = r.ox + r.dx * t, py = r.oy + r.dy * t, pz = r.oz + r.dz * t,
+               pw = r.ow + r.dw * t;
+  double dx = r.dx, dy = r.dy, dz = r.dz, dw = r.dw, index = index_in, surface_id = -1.0;
+  // material dispatch: the primitive table is wave-uniform data, so lanes that hit the same
+  // surface shade together and the loop runs once per distinct surface hit in the wave
+  unsigned long long todo = __ballot(true);
+  bool ok = true;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int cur = __shfl(prim, leader);
+    if (prim == cur) {
+      const DevPrim* __restrict__ p = scene.prims + cur;
+      ok = shade(p, px, py, pz, pw, dx, dy, dz, dw, wavelength, index);
+      surface_id = p->surface_id;
+    }
+    todo &= ~__ballot(prim == cur);
+  }
+
+  // record row (_pyrayt.py:168-186): pre-hit metadata, surface, start, end, unit tilt
+  const double tilt = norm3(r.dx, r.dy, r.dz);
+  rows[PRT_COL_GENERATION * ld_rows + row] = generation;
+  rows[PRT_COL_INTENSITY * ld_rows + row] = intensity;
+  rows[PRT_COL_WAVELENGTH * ld_rows + row] = wavelength;
+  rows[PRT_COL_INDEX * ld_rows + row] = index_in;
+  rows[PRT_COL_ID * ld_rows + row] = id;
+  rows[PRT_COL_SURFACE * ld_rows + row] = surface_id;
+  rows[PRT_COL_X0 * ld_rows + row] = r.ox;
+  rows[PRT_COL_Y0 * ld_rows + row] = r.oy;
+  rows[PRT_COL_Z0 * ld_rows + row] = r.oz;
+  rows[PRT_COL_X1 * ld_rows + row] = px;
+  rows[PRT_COL_Y1 * ld_rows + row] = py;
+  rows[PRT_COL_Z1 * ld_rows + row] = pz;
+  rows[PRT_COL_XTILT * ld_rows + row] = r.dx / tilt;
+  rows[PRT_COL_YTILT * ld_rows + row] = r.dy / tilt;
+  rows[PRT_COL_ZTILT * ld_rows + row] = r.dz / tilt;
+
+  if (carry) {
+    // next state (_pyrayt.py:437-449): generation + 1, re-launch 1e-6 along the new direction
+    double qx = px, qy = py, qz = pz, qw = pw;
+    if (relaunch) {
+      qx = px + ray_offset * dx; qy = py + ray_offset * dy; qz = pz + ray_offset * dz;
+      qw = pw + ray_offset * dw;
+    }
+    next[0 * ld_next + j] = qx;
+    next[1 * ld_next + j] = qy;
+    next[2 * ld_next + j] = qz;
+    next[3 * ld_next + j] = qw;
+    next[4 * ld_next + j] = dx;
+    next[5 * ld_next + j] = dy;
+    next[6 * ld_next + j] = dz;
+    next[7 * ld_next + j] = dw;
+    next[8 * ld_next + j] = next_generation;
+    next[9 * ld_next + j] = intensity;
+    next[10 * ld_next + j] = wavelength;
+    next[11 * ld_next + j] = index;
+    next[12 * ld_next + j] = id;
+  }
+  return ok;
+}
+
 // [_st_interact + _RayTraceDataframe.insert]
 __global__ void __launch_bounds__(PRT_BLOCK)
 k_shade(SceneDev scene, const double* __restrict__ rays, int64_t ld, const TraceCtrl* __restrict__ ctrl_in,
@@ -501,72 +574,10 @@ k_shade(SceneDev scene, const double* __restrict__ rays, int64_t ld, const Trace
   const int carry_rank = block_rank(carry, s_wave);
   if (!live) return;
 
-  const double generation = rays[8 * ld + i];
-  const double intensity = rays[9 * ld + i];
-  const double wavelength = rays[10 * ld + i];
-  const double index_in = rays[11 * ld + i];
-  const double id = rays[12 * ld + i];
-
-  // advance to the hit point: o += d * t, all four homogeneous components (_pyrayt.py:404-407)
-  const double px = r.ox + r.dx * t, py = r.oy + r.dy * t, pz = r.oz + r.dz * t,
-               pw = r.ow + r.dw * t;
-  double dx = r.dx, dy = r.dy, dz = r.dz, dw = r.dw, index = index_in, surface_id = -1.0;
-  // material dispatch: the primitive table is wave-uniform data, so lanes that hit the same
-  // surface shade together and the loop runs once per distinct surface hit in the wave
-  unsigned long long todo = __ballot(true);
-  bool ok = true;
-  while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const int cur = __shfl(prim, leader);
-    if (prim == cur) {
-      const DevPrim* __restrict__ p = scene.prims + cur;
-      ok = shade(p, px, py, pz, pw, dx, dy, dz, dw, wavelength, index);
-      surface_id = p->surface_id;
-    }
-    todo &= ~__ballot(prim == cur);
-  }
-  if (!ok) atomicExch(&ctrl->error, PRT_ERR_UNTRACABLE);
-
-  // record row (_pyrayt.py:168-186): pre-hit metadata, surface, start, end, unit tilt
-  const int64_t row = row_base + block_offsets[2 * blockIdx.x] + live_rank;
-  const double tilt = norm3(r.dx, r.dy, r.dz);
-  rows[PRT_COL_GENERATION * ld_rows + row] = generation;
-  rows[PRT_COL_INTENSITY * ld_rows + row] = intensity;
-  rows[PRT_COL_WAVELENGTH * ld_rows + row] = wavelength;
-  rows[PRT_COL_INDEX * ld_rows + row] = index_in;
-  rows[PRT_COL_ID * ld_rows + row] = id;
-  rows[PRT_COL_SURFACE * ld_rows + row] = surface_id;
-  rows[PRT_COL_X0 * ld_rows + row] = r.ox;
-  rows[PRT_COL_Y0 * ld_rows + row] = r.oy;
-  rows[PRT_COL_Z0 * ld_rows + row] = r.oz;
-  rows[PRT_COL_X1 * ld_rows + row] = px;
-  rows[PRT_COL_Y1 * ld_rows + row] = py;
-  rows[PRT_COL_Z1 * ld_rows + row] = pz;
-  rows[PRT_COL_XTILT * ld_rows + row] = r.dx / tilt;
-  rows[PRT_COL_YTILT * ld_rows + row] = r.dy / tilt;
-  rows[PRT_COL_ZTILT * ld_rows + row] = r.dz / tilt;
-
-  if (!carry) return;
-  // next state (_pyrayt.py:437-449): generation + 1, re-launch 1e-6 along the new direction
-  const int64_t j = block_offsets[2 * blockIdx.x + 1] + carry_rank;
-  double qx = px, qy = py, qz = pz, qw = pw;
-  if (relaunch) {
-    qx = px + ray_offset * dx; qy = py + ray_offset * dy; qz = pz + ray_offset * dz;
-    qw = pw + ray_offset * dw;
-  }
-  next[0 * ld_next + j] = qx;
-  next[1 * ld_next + j] = qy;
-  next[2 * ld_next + j] = qz;
-  next[3 * ld_next + j] = qw;
-  next[4 * ld_next + j] = dx;
-  next[5 * ld_next + j] = dy;
-  next[6 * ld_next + j] = dz;
-  next[7 * ld_next + j] = dw;
-  next[8 * ld_next + j] = next_generation;
-  next[9 * ld_next + j] = intensity;
-  next[10 * ld_next + j] = wavelength;
-  next[11 * ld_next + j] = index;
-  next[12 * ld_next + j] = id;
+  if (!interact_lane(scene, rays, ld, i, r, t, prim, carry, row_base + block_offsets[2 * blockIdx.x] + live_rank,
+                     block_offsets[2 * blockIdx.x + 1] + carry_rank, next, ld_next, rows, ld_rows,
+                     next_generation, relaunch, ray_offset))
+    atomicExch(&ctrl->error, PRT_ERR_UNTRACABLE);
 }
 
 // end of a generation: roll the control block forward
@@ -580,6 +591,187 @@ __global__ void k_advance(TraceCtrl* ctrl, int64_t* __restrict__ rows_per_genera
     ctrl->n_live = 0;
     ctrl->n_carry = 0;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused generation: PROPAGATE + INTERACT + record in ONE launch, one pass over HBM
+// ------------------------------------------------------------------------------------------------
+// per-generation control slot (device memory).  Generation g reads slot g and its last tile
+// fills slot g+1, so consecutive generations chain on the stream with no host round trip.
+struct GenCtrl {
+  int64_t n_in;      // rays alive at entry
+  int64_t row_base;  // first record column of this generation
+  int64_t n_live;    // rows recorded by this generation
+  int64_t n_carry;   // rays handed to the next generation
+  uint32_t pad[8];
+};
+struct FusedCtrl {
+  int32_t error;
+  int32_t pad;
+  int64_t rows_cap;
+};
+
+#define PRT_ERR_STALL (-100) /* internal: look-back gave up -> host falls back to the unfused path */
+
+// tile status word for the decoupled look-back: [63:62] status, [61:31] live, [30:0] carried.
+// One naturally aligned 8-byte word written by one agent-scope store: payload and flag cannot
+// be observed torn, so no fence is needed around it.
+#define TILE_INVALID 0ull
+#define TILE_AGGREGATE 1ull
+#define TILE_PREFIX 2ull
+__device__ __forceinline__ unsigned long long tile_pack(unsigned long long status, unsigned live,
+                                                        unsigned carry) {
+  return (status << 62) | ((unsigned long long)live << 31) | (unsigned long long)carry;
+}
+__device__ __forceinline__ void tile_store(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long tile_load(unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Exclusive prefix of (live, carry) over all tiles before `tile`; called by one full wave.
+// Lane l inspects tile (base - l).  The wave consumes the contiguous run of published words
+// nearest to it -- up to and including the first inclusive prefix -- and moves on; if the
+// nearest predecessor has not published yet it backs off with s_sleep and polls again.
+// Tiles are numbered by blockIdx.x: the dispatcher starts workgroups in index order, so
+// every predecessor is resident (or finished) before its successors and publishes without
+// waiting on anything behind it.  That ordering is not an architectural guarantee, so the spin
+// is bounded: on expiry the wave reports failure and the host re-runs the generation loop on
+// the three-kernel path, which has no inter-workgroup dependency.
+__device__ __forceinline__ bool lookback(unsigned long long* state, int tile, unsigned agg_live,
+                                         unsigned agg_carry, unsigned& excl_live,
+                                         unsigned& excl_carry) {
+  const int lane = threadIdx.x & 63;
+  unsigned sum_live = 0, sum_carry = 0;
+  int base = tile - 1;
+  int idle = 0;
+  bool ok = true;
+  while (base >= 0) {
+    const int idx = base - lane;
+    unsigned long long w = tile_pack(TILE_PREFIX, 0, 0);  // before tile 0: empty prefix
+    if (idx >= 0) w = tile_load(state + idx);
+    const unsigned long long status = w >> 62;
+    const unsigned long long pending = __ballot(status == TILE_INVALID);
+    const unsigned long long prefix = __ballot(status == TILE_PREFIX);
+    // lanes [0, run) have published; stop after the first inclusive prefix among them
+    int run = pending ? (__ffsll((long long)pending) - 1) : 64;
+    bool closed = false;
+    if (prefix) {
+      const int first = __ffsll((long long)prefix) - 1;
+      if (first < run) { run = first + 1; closed = true; }
+    }
+    if (run == 0) {
+      if (++idle > (1 << 20)) { ok = false; break; }
+      __builtin_amdgcn_s_sleep(8);
+      continue;
+    }
+    unsigned l = (lane < run) ? (unsigned)((w >> 31) & 0x7fffffffull) : 0u;
+    unsigned c = (lane < run) ? (unsigned)(w & 0x7fffffffull) : 0u;
+    for (int off = 32; off > 0; off >>= 1) {
+      l += __shfl_xor(l, off);
+      c += __shfl_xor(c, off);
+    }
+    sum_live += l;
+    sum_carry += c;
+    if (closed) break;
+    base -= run;
+  }
+  excl_live = sum_live;
+  excl_carry = sum_carry;
+  if (lane == 0) tile_store(state + tile, tile_pack(TILE_PREFIX, sum_live + agg_live, sum_carry + agg_carry));
+  return ok;
+}
+
+__global__ void __launch_bounds__(PRT_BLOCK)
+k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double* __restrict__ next,
+             int64_t ld_next, double* __restrict__ rows, int64_t ld_rows, FusedCtrl* __restrict__ ctrl,
+             GenCtrl* __restrict__ gen, int g, unsigned long long* __restrict__ tiles_cur,
+             unsigned long long* __restrict__ tiles_next, double next_generation, int relaunch,
+             double ray_offset, int keep_absorbed) {
+  __shared__ int s_wave_live[4], s_wave_carry[4];
+  __shared__ unsigned s_excl[2];
+  // A ticket from one atomic word would also give start-ordered tile numbers, but a single
+  // word hands out only ~80 tickets/us chip-wide: 4k tiles would cost ~50 us per generation.
+  const int tile = blockIdx.x;
+  const int64_t n = gen[g].n_in;
+  if ((int64_t)tile * PRT_BLOCK >= n) return;  // uniform per workgroup; never a predecessor
+  // A tile that sees an error raised earlier does no work but MUST still publish its (empty)
+  // aggregate: tiles behind it may already be waiting on it.
+  const bool failed = ctrl->error != 0;
+  const int64_t row_base = gen[g].row_base;
+  if (threadIdx.x == 0) tiles_next[tile] = TILE_INVALID;  // recycle the other buffer's word
+
+  const int64_t i = (int64_t)tile * PRT_BLOCK + threadIdx.x;
+  const LaneLists lists = lane_lists(scene.lds_slots);
+  Ray8 r = {0, 0, 0, 1, 0, 0, 0, 0};
+  double t = PRT_INF;
+  int prim = -1;
+  bool live = false, carry = false;
+  if (i < n && !failed) {
+    r = load_ray8(rays, ld, i);
+    nearest_hit(scene.prims, scene.code, scene.n_instr, r, lists, t, prim);
+    live = is_live(r, prim);
+    carry = live && (keep_absorbed || scene.prims[prim].mat_kind != MAT_ABSORBER);
+  }
+  // workgroup aggregate and ranks: wave ballots + popcounts, four waves combined through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long m_live = __ballot(live), m_carry = __ballot(carry);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int live_rank = __popcll(m_live & below), carry_rank = __popcll(m_carry & below);
+  if (lane == 0) {
+    s_wave_live[wave] = __popcll(m_live);
+    s_wave_carry[wave] = __popcll(m_carry);
+  }
+  __syncthreads();
+  unsigned agg_live = 0, agg_carry = 0;
+  for (int w = 0; w < 4; ++w) {
+    if (w < wave) { live_rank += s_wave_live[w]; carry_rank += s_wave_carry[w]; }
+    agg_live += s_wave_live[w];
+    agg_carry += s_wave_carry[w];
+  }
+  if (wave == 0) {
+    if (lane == 0 && tile > 0) tile_store(tiles_cur + tile, tile_pack(TILE_AGGREGATE, agg_live, agg_carry));
+    unsigned e_live, e_carry;
+    if (!lookback(tiles_cur, tile, agg_live, agg_carry, e_live, e_carry) && lane == 0)
+      atomicExch(&ctrl->error, PRT_ERR_STALL);
+    if (lane == 0) { s_excl[0] = e_live; s_excl[1] = e_carry; }
+  }
+  __syncthreads();
+  const int64_t excl_live = s_excl[0], excl_carry = s_excl[1];
+
+  const int64_t last_tile = (n - 1) / PRT_BLOCK;
+  if (tile == last_tile && threadIdx.x == 0) {  // totals are known here: hand over to g + 1
+    const int64_t total_live = excl_live + agg_live, total_carry = excl_carry + agg_carry;
+    gen[g].n_live = total_live;
+    gen[g].n_carry = total_carry;
+    gen[g + 1].n_in = (total_live == 0) ? 0 : total_carry;
+    gen[g + 1].row_base = row_base + total_live;
+  }
+  if (row_base + excl_live + agg_live > ctrl->rows_cap) {  // uniform per workgroup
+    if (threadIdx.x == 0) atomicExch(&ctrl->error, PRT_ERR_ROWS_CAP);
+    return;
+  }
+  if (!live) return;
+  if (!interact_lane(scene, rays, ld, i, r, t, prim, carry, row_base + excl_live + live_rank,
+                     excl_carry + carry_rank, next, ld_next, rows, ld_rows, next_generation,
+                     relaunch, ray_offset))
+    atomicExch(&ctrl->error, PRT_ERR_UNTRACABLE);
+}
+
+// start of a fused trace: clear the control slots and tile buffer 0
+__global__ void k_fused_init(FusedCtrl* ctrl, GenCtrl* gen, int n_gen_slots,
+                             unsigned long long* tiles0, int64_t n_tiles, int64_t n, int64_t rows_cap) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = i; k < n_tiles; k += stride) tiles0[k] = TILE_INVALID;
+  for (int64_t k = i; k < n_gen_slots; k += stride) {
+    GenCtrl z;
+    memset(&z, 0, sizeof(z));
+    if (k == 0) z.n_in = n;
+    gen[k] = z;
+  }
+  if (i == 0) { ctrl->error = 0; ctrl->pad = 0; ctrl->rows_cap = rows_cap; }
 }
 
 // component.intersect(): run one component's program and spill its list
@@ -813,25 +1005,33 @@ extern "C" int prt_interact(prt_scene* s, int device, const double* rays_in, int
 }
 
 // workspace of prt_trace:
-//   ctrl | rows_per_generation (device, 1024 x int64) | block counts | block offsets
-//   | hit_t (n f64) | hit_prim (n i32) | ray buffer A (13 n) | ray buffer B (13 n)
+//   ctrl | fused ctrl | generation slots | rows_per_generation (device) | tile words A | B
+//   | block counts | block offsets | hit_t (n f64) | hit_prim (n i32)      [unfused path only]
+//   | ray buffer A (13 n) | ray buffer B (13 n)
 static const int kMaxGenerationSlots = 1024;
 struct TraceLayout {
-  size_t ctrl, gen_rows, counts, offsets, hit_t, hit_prim, rays_a, rays_b, total;
+  size_t ctrl, fctrl, gen, gen_rows, tiles_a, tiles_b, counts, offsets, hit_t, hit_prim, rays_a,
+      rays_b, total;
 };
 static TraceLayout trace_layout(int64_t n) {
   const size_t nb = blocks_for(n) + 1;
   const size_t nn = (size_t)(n < 1 ? 1 : n);
   TraceLayout l;
-  l.ctrl = 0;
-  l.gen_rows = align_up(sizeof(TraceCtrl), 256);
-  l.counts = l.gen_rows + align_up(kMaxGenerationSlots * sizeof(int64_t), 256);
-  l.offsets = l.counts + align_up(nb * 2 * sizeof(int32_t), 256);
-  l.hit_t = l.offsets + align_up(nb * 2 * sizeof(int64_t), 256);
-  l.hit_prim = l.hit_t + align_up(nn * sizeof(double), 256);
-  l.rays_a = l.hit_prim + align_up(nn * sizeof(int32_t), 256);
-  l.rays_b = l.rays_a + align_up(nn * PRT_RAY_ROWS * sizeof(double), 256);
-  l.total = l.rays_b + align_up(nn * PRT_RAY_ROWS * sizeof(double), 256);
+  size_t at = 0;
+  auto take = [&](size_t bytes) { size_t here = at; at += align_up(bytes, 256); return here; };
+  l.ctrl = take(sizeof(TraceCtrl));
+  l.fctrl = take(sizeof(FusedCtrl));
+  l.gen = take((kMaxGenerationSlots + 1) * sizeof(GenCtrl));
+  l.gen_rows = take(kMaxGenerationSlots * sizeof(int64_t));
+  l.tiles_a = take(nb * sizeof(unsigned long long));
+  l.tiles_b = take(nb * sizeof(unsigned long long));
+  l.counts = take(nb * 2 * sizeof(int32_t));
+  l.offsets = take(nb * 2 * sizeof(int64_t));
+  l.hit_t = take(nn * sizeof(double));
+  l.hit_prim = take(nn * sizeof(int32_t));
+  l.rays_a = take(nn * PRT_RAY_ROWS * sizeof(double));
+  l.rays_b = take(nn * PRT_RAY_ROWS * sizeof(double));
+  l.total = at;
   return l;
 }
 
@@ -839,23 +1039,20 @@ extern "C" int64_t prt_trace_workspace_bytes(int64_t n) {
   return (int64_t)trace_layout(n < 0 ? 0 : n).total;
 }
 
-extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64_t n, int64_t ld,
-                             int generation_limit, double ray_offset, double* rows_out,
-                             int64_t rows_cap, int64_t* rows_per_generation, void* workspace,
-                             int flags, void* stream) {
-  DeviceCopy* c;
-  int rc = on_device(s, device, &c);
-  if (rc) return rc;
-  if (n < 0 || ld < n || generation_limit < 0 || rows_cap < 0 || !rows_per_generation ||
-      !workspace || (n && !rays) || (rows_cap && !rows_out))
-    return fail(PRT_ERR_ARG, "bad buffers");
-  for (int g = 0; g < generation_limit; ++g) rows_per_generation[g] = 0;
-  s->stats[0] = s->stats[1] = s->stats[2] = s->stats[3] = 0;
-  if (n == 0 || generation_limit == 0) return 0;
+static int64_t trace_error(int error) {
+  if (error == PRT_ERR_ROWS_CAP) return fail(PRT_ERR_ROWS_CAP, "rows_cap too small");
+  if (error == PRT_ERR_UNTRACABLE)
+    return fail(PRT_ERR_UNTRACABLE, "a ray hit a surface whose material has no trace()");
+  if (error == PRT_ERR_STALL) return PRT_ERR_STALL;
+  return fail(error, "device error during trace");
+}
 
-  hipStream_t st = (hipStream_t)stream;
+// three kernels per generation + a host round trip (kept for A/B runs and cross-checks)
+static int64_t trace_unfused(prt_scene* s, DeviceCopy* c, const double* rays, int64_t n, int64_t ld,
+                             int generation_limit, double ray_offset, double* rows_out,
+                             int64_t rows_cap, int64_t* rows_per_generation, char* w, int flags,
+                             hipStream_t st) {
   const TraceLayout l = trace_layout(n);
-  char* w = (char*)workspace;
   TraceCtrl* ctrl = (TraceCtrl*)(w + l.ctrl);
   int64_t* gen_rows = (int64_t*)(w + l.gen_rows);
   int32_t* counts = (int32_t*)(w + l.counts);
@@ -908,11 +1105,98 @@ extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64
     src = dst;
     src_ld = n;
   }
-  if (error == PRT_ERR_ROWS_CAP) return fail(PRT_ERR_ROWS_CAP, "rows_cap too small");
-  if (error == PRT_ERR_UNTRACABLE)
-    return fail(PRT_ERR_UNTRACABLE, "a ray hit a surface whose material has no trace()");
-  if (error) return fail(error, "device error during trace");
+  if (error) return trace_error(error);
   return total_rows;
+}
+
+// one kernel per generation; generations are launched in batches with no host round trip in
+// between (a generation whose predecessor left no rays exits in its prologue)
+static const int kGenerationBatch = 4;
+
+static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int64_t n, int64_t ld,
+                           int generation_limit, double ray_offset, double* rows_out,
+                           int64_t rows_cap, int64_t* rows_per_generation, char* w, int flags,
+                           hipStream_t st) {
+  const TraceLayout l = trace_layout(n);
+  FusedCtrl* ctrl = (FusedCtrl*)(w + l.fctrl);
+  GenCtrl* gen = (GenCtrl*)(w + l.gen);
+  unsigned long long* tiles[2] = {(unsigned long long*)(w + l.tiles_a),
+                                  (unsigned long long*)(w + l.tiles_b)};
+  double* buf[2] = {(double*)(w + l.rays_a), (double*)(w + l.rays_b)};
+  const int keep_absorbed = (flags & PRT_TRACE_KEEP_ABSORBED) ? 1 : 0;
+  SceneDev sd = trace_scene_dev(s, c);
+  const size_t lds = lds_bytes(sd.lds_slots);
+  const int n_slots = generation_limit + 1;
+  hipLaunchKernelGGL(k_fused_init, dim3(64), dim3(256), 0, st, ctrl, gen, n_slots, tiles[0],
+                     (int64_t)blocks_for(n), n, rows_cap);
+
+  GenCtrl* host_gen = c->host_gen;
+  int64_t bound = n, total_rows = 0;
+  int g = 0, error = 0;
+  bool done = false;
+  while (g < generation_limit && !done) {
+    const int batch = std::min(kGenerationBatch, generation_limit - g);
+    HIP_TRY(hipEventRecord(c->ev0, st));
+    for (int b = 0; b < batch; ++b) {
+      const int gg = g + b;
+      const double* src = (gg == 0) ? rays : buf[(gg - 1) & 1];
+      const int64_t src_ld = (gg == 0) ? ld : n;
+      const int relaunch = (gg + 1 != generation_limit) ? 1 : 0;
+      hipLaunchKernelGGL(k_generation, dim3(blocks_for(bound)), dim3(PRT_BLOCK), lds, st, sd, src,
+                         src_ld, buf[gg & 1], n, rows_out, rows_cap, ctrl, gen, gg, tiles[gg & 1],
+                         tiles[(gg + 1) & 1], (double)(gg + 1), relaunch, ray_offset, keep_absorbed);
+    }
+    HIP_TRY(hipEventRecord(c->ev1, st));
+    HIP_TRY(hipMemcpyAsync(host_gen, gen + g, (batch + 1) * sizeof(GenCtrl), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(c->host_pinned, ctrl, sizeof(FusedCtrl), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    s->stats[2] += ms;
+    s->stats[3] += batch;
+    error = ((const FusedCtrl*)c->host_pinned)->error;
+    if (error) break;
+    for (int b = 0; b < batch; ++b) {
+      if (host_gen[b].n_in == 0) { done = true; break; }
+      s->stats[0] += 1;
+      s->stats[1] += (double)host_gen[b].n_in;
+      rows_per_generation[g + b] = host_gen[b].n_live;
+      total_rows += host_gen[b].n_live;
+    }
+    bound = host_gen[batch].n_in;
+    if (bound == 0) done = true;
+    g += batch;
+  }
+  if (error) return trace_error(error);
+  return total_rows;
+}
+
+extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64_t n, int64_t ld,
+                             int generation_limit, double ray_offset, double* rows_out,
+                             int64_t rows_cap, int64_t* rows_per_generation, void* workspace,
+                             int flags, void* stream) {
+  DeviceCopy* c;
+  int rc = on_device(s, device, &c);
+  if (rc) return rc;
+  if (n < 0 || ld < n || generation_limit < 0 || generation_limit > kMaxGenerationSlots ||
+      rows_cap < 0 || !rows_per_generation || !workspace || (n && !rays) || (rows_cap && !rows_out))
+    return fail(PRT_ERR_ARG, "bad buffers (generation_limit must be <= 1024)");
+  if (n >= (1ll << 31)) return fail(PRT_ERR_ARG, "at most 2^31-1 rays per call");
+  for (int g = 0; g < generation_limit; ++g) rows_per_generation[g] = 0;
+  s->stats[0] = s->stats[1] = s->stats[2] = s->stats[3] = 0;
+  if (n == 0 || generation_limit == 0) return 0;
+  if (flags & PRT_TRACE_UNFUSED)
+    return trace_unfused(s, c, rays, n, ld, generation_limit, ray_offset, rows_out, rows_cap,
+                         rows_per_generation, (char*)workspace, flags, (hipStream_t)stream);
+  int64_t rc64 = trace_fused(s, c, rays, n, ld, generation_limit, ray_offset, rows_out, rows_cap,
+                             rows_per_generation, (char*)workspace, flags, (hipStream_t)stream);
+  if (rc64 == PRT_ERR_STALL) {  // never observed; see lookback()
+    for (int g = 0; g < generation_limit; ++g) rows_per_generation[g] = 0;
+    s->stats[0] = s->stats[1] = s->stats[2] = s->stats[3] = 0;
+    rc64 = trace_unfused(s, c, rays, n, ld, generation_limit, ray_offset, rows_out, rows_cap,
+                         rows_per_generation, (char*)workspace, flags, (hipStream_t)stream);
+  }
+  return rc64;
 }
 
 extern "C" int prt_trace_stats(const prt_scene* s, double* out4) {

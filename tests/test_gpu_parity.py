@@ -65,7 +65,7 @@ def test_library_loads_on_gpu():
 # golden scenes: whole trace and the stepwise propagate / interact entry points
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", SCENE_FIXTURES)
-@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("flags", [0, 1, 2, 3])
 def test_trace_matches_reference(name, flags):
     fx = helpers.load(f"scene_{name}.npz")
     ds = device_scene(helpers.scene_of(fx))
