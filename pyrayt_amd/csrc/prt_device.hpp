@@ -461,6 +461,143 @@ __device__ __forceinline__ void first_positive(const Operand& o, const LaneLists
   }
 }
 
+// The same node, branch-free, for the list shapes the part factories produce (a register
+// pair against a register pair or against a short LDS list).  Instead of walking the merged
+// order it computes, for every entry independently, what the walk would have seen:
+//   with c(i,j) = (L_i <= R_j)            [ties: left first, the stable order]
+//   #R before L_i = sum_j !c(i,j)         #L before-or-at R_j = sum_i c(i,j)
+//   depth after an entry = own-list signs up to it + other-list signs before it (+1 if DIFF);
+//   both lists alternate +,-,... (the right one negated for DIFFERENCE), so a partial sum is
+//   the first sign if the count is odd and 0 if even;  depth before it = depth - own sign
+//   (for the first merged entry that is the wrap-around value of np.roll).
+// Keep rule as in csg_merge.  Survivors are scattered to LDS at their compacted position
+// (= kept entries of lower merged rank), or -- for the root node of a component -- reduced
+// directly to the nearest positive survivor, ties to the lower merged rank, without
+// materialising the list (the tracer only ever looks at that entry, _pyrayt.py:380-386).
+template <int ML, int MR, bool LREG, bool RREG>
+__device__ __forceinline__ void csg_node(int op, int l_base, int r_base, int out_base, bool touched,
+                                         bool is_root, const LaneLists& lists, const Pair& ra,
+                                         const Pair& rb, double& node_t, int& node_prim) {
+  double lv[ML], rv[MR];
+  int lid[ML], rid[MR];
+#pragma unroll
+  for (int i = 0; i < ML; ++i) {
+    if (LREG) { lv[i] = (i == 0) ? ra.t0 : ra.t1; lid[i] = ra.prim; }
+    else { lv[i] = lists.get_t(l_base + i); lid[i] = lists.get_id(l_base + i); }
+  }
+#pragma unroll
+  for (int j = 0; j < MR; ++j) {
+    if (RREG) { rv[j] = (j == 0) ? rb.t0 : rb.t1; rid[j] = rb.prim; }
+    else { rv[j] = lists.get_t(r_base + j); rid[j] = lists.get_id(r_base + j); }
+  }
+  bool c[ML][MR];
+  int r_before[ML], l_before[MR];
+#pragma unroll
+  for (int i = 0; i < ML; ++i) r_before[i] = 0;
+#pragma unroll
+  for (int j = 0; j < MR; ++j) l_before[j] = 0;
+#pragma unroll
+  for (int i = 0; i < ML; ++i) {
+#pragma unroll
+    for (int j = 0; j < MR; ++j) {
+      c[i][j] = lv[i] <= rv[j];
+      l_before[j] += c[i][j] ? 1 : 0;
+      r_before[i] += c[i][j] ? 0 : 1;
+    }
+  }
+  const int diff = (op == CSG_DIFFERENCE) ? 1 : 0;
+  const int r_first = diff ? -1 : 1;
+  bool keep_l[ML], keep_r[MR];
+#pragma unroll
+  for (int i = 0; i < ML; ++i) {
+    const int own = (i & 1) ? -1 : 1;
+    const int depth = ((i & 1) ? 0 : 1) + ((r_before[i] & 1) ? r_first : 0) + diff;
+    const int before = depth - own;
+    const bool keep = (op == CSG_UNION) ? ((depth != 0) != (before != 0)) : (depth == 2 || before == 2);
+    keep_l[i] = keep && touched && lv[i] < PRT_INF;
+  }
+#pragma unroll
+  for (int j = 0; j < MR; ++j) {
+    const int own = (j & 1) ? -r_first : r_first;
+    const int depth = ((j & 1) ? 0 : r_first) + (l_before[j] & 1) + diff;
+    const int before = depth - own;
+    const bool keep = (op == CSG_UNION) ? ((depth != 0) != (before != 0)) : (depth == 2 || before == 2);
+    keep_r[j] = keep && touched && rv[j] < PRT_INF;
+  }
+  if (is_root) {
+    double best = PRT_INF;
+    int best_rank = ML + MR, best_id = -1;
+#pragma unroll
+    for (int i = 0; i < ML; ++i) {
+      const int rank = i + r_before[i];
+      const bool better = keep_l[i] && lv[i] > 0 && (lv[i] < best || (lv[i] == best && rank < best_rank));
+      if (better) { best = lv[i]; best_rank = rank; best_id = lid[i]; }
+    }
+#pragma unroll
+    for (int j = 0; j < MR; ++j) {
+      const int rank = j + l_before[j];
+      const bool better = keep_r[j] && rv[j] > 0 && (rv[j] < best || (rv[j] == best && rank < best_rank));
+      if (better) { best = rv[j]; best_rank = rank; best_id = rid[j]; }
+    }
+    node_t = best;
+    node_prim = best_id;
+    return;
+  }
+  int kept = 0;
+#pragma unroll
+  for (int i = 0; i < ML; ++i) {
+    int pos = 0;
+#pragma unroll
+    for (int k = 0; k < i; ++k) pos += keep_l[k] ? 1 : 0;
+#pragma unroll
+    for (int j = 0; j < MR; ++j) pos += (!c[i][j] && keep_r[j]) ? 1 : 0;
+    if (keep_l[i]) lists.put(out_base + pos, lv[i], lid[i]);
+    kept += keep_l[i] ? 1 : 0;
+  }
+#pragma unroll
+  for (int j = 0; j < MR; ++j) {
+    int pos = 0;
+#pragma unroll
+    for (int k = 0; k < j; ++k) pos += keep_r[k] ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < ML; ++i) pos += (c[i][j] && keep_l[i]) ? 1 : 0;
+    if (keep_r[j]) lists.put(out_base + pos, rv[j], rid[j]);
+    kept += keep_r[j] ? 1 : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < ML + MR; ++k)
+    if (k >= kept) lists.put(out_base + k, PRT_INF, -1);
+}
+
+// One CSG step of the program: pick the specialised node for the common shapes, fall back
+// to the serial merge for anything else (two LDS operands, very long chains).
+// `in->pad[0]` marks the root node of a component in the trace program.
+__device__ __forceinline__ void csg_step(const DevInstr* __restrict__ in, bool touched,
+                                         const LaneLists& lists, const Pair& ra, const Pair& rb,
+                                         bool& produced_root, double& node_t, int& node_prim) {
+  const int op = in->a0, lmode = in->a1, lbase = in->a2, ml = in->a3;
+  const int rmode = in->a4, rbase = in->a5, mr = in->a6, obase = in->a7;
+  const bool is_root = in->pad[0] != 0;
+  produced_root = is_root;
+  if (lmode == OPER_REGA && rmode == OPER_REGB) {
+    csg_node<2, 2, true, true>(op, 0, 0, obase, touched, is_root, lists, ra, rb, node_t, node_prim);
+    return;
+  }
+  if (lmode == OPER_LDS && rmode == OPER_REGB) {
+    if (ml == 4) { csg_node<4, 2, false, true>(op, lbase, 0, obase, touched, is_root, lists, ra, rb, node_t, node_prim); return; }
+  }
+  if (lmode == OPER_REGA && rmode == OPER_LDS) {
+    if (mr == 4) { csg_node<2, 4, true, false>(op, 0, rbase, obase, touched, is_root, lists, ra, rb, node_t, node_prim); return; }
+  }
+  const Operand L = {lmode, lbase, ml};
+  const Operand R = {rmode, rbase, mr};
+  csg_merge(op, L, R, obase, touched, lists, ra, rb);
+  if (is_root) {
+    const Operand o = {OPER_LDS, obase, ml + mr};
+    first_positive(o, lists, ra, rb, node_t, node_prim);
+  }
+}
+
 // Run the scene program for one ray: nearest positive hit over all components with the
 // strict '<' running minimum of _pyrayt.py:384-386.  `prims`/`code` are wave-uniform.
 __device__ __forceinline__ void nearest_hit(const DevPrim* __restrict__ prims,
@@ -487,11 +624,16 @@ __device__ __forceinline__ void nearest_hit(const DevPrim* __restrict__ prims,
         lists.put(in->a2 + 1, t1, p);
       }
     } else if (kind == I_CSG) {
-      const Operand L = {in->a1, in->a2, in->a3};
-      const Operand R = {in->a4, in->a5, in->a6};
       const bool touched = box_touched(in->aabb, ray);
-      csg_merge(in->a0, L, R, in->a7, touched, lists, ra, rb);
-    } else {  // I_ROOT
+      bool is_root;
+      double t = PRT_INF;
+      int prim = -1;
+      csg_step(in, touched, lists, ra, rb, is_root, t, prim);
+      if (is_root && t < best_t) {
+        best_t = t;
+        best_prim = prim;
+      }
+    } else {  // I_ROOT: a component that is a single surface (its pair sits in REGA)
       const Operand o = {in->a0, in->a1, in->a2};
       double t;
       int prim;

@@ -184,9 +184,13 @@ static Operand compile_component(const prt_scene* s, int root_node, std::vector<
   else
     res = c.emit(root_node, 0);
   if (with_root) {
-    DevInstr in = Compiler::blank(I_ROOT);
-    in.a0 = res.mode; in.a1 = res.base; in.a2 = res.len;
-    code.push_back(in);
+    if (!code.empty() && code.size() > from && code.back().kind == I_CSG) {
+      code.back().pad[0] = 1;  // the node reduces straight to its nearest positive survivor
+    } else {
+      DevInstr in = Compiler::blank(I_ROOT);
+      in.a0 = res.mode; in.a1 = res.base; in.a2 = res.len;
+      code.push_back(in);
+    }
   }
   const int shift = -c.lowest;
   shift_slots(code, from, shift);
@@ -683,7 +687,7 @@ __device__ __forceinline__ bool lookback(unsigned long long* state, int tile, un
   return ok;
 }
 
-__global__ void __launch_bounds__(PRT_BLOCK)
+__global__ void __launch_bounds__(PRT_BLOCK, 5)
 k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double* __restrict__ next,
              int64_t ld_next, double* __restrict__ rows, int64_t ld_rows, FusedCtrl* __restrict__ ctrl,
              GenCtrl* __restrict__ gen, int g, unsigned long long* __restrict__ tiles_cur,
@@ -793,9 +797,10 @@ k_intersect(SceneDev scene, Operand result, const double* __restrict__ rays, int
       else if (in->a1 == OPER_REGB) { rb.t0 = t0; rb.t1 = t1; rb.prim = in->a0; }
       else { lists.put(in->a2, t0, in->a0); lists.put(in->a2 + 1, t1, in->a0); }
     } else if (in->kind == I_CSG) {
-      const Operand L = {in->a1, in->a2, in->a3};
-      const Operand R = {in->a4, in->a5, in->a6};
-      csg_merge(in->a0, L, R, in->a7, box_touched(in->aabb, r), lists, ra, rb);
+      bool is_root;
+      double t_unused;
+      int prim_unused;
+      csg_step(in, box_touched(in->aabb, r), lists, ra, rb, is_root, t_unused, prim_unused);
     }
   }
   for (int k = 0; k < result.len; ++k) {
