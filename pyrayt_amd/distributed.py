@@ -78,9 +78,10 @@ def assemble_rows(rows, counts, generation_limit, group=None, gather="all"):
     mine = torch.zeros(limit, dtype=torch.int64, device=dev)
     if counts:
         mine[: len(counts)] = torch.tensor(list(counts), dtype=torch.int64, device=dev)
-    matrix = torch.empty((world, limit), dtype=torch.int64, device=dev)
+    # outputs are the rank-major concatenation along dim 0 (the form every backend accepts)
+    matrix = torch.empty(world * limit, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(matrix, mine, group=group)
-    matrix_host = matrix.cpu()
+    matrix_host = matrix.view(world, limit).cpu()
     dest, local, total = placement(matrix_host)
     per_rank = matrix_host.sum(dim=1)
     widest = int(per_rank.max())
@@ -91,9 +92,9 @@ def assemble_rows(rows, counts, generation_limit, group=None, gather="all"):
     padded = torch.zeros((rows.shape[0], widest), dtype=rows.dtype, device=dev)
     padded[:, : rows.shape[1]] = rows
     if gather == "all":
-        everything = torch.empty((world,) + tuple(padded.shape), dtype=rows.dtype, device=dev)
+        everything = torch.empty((world * padded.shape[0], widest), dtype=rows.dtype, device=dev)
         dist.all_gather_into_tensor(everything, padded, group=group)
-        blocks = list(everything.unbind(0))
+        blocks = list(everything.view(world, padded.shape[0], widest).unbind(0))
     elif gather == "root":
         root = dist.get_global_rank(group, 0) if hasattr(dist, "get_global_rank") else 0
         blocks = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None

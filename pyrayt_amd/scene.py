@@ -118,7 +118,7 @@ class SceneSnapshot:
         return 2 * leaves(int(self.roots[root]))
 
     def as_dict(self):
-        """Plain-array form (what fixtures store and what the oracle consumes)."""
+        """Plain-array copy of the snapshot."""
         return {
             "prims": self.prims.copy(),
             "nodes": self.nodes.copy(),
