@@ -474,10 +474,21 @@ __device__ __forceinline__ void first_positive(const Operand& o, const LaneLists
 // (= kept entries of lower merged rank), or -- for the root node of a component -- reduced
 // directly to the nearest positive survivor, ties to the lower merged rank, without
 // materialising the list (the tracer only ever looks at that entry, _pyrayt.py:380-386).
+//
+// The cull box (csg.py:126-128) is evaluated lazily where it is implied: for an INTERSECT or
+// DIFFERENCE node over UNION-free subtrees the node's box contains the node's solid (it is the
+// intersection of the children's boxes, resp. the left child's box, and a surface's box bounds
+// the surface), so a ray with two survivors a robust distance apart runs through the box for
+// at least that chord and the strict enter < leave test of primitives.py:578 holds; a ray with
+// no survivor gets the all-inf list either way.  Only rays whose survivors are (nearly)
+// coincident -- tangent rays, a Plane's double hit (t,t) -- take the exact six-division test.
+// UNION nodes always take it (their upstream box can be smaller than the solid).
 template <int ML, int MR, bool LREG, bool RREG>
-__device__ __forceinline__ void csg_node(int op, int l_base, int r_base, int out_base, bool touched,
-                                         bool is_root, const LaneLists& lists, const Pair& ra,
-                                         const Pair& rb, double& node_t, int& node_prim) {
+__device__ __forceinline__ void csg_node(int op, int l_base, int r_base, int out_base,
+                                         const double* __restrict__ aabb, const Ray8& ray,
+                                         bool box_implied, bool is_root, const LaneLists& lists,
+                                         const Pair& ra, const Pair& rb, double& node_t,
+                                         int& node_prim) {
   double lv[ML], rv[MR];
   int lid[ML], rid[MR];
 #pragma unroll
@@ -514,7 +525,7 @@ __device__ __forceinline__ void csg_node(int op, int l_base, int r_base, int out
     const int depth = ((i & 1) ? 0 : 1) + ((r_before[i] & 1) ? r_first : 0) + diff;
     const int before = depth - own;
     const bool keep = (op == CSG_UNION) ? ((depth != 0) != (before != 0)) : (depth == 2 || before == 2);
-    keep_l[i] = keep && touched && lv[i] < PRT_INF;
+    keep_l[i] = keep && lv[i] < PRT_INF;
   }
 #pragma unroll
   for (int j = 0; j < MR; ++j) {
@@ -522,7 +533,28 @@ __device__ __forceinline__ void csg_node(int op, int l_base, int r_base, int out
     const int depth = ((j & 1) ? 0 : r_first) + (l_before[j] & 1) + diff;
     const int before = depth - own;
     const bool keep = (op == CSG_UNION) ? ((depth != 0) != (before != 0)) : (depth == 2 || before == 2);
-    keep_r[j] = keep && touched && rv[j] < PRT_INF;
+    keep_r[j] = keep && rv[j] < PRT_INF;
+  }
+  {
+    bool touched = true;
+    if (!box_implied) {  // wave-uniform
+      touched = box_touched(aabb, ray);
+    } else {
+      double lo = PRT_INF, hi = -PRT_INF;
+#pragma unroll
+      for (int i = 0; i < ML; ++i)
+        if (keep_l[i]) { lo = dmin(lo, lv[i]); hi = dmax(hi, lv[i]); }
+#pragma unroll
+      for (int j = 0; j < MR; ++j)
+        if (keep_r[j]) { lo = dmin(lo, rv[j]); hi = dmax(hi, rv[j]); }
+      const bool any = hi >= lo;  // false when nothing survived (lo = +inf, hi = -inf)
+      const bool robust = any && lo > -PRT_INF && (hi - lo) > 1e-6 * ((1.0 + fabs(lo)) + fabs(hi));
+      if (any && !robust) touched = box_touched(aabb, ray);
+    }
+#pragma unroll
+    for (int i = 0; i < ML; ++i) keep_l[i] = keep_l[i] && touched;
+#pragma unroll
+    for (int j = 0; j < MR; ++j) keep_r[j] = keep_r[j] && touched;
   }
   if (is_root) {
     double best = PRT_INF;
@@ -572,26 +604,29 @@ __device__ __forceinline__ void csg_node(int op, int l_base, int r_base, int out
 // One CSG step of the program: pick the specialised node for the common shapes, fall back
 // to the serial merge for anything else (two LDS operands, very long chains).
 // `in->pad[0]` marks the root node of a component in the trace program.
-__device__ __forceinline__ void csg_step(const DevInstr* __restrict__ in, bool touched,
+__device__ __forceinline__ void csg_step(const DevInstr* __restrict__ in, const Ray8& ray,
                                          const LaneLists& lists, const Pair& ra, const Pair& rb,
                                          bool& produced_root, double& node_t, int& node_prim) {
   const int op = in->a0, lmode = in->a1, lbase = in->a2, ml = in->a3;
   const int rmode = in->a4, rbase = in->a5, mr = in->a6, obase = in->a7;
   const bool is_root = in->pad[0] != 0;
+  const bool implied = in->pad[1] != 0;
   produced_root = is_root;
   if (lmode == OPER_REGA && rmode == OPER_REGB) {
-    csg_node<2, 2, true, true>(op, 0, 0, obase, touched, is_root, lists, ra, rb, node_t, node_prim);
+    csg_node<2, 2, true, true>(op, 0, 0, obase, in->aabb, ray, implied, is_root, lists, ra, rb, node_t, node_prim);
     return;
   }
-  if (lmode == OPER_LDS && rmode == OPER_REGB) {
-    if (ml == 4) { csg_node<4, 2, false, true>(op, lbase, 0, obase, touched, is_root, lists, ra, rb, node_t, node_prim); return; }
+  if (lmode == OPER_LDS && rmode == OPER_REGB && ml == 4) {
+    csg_node<4, 2, false, true>(op, lbase, 0, obase, in->aabb, ray, implied, is_root, lists, ra, rb, node_t, node_prim);
+    return;
   }
-  if (lmode == OPER_REGA && rmode == OPER_LDS) {
-    if (mr == 4) { csg_node<2, 4, true, false>(op, 0, rbase, obase, touched, is_root, lists, ra, rb, node_t, node_prim); return; }
+  if (lmode == OPER_REGA && rmode == OPER_LDS && mr == 4) {
+    csg_node<2, 4, true, false>(op, 0, rbase, obase, in->aabb, ray, implied, is_root, lists, ra, rb, node_t, node_prim);
+    return;
   }
   const Operand L = {lmode, lbase, ml};
   const Operand R = {rmode, rbase, mr};
-  csg_merge(op, L, R, obase, touched, lists, ra, rb);
+  csg_merge(op, L, R, obase, box_touched(in->aabb, ray), lists, ra, rb);
   if (is_root) {
     const Operand o = {OPER_LDS, obase, ml + mr};
     first_positive(o, lists, ra, rb, node_t, node_prim);
@@ -613,7 +648,11 @@ __device__ __forceinline__ void nearest_hit(const DevPrim* __restrict__ prims,
     if (kind == I_LEAF) {
       const int p = in->a0;
       double t0, t1;
+#if defined(PRT_ABLATE) && (PRT_ABLATE & 4)
+      t0 = ray.ox + prims[p].params[0]; t1 = ray.dx;  // timing experiment: no primitive math
+#else
       surface_pair(prims + p, ray, t0, t1);
+#endif
       const int dst = in->a1;
       if (dst == OPER_REGA) {
         ra.t0 = t0; ra.t1 = t1; ra.prim = p;
@@ -624,11 +663,14 @@ __device__ __forceinline__ void nearest_hit(const DevPrim* __restrict__ prims,
         lists.put(in->a2 + 1, t1, p);
       }
     } else if (kind == I_CSG) {
-      const bool touched = box_touched(in->aabb, ray);
       bool is_root;
       double t = PRT_INF;
       int prim = -1;
-      csg_step(in, touched, lists, ra, rb, is_root, t, prim);
+#if defined(PRT_ABLATE) && (PRT_ABLATE & 2)
+      is_root = in->pad[0] != 0; t = ra.t0 + rb.t0; prim = ra.prim;  // timing experiment: no CSG
+#else
+      csg_step(in, ray, lists, ra, rb, is_root, t, prim);
+#endif
       if (is_root && t < best_t) {
         best_t = t;
         best_prim = prim;

@@ -123,6 +123,15 @@ struct Compiler {
     return o;
   }
 
+  // does the upstream cull box of `node` provably contain the node's solid?  (see csg_node)
+  bool box_contains_solid(int node) const {
+    const prt_node& n = s->nodes[node];
+    if (n.op == PRT_NODE_LEAF) return true;
+    if (n.op == PRT_NODE_INTERSECT) return box_contains_solid(n.left) && box_contains_solid(n.right);
+    if (n.op == PRT_NODE_DIFFERENCE) return box_contains_solid(n.left);
+    return false;  // UNION of disjoint operands keeps only the first operand's span (csg.py:98-109)
+  }
+
   Operand emit(int node, int ceiling) {
     const prt_node& n = s->nodes[node];
     if (n.op == PRT_NODE_LEAF) return leaf(node, OPER_LDS, ceiling);
@@ -149,6 +158,7 @@ struct Compiler {
       base = L.base - m_r;
     }
     DevInstr in = blank(I_CSG);
+    in.pad[1] = box_contains_solid(node) ? 1 : 0;
     in.a0 = n.op;
     in.a1 = L.mode; in.a2 = L.base; in.a3 = L.len;
     in.a4 = R.mode; in.a5 = R.base; in.a6 = R.len;
@@ -469,81 +479,103 @@ __device__ __forceinline__ int block_rank(bool flag, int* s_wave /*[4]*/) {
   return base + before;
 }
 
-// One live ray through INTERACT (_pyrayt.py:394-452) and the record writer (:168-186):
-// advance to the hit point, shade by the material of the primitive hit, write the record row
-// at column `row` and -- if the ray goes on -- its next state at column `j`.
-// Returns false if the surface hit has an untracable material.
+// One live ray through INTERACT (_pyrayt.py:394-452) and the record writer (:168-186), in two
+// halves so that a kernel can do the arithmetic before it knows where the results go:
+//   interact_compute : load the 5 metadata rows, advance to the hit point, shade by the material
+//                      of the primitive hit (wave "waterfall" over the distinct primitives)
+//   interact_store   : record row at column `row`, next state at column `j` if the ray goes on
+struct Shaded {
+  double generation, intensity, wavelength, index_in, id;  // pre-hit metadata
+  double px, py, pz, pw;                                    // hit point
+  double dx, dy, dz, dw, index;                             // post-interaction direction / index
+  double surface_id;
+  bool ok;                                                  // false: untracable material
+};
+
+__device__ __forceinline__ Shaded interact_compute(const SceneDev& scene, const double* __restrict__ rays,
+                                                   int64_t ld, int64_t i, const Ray8& r, double t,
+                                                   int prim) {
+  Shaded s;
+  s.generation = rays[8 * ld + i];
+  s.intensity = rays[9 * ld + i];
+  s.wavelength = rays[10 * ld + i];
+  s.index_in = rays[11 * ld + i];
+  s.id = rays[12 * ld + i];
+  // advance to the hit point: o += d * t, all four homogeneous components (_pyrayt.py:404-407)
+  s.px = r.ox + r.dx * t; s.py = r.oy + r.dy * t; s.pz = r.oz + r.dz * t; s.pw = r.ow + r.dw * t;
+  s.dx = r.dx; s.dy = r.dy; s.dz = r.dz; s.dw = r.dw;
+  s.index = s.index_in;
+  s.surface_id = -1.0;
+  s.ok = true;
+  // material dispatch: the primitive table is wave-uniform data, so lanes that hit the same
+  // surface shade together and the loop runs once per distinct surface hit in the wave
+  unsigned long long todo = __ballot(true);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int cur = __shfl(prim, leader);
+    if (prim == cur) {
+      const DevPrim* __restrict__ p = scene.prims + cur;
+      s.ok = shade(p, s.px, s.py, s.pz, s.pw, s.dx, s.dy, s.dz, s.dw, s.wavelength, s.index);
+      s.surface_id = p->surface_id;
+    }
+    todo &= ~__ballot(prim == cur);
+  }
+  return s;
+}
+
+__device__ __forceinline__ void interact_store(const Shaded& s, const Ray8& r, bool carry, int64_t row,
+                                               int64_t j, double* __restrict__ next, int64_t ld_next,
+                                               double* __restrict__ rows, int64_t ld_rows,
+                                               double next_generation, int relaunch, double ray_offset) {
+  // record row (_pyrayt.py:168-186): pre-hit metadata, surface, start, end, unit tilt
+  const double tilt = norm3(r.dx, r.dy, r.dz);
+  rows[PRT_COL_GENERATION * ld_rows + row] = s.generation;
+  rows[PRT_COL_INTENSITY * ld_rows + row] = s.intensity;
+  rows[PRT_COL_WAVELENGTH * ld_rows + row] = s.wavelength;
+  rows[PRT_COL_INDEX * ld_rows + row] = s.index_in;
+  rows[PRT_COL_ID * ld_rows + row] = s.id;
+  rows[PRT_COL_SURFACE * ld_rows + row] = s.surface_id;
+  rows[PRT_COL_X0 * ld_rows + row] = r.ox;
+  rows[PRT_COL_Y0 * ld_rows + row] = r.oy;
+  rows[PRT_COL_Z0 * ld_rows + row] = r.oz;
+  rows[PRT_COL_X1 * ld_rows + row] = s.px;
+  rows[PRT_COL_Y1 * ld_rows + row] = s.py;
+  rows[PRT_COL_Z1 * ld_rows + row] = s.pz;
+  rows[PRT_COL_XTILT * ld_rows + row] = r.dx / tilt;
+  rows[PRT_COL_YTILT * ld_rows + row] = r.dy / tilt;
+  rows[PRT_COL_ZTILT * ld_rows + row] = r.dz / tilt;
+  if (carry) {
+    // next state (_pyrayt.py:437-449): generation + 1, re-launch 1e-6 along the new direction
+    double qx = s.px, qy = s.py, qz = s.pz, qw = s.pw;
+    if (relaunch) {
+      qx = s.px + ray_offset * s.dx; qy = s.py + ray_offset * s.dy; qz = s.pz + ray_offset * s.dz;
+      qw = s.pw + ray_offset * s.dw;
+    }
+    next[0 * ld_next + j] = qx;
+    next[1 * ld_next + j] = qy;
+    next[2 * ld_next + j] = qz;
+    next[3 * ld_next + j] = qw;
+    next[4 * ld_next + j] = s.dx;
+    next[5 * ld_next + j] = s.dy;
+    next[6 * ld_next + j] = s.dz;
+    next[7 * ld_next + j] = s.dw;
+    next[8 * ld_next + j] = next_generation;
+    next[9 * ld_next + j] = s.intensity;
+    next[10 * ld_next + j] = s.wavelength;
+    next[11 * ld_next + j] = s.index;
+    next[12 * ld_next + j] = s.id;
+  }
+}
+
 __device__ __forceinline__ bool interact_lane(const SceneDev& scene, const double* __restrict__ rays,
                                               int64_t ld, int64_t i, const Ray8& r, double t, int prim,
                                               bool carry, int64_t row, int64_t j,
                                               double* __restrict__ next, int64_t ld_next,
                                               double* __restrict__ rows, int64_t ld_rows,
                                               double next_generation, int relaunch, double ray_offset) {
-  const double generation = rays[8 * ld + i];
-  const double intensity = rays[9 * ld + i];
-  const double wavelength = rays[10 * ld + i];
-  const double index_in = rays[11 * ld + i];
-  const double id = rays[12 * ld + i];
-
-  // advance to the hit point: o += d * t, all four homogeneous components (_pyrayt.py:404-407)
-  const double px = r.ox + r.dx * t, py = r.oy + r.dy * t, pz = r.oz + r.dz * t,
-               pw = r.ow + r.dw * t;
-  double dx = r.dx, dy = r.dy, dz = r.dz, dw = r.dw, index = index_in, surface_id = -1.0;
-  // material dispatch: the primitive table is wave-uniform data, so lanes that hit the same
-  // surface shade together and the loop runs once per distinct surface hit in the wave
-  unsigned long long todo = __ballot(true);
-  bool ok = true;
-  while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const int cur = __shfl(prim, leader);
-    if (prim == cur) {
-      const DevPrim* __restrict__ p = scene.prims + cur;
-      ok = shade(p, px, py, pz, pw, dx, dy, dz, dw, wavelength, index);
-      surface_id = p->surface_id;
-    }
-    todo &= ~__ballot(prim == cur);
-  }
-
-  // record row (_pyrayt.py:168-186): pre-hit metadata, surface, start, end, unit tilt
-  const double tilt = norm3(r.dx, r.dy, r.dz);
-  rows[PRT_COL_GENERATION * ld_rows + row] = generation;
-  rows[PRT_COL_INTENSITY * ld_rows + row] = intensity;
-  rows[PRT_COL_WAVELENGTH * ld_rows + row] = wavelength;
-  rows[PRT_COL_INDEX * ld_rows + row] = index_in;
-  rows[PRT_COL_ID * ld_rows + row] = id;
-  rows[PRT_COL_SURFACE * ld_rows + row] = surface_id;
-  rows[PRT_COL_X0 * ld_rows + row] = r.ox;
-  rows[PRT_COL_Y0 * ld_rows + row] = r.oy;
-  rows[PRT_COL_Z0 * ld_rows + row] = r.oz;
-  rows[PRT_COL_X1 * ld_rows + row] = px;
-  rows[PRT_COL_Y1 * ld_rows + row] = py;
-  rows[PRT_COL_Z1 * ld_rows + row] = pz;
-  rows[PRT_COL_XTILT * ld_rows + row] = r.dx / tilt;
-  rows[PRT_COL_YTILT * ld_rows + row] = r.dy / tilt;
-  rows[PRT_COL_ZTILT * ld_rows + row] = r.dz / tilt;
-
-  if (carry) {
-    // next state (_pyrayt.py:437-449): generation + 1, re-launch 1e-6 along the new direction
-    double qx = px, qy = py, qz = pz, qw = pw;
-    if (relaunch) {
-      qx = px + ray_offset * dx; qy = py + ray_offset * dy; qz = pz + ray_offset * dz;
-      qw = pw + ray_offset * dw;
-    }
-    next[0 * ld_next + j] = qx;
-    next[1 * ld_next + j] = qy;
-    next[2 * ld_next + j] = qz;
-    next[3 * ld_next + j] = qw;
-    next[4 * ld_next + j] = dx;
-    next[5 * ld_next + j] = dy;
-    next[6 * ld_next + j] = dz;
-    next[7 * ld_next + j] = dw;
-    next[8 * ld_next + j] = next_generation;
-    next[9 * ld_next + j] = intensity;
-    next[10 * ld_next + j] = wavelength;
-    next[11 * ld_next + j] = index;
-    next[12 * ld_next + j] = id;
-  }
-  return ok;
+  const Shaded s = interact_compute(scene, rays, ld, i, r, t, prim);
+  interact_store(s, r, carry, row, j, next, ld_next, rows, ld_rows, next_generation, relaunch, ray_offset);
+  return s.ok;
 }
 
 // [_st_interact + _RayTraceDataframe.insert]
@@ -734,8 +766,14 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     agg_live += s_wave_live[w];
     agg_carry += s_wave_carry[w];
   }
+  if (threadIdx.x == 0 && tile > 0)
+    tile_store(tiles_cur + tile, tile_pack(TILE_AGGREGATE, agg_live, agg_carry));
+  // Shade BEFORE asking where the results go: the predecessors get this long to publish their
+  // aggregates, so the look-back below mostly finds them ready instead of waiting.
+  Shaded sh;
+  sh.ok = true;
+  if (live) sh = interact_compute(scene, rays, ld, i, r, t, prim);
   if (wave == 0) {
-    if (lane == 0 && tile > 0) tile_store(tiles_cur + tile, tile_pack(TILE_AGGREGATE, agg_live, agg_carry));
     unsigned e_live, e_carry;
     if (!lookback(tiles_cur, tile, agg_live, agg_carry, e_live, e_carry) && lane == 0)
       atomicExch(&ctrl->error, PRT_ERR_STALL);
@@ -757,10 +795,9 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     return;
   }
   if (!live) return;
-  if (!interact_lane(scene, rays, ld, i, r, t, prim, carry, row_base + excl_live + live_rank,
-                     excl_carry + carry_rank, next, ld_next, rows, ld_rows, next_generation,
-                     relaunch, ray_offset))
-    atomicExch(&ctrl->error, PRT_ERR_UNTRACABLE);
+  interact_store(sh, r, carry, row_base + excl_live + live_rank, excl_carry + carry_rank, next,
+                 ld_next, rows, ld_rows, next_generation, relaunch, ray_offset);
+  if (!sh.ok) atomicExch(&ctrl->error, PRT_ERR_UNTRACABLE);
 }
 
 // start of a fused trace: clear the control slots and tile buffer 0
@@ -800,7 +837,7 @@ k_intersect(SceneDev scene, Operand result, const double* __restrict__ rays, int
       bool is_root;
       double t_unused;
       int prim_unused;
-      csg_step(in, box_touched(in->aabb, r), lists, ra, rb, is_root, t_unused, prim_unused);
+      csg_step(in, r, lists, ra, rb, is_root, t_unused, prim_unused);
     }
   }
   for (int k = 0; k < result.len; ++k) {

@@ -12,7 +12,7 @@ import numpy as np
 from . import scene as _scene
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libprt_hip.so")
+LIB_PATH = os.environ.get("PRT_LIB", os.path.join(_HERE, "csrc", "libprt_hip.so"))
 
 RAY_ROWS = 13
 RECORD_COLS = 15
