@@ -492,15 +492,27 @@ struct Shaded {
   bool ok;                                                  // false: untracable material
 };
 
-__device__ __forceinline__ Shaded interact_compute(const SceneDev& scene, const double* __restrict__ rays,
-                                                   int64_t ld, int64_t i, const Ray8& r, double t,
-                                                   int prim) {
+struct Meta5 {
+  double generation, intensity, wavelength, index, id;
+};
+__device__ __forceinline__ Meta5 load_meta(const double* __restrict__ rays, int64_t ld, int64_t i) {
+  Meta5 m;
+  m.generation = rays[8 * ld + i];
+  m.intensity = rays[9 * ld + i];
+  m.wavelength = rays[10 * ld + i];
+  m.index = rays[11 * ld + i];
+  m.id = rays[12 * ld + i];
+  return m;
+}
+
+__device__ __forceinline__ Shaded interact_compute(const SceneDev& scene, const Meta5& m, const Ray8& r,
+                                                   double t, int prim) {
   Shaded s;
-  s.generation = rays[8 * ld + i];
-  s.intensity = rays[9 * ld + i];
-  s.wavelength = rays[10 * ld + i];
-  s.index_in = rays[11 * ld + i];
-  s.id = rays[12 * ld + i];
+  s.generation = m.generation;
+  s.intensity = m.intensity;
+  s.wavelength = m.wavelength;
+  s.index_in = m.index;
+  s.id = m.id;
   // advance to the hit point: o += d * t, all four homogeneous components (_pyrayt.py:404-407)
   s.px = r.ox + r.dx * t; s.py = r.oy + r.dy * t; s.pz = r.oz + r.dz * t; s.pw = r.ow + r.dw * t;
   s.dx = r.dx; s.dy = r.dy; s.dz = r.dz; s.dw = r.dw;
@@ -573,7 +585,7 @@ __device__ __forceinline__ bool interact_lane(const SceneDev& scene, const doubl
                                               double* __restrict__ next, int64_t ld_next,
                                               double* __restrict__ rows, int64_t ld_rows,
                                               double next_generation, int relaunch, double ray_offset) {
-  const Shaded s = interact_compute(scene, rays, ld, i, r, t, prim);
+  const Shaded s = interact_compute(scene, load_meta(rays, ld, i), r, t, prim);
   interact_store(s, r, carry, row, j, next, ld_next, rows, ld_rows, next_generation, relaunch, ray_offset);
   return s.ok;
 }
@@ -719,7 +731,14 @@ __device__ __forceinline__ bool lookback(unsigned long long* state, int tile, un
   return ok;
 }
 
-__global__ void __launch_bounds__(PRT_BLOCK, 5)
+// Register-allocated for 4 waves per SIMD (<= 128 VGPRs, no spills).  Measured on MI355X
+// (same box, interleaved runs): 3 and 4 waves/SIMD tie, 5 (96 VGPRs, 60 B/lane of scratch)
+// is 6 % slower, 6 (80 VGPRs) 30 % slower -- spills in the fp64 hot path cost more than the
+// extra occupancy buys.
+#ifndef PRT_GEN_WAVES
+#define PRT_GEN_WAVES 4
+#endif
+__global__ void __launch_bounds__(PRT_BLOCK, PRT_GEN_WAVES)
 k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double* __restrict__ next,
              int64_t ld_next, double* __restrict__ rows, int64_t ld_rows, FusedCtrl* __restrict__ ctrl,
              GenCtrl* __restrict__ gen, int g, unsigned long long* __restrict__ tiles_cur,
@@ -744,6 +763,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   double t = PRT_INF;
   int prim = -1;
   bool live = false, carry = false;
+  Meta5 meta = {0, 0, 0, 0, 0};
   if (i < n && !failed) {
     r = load_ray8(rays, ld, i);
     nearest_hit(scene.prims, scene.code, scene.n_instr, r, lists, t, prim);
@@ -772,7 +792,8 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   // aggregates, so the look-back below mostly finds them ready instead of waiting.
   Shaded sh;
   sh.ok = true;
-  if (live) sh = interact_compute(scene, rays, ld, i, r, t, prim);
+  if (live) meta = load_meta(rays, ld, i);  // (loading these up front measured no faster)
+  if (live) sh = interact_compute(scene, meta, r, t, prim);
   if (wave == 0) {
     unsigned e_live, e_carry;
     if (!lookback(tiles_cur, tile, agg_live, agg_carry, e_live, e_carry) && lane == 0)
