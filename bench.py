@@ -96,13 +96,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    kernel_ms = launches = ray_generations = 0.0
+    kernel_ms = launches = ray_generations = rows_recorded = rays_carried = 0.0
     for _ in range(args.steps):
         rows, counts = step()
         st = scene.trace_stats()
         kernel_ms += st["kernel_ms"]
         launches += st["kernel_launches"]
         ray_generations += st["ray_generations"]
+        rows_recorded += st["rows"]
+        rays_carried += st["rays_carried"]
     torch.cuda.synchronize(device)
     if distributed:
         dist.barrier()
@@ -154,8 +156,16 @@ def main():
         return
 
     value = total_rows_per_step * args.steps / elapsed
-    algorithmic_bytes = ray_generations * BYTES_PER_RAY_GENERATION
+    # algorithmic bytes: 104 B state read per ray alive at generation entry,
+    # 120 B record row per recorded ray, 104 B next state per ray that goes on; = 328 B per
+    # ray-generation when every ray is recorded and goes on
+    algorithmic_bytes = 104.0 * ray_generations + 120.0 * rows_recorded + 104.0 * rays_carried
     achieved = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    traffic = None
+    traffic_file = os.path.join(ROOT, "profiles", "r1", "traffic.json")
+    if os.path.exists(traffic_file) and args.flags == 0 and n == RAYS_PER_GPU:
+        with open(traffic_file) as fh:
+            traffic = json.load(fh).get("hbm_bytes_per_launch")
     line = {
         "metric": "ray-surface intersections/sec, 1M-ray biconvex lens",
         "value": value,
@@ -185,11 +195,15 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
-            "kernel": "generation pipeline (see profiles/)",
+            "traffic": traffic,
+            "traffic_source": "profiles/r1/traffic.json (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, "
+                              "calibrated; same command, separate passes)" if traffic else None,
+            "kernel": "k_generation" if not (args.flags & 2) else "k_hit + k_scan + k_shade + k_advance",
             "algorithmic_bytes_per_launch": algorithmic_bytes / launches if launches else 0,
             "avg_launch_ms": kernel_ms / launches if launches else 0,
+            "launches_per_step": launches / args.steps,
             "kernel_ms_per_step": kernel_ms / args.steps,
+            "bytes_per_ray_generation_if_all_survive": BYTES_PER_RAY_GENERATION,
         },
         "end_to_end_trace": end_to_end,
     }

@@ -182,10 +182,11 @@ int64_t prt_trace(prt_scene* scene, int device, const double* rays, int64_t n, i
                   int64_t* rows_per_generation, void* workspace, int flags, void* stream);
 
 /* statistics of the last prt_trace on this scene (for bench.py's roofline):
- * out[0] = generations launched, out[1] = sum over generations of rays alive at entry,
+ * out[0] = generations that found rays, out[1] = sum over generations of rays alive at entry,
  * out[2] = GPU milliseconds spent in generation kernels (hipEvent, on the trace stream),
- * out[3] = number of generation-kernel launches. */
-int prt_trace_stats(const prt_scene* scene, double* out4);
+ * out[3] = number of generation-kernel launches, out[4] = sum of rows recorded,
+ * out[5] = sum of rays handed to the next generation, out[6..7] reserved. */
+int prt_trace_stats(const prt_scene* scene, double* out8);
 
 /* error codes */
 #define PRT_OK 0

@@ -79,7 +79,7 @@ struct prt_scene {
   std::vector<Operand> component_result;        // where each component program leaves its list
   std::vector<DeviceCopy> per_device;
   bool has_untracable = false;
-  double stats[4] = {0, 0, 0, 0};
+  double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 static int leaves_under(const prt_scene* s, int node) {
@@ -1164,6 +1164,8 @@ static int64_t trace_unfused(prt_scene* s, DeviceCopy* c, const double* rays, in
     const int64_t live = c->host_pinned[6];
     rows_per_generation[g] = live;
     total_rows += live;
+    s->stats[4] += (double)live;
+    s->stats[5] += (double)h->n_cur;
     n_cur = h->n_cur;
     src = dst;
     src_ld = n;
@@ -1223,6 +1225,8 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
       if (host_gen[b].n_in == 0) { done = true; break; }
       s->stats[0] += 1;
       s->stats[1] += (double)host_gen[b].n_in;
+      s->stats[4] += (double)host_gen[b].n_live;
+      s->stats[5] += (double)host_gen[b].n_carry;
       rows_per_generation[g + b] = host_gen[b].n_live;
       total_rows += host_gen[b].n_live;
     }
@@ -1246,7 +1250,7 @@ extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64
     return fail(PRT_ERR_ARG, "bad buffers (generation_limit must be <= 1024)");
   if (n >= (1ll << 31)) return fail(PRT_ERR_ARG, "at most 2^31-1 rays per call");
   for (int g = 0; g < generation_limit; ++g) rows_per_generation[g] = 0;
-  s->stats[0] = s->stats[1] = s->stats[2] = s->stats[3] = 0;
+  for (double& v : s->stats) v = 0;
   if (n == 0 || generation_limit == 0) return 0;
   if (flags & PRT_TRACE_UNFUSED)
     return trace_unfused(s, c, rays, n, ld, generation_limit, ray_offset, rows_out, rows_cap,
@@ -1255,15 +1259,15 @@ extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64
                              rows_per_generation, (char*)workspace, flags, (hipStream_t)stream);
   if (rc64 == PRT_ERR_STALL) {  // never observed; see lookback()
     for (int g = 0; g < generation_limit; ++g) rows_per_generation[g] = 0;
-    s->stats[0] = s->stats[1] = s->stats[2] = s->stats[3] = 0;
+    for (double& v : s->stats) v = 0;
     rc64 = trace_unfused(s, c, rays, n, ld, generation_limit, ray_offset, rows_out, rows_cap,
                          rows_per_generation, (char*)workspace, flags, (hipStream_t)stream);
   }
   return rc64;
 }
 
-extern "C" int prt_trace_stats(const prt_scene* s, double* out4) {
-  if (!s || !out4) return fail(PRT_ERR_ARG, "null argument");
-  for (int k = 0; k < 4; ++k) out4[k] = s->stats[k];
+extern "C" int prt_trace_stats(const prt_scene* s, double* out8) {
+  if (!s || !out8) return fail(PRT_ERR_ARG, "null argument");
+  for (int k = 0; k < 8; ++k) out8[k] = s->stats[k];
   return PRT_OK;
 }

@@ -184,10 +184,11 @@ class DeviceScene:
         return rows[:, :total], per_generation
 
     def trace_stats(self):
-        out = (ctypes.c_double * 4)()
+        out = (ctypes.c_double * 8)()
         _check(library().prt_trace_stats(self.handle, out))
         return {"generations": int(out[0]), "ray_generations": int(out[1]),
-                "kernel_ms": float(out[2]), "kernel_launches": int(out[3])}
+                "kernel_ms": float(out[2]), "kernel_launches": int(out[3]),
+                "rows": int(out[4]), "rays_carried": int(out[5])}
 
     # --- per-state entry points -----------------------------------------------------------------
     def propagate(self, rays):
