@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -796,8 +797,9 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   if (live) sh = interact_compute(scene, meta, r, t, prim);
   if (wave == 0) {
     unsigned e_live, e_carry;
-    if (!lookback(tiles_cur, tile, agg_live, agg_carry, e_live, e_carry) && lane == 0)
-      atomicExch(&ctrl->error, PRT_ERR_STALL);
+    bool ok = lookback(tiles_cur, tile, agg_live, agg_carry, e_live, e_carry);
+    if (ctrl->pad == 1 && tile == 3) ok = false;  // test hook: pretend the spin expired
+    if (!ok && lane == 0) atomicExch(&ctrl->error, PRT_ERR_STALL);
     if (lane == 0) { s_excl[0] = e_live; s_excl[1] = e_carry; }
   }
   __syncthreads();
@@ -823,7 +825,8 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
 
 // start of a fused trace: clear the control slots and tile buffer 0
 __global__ void k_fused_init(FusedCtrl* ctrl, GenCtrl* gen, int n_gen_slots,
-                             unsigned long long* tiles0, int64_t n_tiles, int64_t n, int64_t rows_cap) {
+                             unsigned long long* tiles0, int64_t n_tiles, int64_t n, int64_t rows_cap,
+                             int test_stall) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t k = i; k < n_tiles; k += stride) tiles0[k] = TILE_INVALID;
@@ -833,7 +836,7 @@ __global__ void k_fused_init(FusedCtrl* ctrl, GenCtrl* gen, int n_gen_slots,
     if (k == 0) z.n_in = n;
     gen[k] = z;
   }
-  if (i == 0) { ctrl->error = 0; ctrl->pad = 0; ctrl->rows_cap = rows_cap; }
+  if (i == 0) { ctrl->error = 0; ctrl->pad = test_stall; ctrl->rows_cap = rows_cap; }
 }
 
 // component.intersect(): run one component's program and spill its list
@@ -1192,8 +1195,12 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
   SceneDev sd = trace_scene_dev(s, c);
   const size_t lds = lds_bytes(sd.lds_slots);
   const int n_slots = generation_limit + 1;
+  // PRT_TEST_STALL=1 makes one tile report an expired look-back so that the tests can exercise
+  // the fallback to the three-kernel path.
+  const char* stall_env = getenv("PRT_TEST_STALL");
+  const int test_stall = (stall_env && stall_env[0] == '1') ? 1 : 0;
   hipLaunchKernelGGL(k_fused_init, dim3(64), dim3(256), 0, st, ctrl, gen, n_slots, tiles[0],
-                     (int64_t)blocks_for(n), n, rows_cap);
+                     (int64_t)blocks_for(n), n, rows_cap, test_stall);
 
   GenCtrl* host_gen = c->host_gen;
   int64_t bound = n, total_rows = 0;

@@ -318,3 +318,21 @@ def test_config2_one_million_rays():
     rows2, _ = ds.trace(dev(rays), 10)
     assert torch.equal(rows, rows2)
     ds.close()
+
+
+def test_lookback_stall_falls_back_to_three_kernel_path(monkeypatch):
+    """If the decoupled look-back ever gave up (it relies on in-order workgroup dispatch, which
+    is observed but not promised), prt_trace must transparently redo the loop on the path with
+    no inter-workgroup dependency and return the same frame."""
+    from pyrayt_amd.engine import DeviceScene
+    from pyrayt_amd.scene import SceneSnapshot
+
+    parts, rays = scenes.config2(scenes.product_api(), 20_000)
+    ds = DeviceScene(SceneSnapshot(parts))
+    want, want_counts = ds.trace(dev(rays), 10)
+    assert ds.trace_stats()["kernel_launches"] == 4  # one fused launch per generation (+1 empty)
+    monkeypatch.setenv("PRT_TEST_STALL", "1")
+    got, counts = ds.trace(dev(rays), 10)
+    assert ds.trace_stats()["kernel_launches"] == 12  # 3 generations x 4 kernels
+    assert counts == want_counts and torch.equal(got, want)
+    ds.close()
