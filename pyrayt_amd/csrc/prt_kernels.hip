@@ -224,7 +224,7 @@ static int validate_tree(const prt_scene* s, int node, int depth, std::vector<ch
   return validate_tree(s, n.right, depth + 1, seen);
 }
 
-static const size_t kMaxLdsBytes = 64 * 1024;  // keep >= 2 workgroups per CU
+static const size_t kMaxLdsBytes = 150 * 1024;  // one workgroup per CU at the very most (160 KiB LDS)
 
 extern "C" int prt_scene_create(const prt_prim* prims, int n_prims, const prt_node* nodes,
                                 int n_nodes, const int32_t* roots, int n_roots,
@@ -316,6 +316,8 @@ static int upload(T** dst, const std::vector<T>& src) {
   return PRT_OK;
 }
 
+static int raise_lds_limits();  // defined after the kernels
+
 // make sure the scene tables exist on `device` and make it current
 static int on_device(prt_scene* s, int device, DeviceCopy** out) {
   if (!s) return fail(PRT_ERR_ARG, "scene is null");
@@ -338,6 +340,8 @@ static int on_device(prt_scene* s, int device, DeviceCopy** out) {
     }
     HIP_TRY(hipHostMalloc((void**)&c.host_pinned, 8 * sizeof(int64_t), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&c.host_gen, 16 * 64, hipHostMallocDefault));
+    int rc_lds = raise_lds_limits();
+    if (rc_lds) return rc_lds;
     HIP_TRY(hipEventCreate(&c.ev0));
     HIP_TRY(hipEventCreate(&c.ev1));
   }
@@ -897,6 +901,14 @@ k_material_trace(const DevPrim* __restrict__ prim, double* __restrict__ rays, in
   rays[6 * ld + i] = dz;
   rays[7 * ld + i] = dw;
   rays[11 * ld + i] = index;
+}
+
+// deep CSG trees may need more than the default 64 KiB of dynamic LDS per workgroup
+static int raise_lds_limits() {
+  HIP_TRY(hipFuncSetAttribute((const void*)k_hit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_generation, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_intersect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  return PRT_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
