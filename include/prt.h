@@ -161,6 +161,37 @@ int prt_interact(prt_scene* scene, int device, const double* rays_in, int64_t n,
                  int generation, int generation_limit, double ray_offset, double* rows_out,
                  int64_t ld_rows, int64_t* n_live_out, void* workspace, void* stream);
 
+/* ---- ray sources (next to the hot path) --------------------------
+ * Source.generate_rays(n) (pyrayt/components.py:481-496): object-space pattern -> 4x4 world
+ * transform -> unit directions, written straight into a device ray set so that the initial
+ * RaySet never crosses PCIe.  Patterns: LineOfRays :511-530, CircleOfRays :533-558,
+ * ConeOfRays :561-585, WedgeOfRays :588-613 (closed form, same arithmetic as upstream) and
+ * Lamp :616-654 (upstream draws from numpy's global RNG; here a counter-based generator keyed
+ * by `seed` and the ray number: same distribution, not the same stream). */
+enum {
+  PRT_SRC_LINE = 0,   /* params: spacing */
+  PRT_SRC_CIRCLE = 1, /* params: diameter */
+  PRT_SRC_CONE = 2,   /* params: half angle (radians) */
+  PRT_SRC_WEDGE = 3,  /* params: full angle (radians) */
+  PRT_SRC_LAMP = 4    /* params: width, length, max angle (radians) */
+};
+typedef struct prt_source {
+  int32_t kind;      /* PRT_SRC_* */
+  int32_t reserved;
+  double params[4];
+  double wavelength; /* um */
+  double world[16];  /* row-major _world_coordinate_transform (world_objects.py:97-99) */
+  uint64_t seed;     /* PRT_SRC_LAMP only */
+} prt_source;
+
+/* Write rays [first, first+count) of the n_total rays this source emits into columns
+ * [col_offset, col_offset+count) of the device (13, >= col_offset+count) ray set `rays_out`
+ * (leading dimension ld); ray k gets id id_first + (k - first), generation 0, index 1,
+ * intensity 100 (Lamp: 100 cos(theta)). */
+int prt_generate_rays(int device, const prt_source* source, int64_t n_total, int64_t first,
+                      int64_t count, int64_t id_first, double* rays_out, int64_t ld,
+                      int64_t col_offset, void* stream);
+
 /* ---- the whole hot loop -------------------------------------------------------------------
  * RayTracer.trace() minus source generation and DataFrame construction
  * (pyrayt/_pyrayt.py:329-339 driving :370-452).  Runs every generation on the device.

@@ -237,6 +237,12 @@ class Source(cg.WorldObject):
         ray_set.wavelength = self._wavelength
         return ray_set
 
+    def device_spec(self):
+        """(kind, params, seed) if the HIP engine can emit this source's rays on the GPU
+        (``prt_generate_rays``), else None: a user-defined source is generated on the host by
+        its own ``_local_ray_generation`` and uploaded."""
+        return None
+
 
 class LineOfRays(Source):
     """Parallel rays along +x spread over ``spacing`` on the y axis (``components.py:511-530``)."""
@@ -251,6 +257,9 @@ class LineOfRays(Source):
             ray_set.rays[0, 1] = np.linspace(-self._spacing / 2, self._spacing / 2, n_rays)
         ray_set.rays[1, 0] = 1
         return ray_set
+
+    def device_spec(self):
+        return 0, (self._spacing,), 0
 
 
 class CircleOfRays(Source):
@@ -267,6 +276,9 @@ class CircleOfRays(Source):
         ray_set.rays[0, 2] = self._diameter / 2 * np.cos(theta)
         ray_set.rays[1, 0] = 1
         return ray_set
+
+    def device_spec(self):
+        return 1, (self._diameter,), 0
 
 
 class ConeOfRays(Source):
@@ -286,6 +298,9 @@ class ConeOfRays(Source):
         ray_set.rays[1, 0] = np.cos(self._angle)
         return ray_set
 
+    def device_spec(self):
+        return 2, (self._angle,), 0
+
 
 class WedgeOfRays(Source):
     """Fan of rays in the xy plane spanning ``angle`` degrees (``components.py:588-613``)."""
@@ -300,6 +315,9 @@ class WedgeOfRays(Source):
         ray_set.rays[1, 0] = np.cos(fan)
         ray_set.rays[1, 1] = np.sin(fan)
         return ray_set
+
+    def device_spec(self):
+        return 3, (self._angle,), 0
 
 
 class Lamp(Source):
@@ -326,6 +344,11 @@ class Lamp(Source):
         ray_set.intensity = 100.0 * np.cos(theta)
         return ray_set
 
+    def device_spec(self):
+        # a fresh stream per call, like upstream's draws from the global RNG
+        seed = int(np.random.randint(0, 2 ** 62))
+        return 4, (self._width, self._length, self._max_angle), seed
+
 
 class StaticLamp(Lamp):
     """A Lamp that returns the same rays for the same ``n_rays`` (``components.py:657-662``)."""
@@ -333,3 +356,6 @@ class StaticLamp(Lamp):
     @lru_cache(10)
     def generate_rays(self, n_rays):
         return super().generate_rays(n_rays)
+
+    def device_spec(self):
+        return None  # must replay the cached host rays (components.py:657-662)

@@ -51,6 +51,7 @@ def _declare(lib):
         "prt_trace": (c_i64, [c_p, c_int, c_p, c_i64, c_i64, c_int, c_d, c_p, c_i64, c_p, c_p,
                               c_int, c_p]),
         "prt_trace_stats": (c_int, [c_p, c_p]),
+        "prt_generate_rays": (c_int, [c_int, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = the library does not match prt.h
@@ -63,7 +64,7 @@ EXPORTED_SYMBOLS = (
     "prt_version", "prt_last_error", "prt_device_count", "prt_scene_create", "prt_scene_destroy",
     "prt_scene_component_rows", "prt_intersect", "prt_propagate", "prt_world_normals",
     "prt_material_trace", "prt_interact_workspace_bytes", "prt_interact",
-    "prt_trace_workspace_bytes", "prt_trace", "prt_trace_stats",
+    "prt_trace_workspace_bytes", "prt_trace", "prt_trace_stats", "prt_generate_rays",
 )
 
 
@@ -306,3 +307,42 @@ def material_trace(material, surface, ray_set):
         return ray_set
     finally:
         ds.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# device-side sources (include/prt.h prt_generate_rays)
+# ---------------------------------------------------------------------------------------------
+SOURCE_DTYPE = np.dtype(
+    [("kind", "<i4"), ("reserved", "<i4"), ("params", "<f8", (4,)), ("wavelength", "<f8"),
+     ("world", "<f8", (16,)), ("seed", "<u8")], align=True)
+assert SOURCE_DTYPE.itemsize == 184
+
+
+def sources_on_device(sources):
+    """True if every source can emit its rays on the GPU (has a ``device_spec``)."""
+    return all(getattr(src, "device_spec", None) is not None and src.device_spec() is not None
+               for src in sources)
+
+
+def generate_rays(sources, rays_per_source, device, lo=0, hi=None):
+    """The concatenated initial ray set of ``sources`` (pyrayt/_pyrayt.py:356-365), columns
+    [lo, hi) of it, built directly in HBM: a CUDA (13, hi-lo) float64 tensor with consecutive
+    ids.  Nothing crosses PCIe but the ~200-byte source descriptions."""
+    torch = _torch()
+    lib = library()
+    n = int(rays_per_source)
+    total = n * len(sources)
+    hi = total if hi is None else hi
+    out = torch.empty((RAY_ROWS, max(0, hi - lo)), dtype=torch.float64, device=device)
+    for k, src in enumerate(sources):
+        a, b = max(lo, k * n), min(hi, (k + 1) * n)
+        if b <= a:
+            continue
+        kind, params, seed = src.device_spec()
+        rec = np.zeros(1, dtype=SOURCE_DTYPE)
+        rec["kind"], rec["wavelength"], rec["seed"] = kind, src.wavelength, seed
+        rec["params"][0, : len(params)] = params
+        rec["world"][0] = np.asarray(src.get_world_transform(), dtype=float).reshape(-1)
+        _check(lib.prt_generate_rays(device.index or 0, rec.ctypes.data, n, a - k * n, b - a, a,
+                                     out.data_ptr(), out.stride(0), a - lo, _stream_ptr(torch, device)))
+    return out

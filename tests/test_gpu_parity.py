@@ -336,3 +336,98 @@ def test_lookback_stall_falls_back_to_three_kernel_path(monkeypatch):
     assert ds.trace_stats()["kernel_launches"] == 12  # 3 generations x 4 kernels
     assert counts == want_counts and torch.equal(got, want)
     ds.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# device-side sources (prt_generate_rays) against the reference's source fixtures and the
+# host implementations of the same patterns
+# ---------------------------------------------------------------------------------------------
+def _source_recipes():
+    import pyrayt_amd.components as c
+
+    return {
+        "line": lambda: c.LineOfRays(spacing=0.1, wavelength=0.5).move_x(-0.5).rotate_y(-3),
+        "circle": lambda: c.CircleOfRays(diameter=2.0).move(0.1, 0.2, 0.3),
+        "cone": lambda: c.ConeOfRays(6).move_x(-1.9).rotate_z(10),
+        "wedge": lambda: c.WedgeOfRays(30, wavelength=0.7).rotate_x(45),
+    }
+
+
+@pytest.mark.parametrize("name", ["line", "circle", "cone", "wedge"])
+def test_device_sources_match_reference(name):
+    from pyrayt_amd import engine
+
+    fx = helpers.load("sources.npz")
+    device = torch.device("cuda", 0)
+    for n in (1, 7, 100):
+        got = engine.generate_rays([_source_recipes()[name]()], n, device).cpu().numpy()
+        assert np.allclose(got, fx[f"{name}_{n}"], rtol=0, atol=1e-14), (name, n)
+    # large n against the host implementation of the same pattern, plus a sub-range (a shard)
+    src = _source_recipes()[name]()
+    want = np.asarray(src.generate_rays(100_003))
+    got = engine.generate_rays([src], 100_003, device).cpu().numpy()
+    assert np.allclose(got, want, rtol=0, atol=1e-14)
+    part = engine.generate_rays([src], 100_003, device, lo=33_333, hi=77_777).cpu().numpy()
+    assert np.array_equal(part, got[:, 33_333:77_777])
+
+
+def test_device_sources_concatenate_like_the_tracer():
+    """Several sources: consecutive ids, per-source wavelength, ranges that straddle sources."""
+    import pyrayt_amd as pyrayt
+    from pyrayt_amd import engine
+
+    srcs = [pyrayt.components.LineOfRays(0.1, wavelength=w).move_x(-0.5).rotate_y(-3)
+            for w in np.linspace(0.44, 0.75, 5)]
+    tracer = pyrayt.RayTracer(srcs, pyrayt.components.baffle((1, 1)), rays_per_source=1000)
+    want = np.asarray(tracer.initial_ray_set())
+    device = torch.device("cuda", 0)
+    got = engine.generate_rays(srcs, 1000, device).cpu().numpy()
+    assert np.allclose(got, want, rtol=0, atol=1e-14)
+    assert np.array_equal(got[12], np.arange(5000))
+    part = engine.generate_rays(srcs, 1000, device, lo=1500, hi=3200).cpu().numpy()
+    assert np.array_equal(part, got[:, 1500:3200])
+
+
+def test_lamp_on_device_is_lambertian():
+    import pyrayt_amd as pyrayt
+    from pyrayt_amd import engine
+
+    lamp = pyrayt.components.Lamp(2.0, 3.0, max_angle=60).move_x(1.0)
+    rays = engine.generate_rays([lamp], 400_000, torch.device("cuda", 0)).cpu().numpy()
+    d = rays[4:7]
+    assert np.allclose(np.linalg.norm(d, axis=0), 1.0, atol=1e-12)
+    cos_t = d[0]
+    assert cos_t.min() >= np.cos(np.radians(60)) - 1e-12
+    assert np.allclose(rays[9], 100.0 * cos_t, atol=1e-9)          # intensity = 100 cos(theta)
+    # inverse-CDF sampling: cos(theta) uniform on [cos(max), 1]
+    assert abs(cos_t.mean() - 0.75) < 2e-3 and abs(np.median(cos_t) - 0.75) < 3e-3
+    assert np.allclose(rays[0], 1.0) and abs(rays[1].mean()) < 5e-3 and abs(rays[2].mean()) < 8e-3
+    assert rays[1].min() >= -1.0 and rays[1].max() <= 1.0 and rays[2].min() >= -1.5 and rays[2].max() <= 1.5
+    assert abs(rays[1].std() - 2.0 / np.sqrt(12)) < 5e-3
+    host = np.asarray(lamp.generate_rays(50_000))                    # same law as the host Lamp
+    assert abs(host[4].mean() - cos_t.mean()) < 5e-3
+
+
+def test_tracer_with_device_sources_equals_host_sources():
+    import pyrayt_amd as pyrayt
+
+    def build():
+        lens = pyrayt.components.biconvex_lens(2, 2, 0.25, aperture=1)
+        focus = scenes.lensmakers_equation(2, -2, 1.5, 0.25)
+        src = pyrayt.components.ConeOfRays(cone_angle=6).move_x(-focus)
+        baffle = pyrayt.components.baffle((1, 1)).move_x(1)
+        return pyrayt.RayTracer(src, [lens, baffle], rays_per_source=20_000, generation_limit=100)
+
+    on_device = build()
+    frame_d = on_device.trace()
+    on_host = build()
+    on_host.device_sources = False
+    frame_h = on_host.trace()
+    assert frame_d.shape == frame_h.shape == (60_000, 15)
+    assert np.array_equal(frame_d["id"].to_numpy(), frame_h["id"].to_numpy())
+    assert np.array_equal(frame_d["generation"].to_numpy(), frame_h["generation"].to_numpy())
+    # surface ids differ by a constant offset only (two scene builds draw different global ids)
+    off = frame_d["surface"].to_numpy() - frame_h["surface"].to_numpy()
+    assert np.all(off == off[0])
+    cols = ["x0", "y0", "z0", "x1", "y1", "z1", "x_tilt", "y_tilt", "z_tilt", "index"]
+    assert np.allclose(frame_d[cols].to_numpy(), frame_h[cols].to_numpy(), rtol=0, atol=1e-9)
