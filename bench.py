@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--rays", type=int, default=RAYS_PER_GPU, help="rays per GPU")
     ap.add_argument("--flags", type=int, default=0, help="PRT_TRACE_* flags")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--generation-limit", type=int, default=GENERATION_LIMIT,
+                    help="experiments only: the north-star workload uses 10")
     ap.add_argument("--cpu-rays", type=int, default=1_000_000,
                     help="rays of the same workload timed on the CPU oracle")
     return ap.parse_args()
@@ -86,8 +88,10 @@ def main():
     scene = engine.DeviceScene(snap)
     rays_dev = torch.from_numpy(rays).to(device)
 
+    limit = args.generation_limit
+
     def step():
-        return scene.trace(rays_dev, GENERATION_LIMIT, flags=args.flags)
+        return scene.trace(rays_dev, limit, flags=args.flags)
 
     for _ in range(args.warmup):
         rows, counts = step()
@@ -128,7 +132,7 @@ def main():
         torch.cuda.synchronize(device)
         dist.barrier()
         g0 = time.perf_counter()
-        full, full_counts = pdist.assemble_rows(rows, counts, GENERATION_LIMIT, dist.group.WORLD, "all")
+        full, full_counts = pdist.assemble_rows(rows, counts, limit, dist.group.WORLD, "all")
         torch.cuda.synchronize(device)
         dist.barrier()
         gather_s = time.perf_counter() - g0
@@ -144,7 +148,7 @@ def main():
         torch.cuda.synchronize(device)
         e0 = time.perf_counter()
         up = torch.from_numpy(rays).to(device)
-        r2, _ = scene.trace(up, GENERATION_LIMIT, flags=args.flags)
+        r2, _ = scene.trace(up, limit, flags=args.flags)
         frame = rows_to_frame(r2)
         e1 = time.perf_counter()
         end_to_end = {"ms": (e1 - e0) * 1e3, "rows_per_s": frame.shape[0] / (e1 - e0)}
@@ -182,7 +186,7 @@ def main():
         "config": {
             "workload": "BASELINE config 2: biconvex_lens(2,2,0.25,aperture=1) + detector baffle, "
                         f"{n} rays per GPU from a seeded 6 degree cone at -f, generation_limit "
-                        f"{GENERATION_LIMIT}, rays resident in HBM",
+                        f"{limit}, rays resident in HBM",
             "rays_per_gpu": n,
             "rows_per_step_per_gpu": rows_per_step,
             "rows_per_generation": counts,
@@ -218,7 +222,7 @@ def main():
         sample = np.ascontiguousarray(rays[:, :m])
         flat = helpers.flat_scene(snap)
         c0 = time.perf_counter()
-        frame, _ = prt_oracle.trace(flat, sample, GENERATION_LIMIT)
+        frame, _ = prt_oracle.trace(flat, sample, limit)
         cpu_s = time.perf_counter() - c0
         line["cpu_baseline"] = {
             "value": frame.shape[0] / cpu_s,

@@ -756,6 +756,13 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   const int tile = blockIdx.x;
   const int64_t n = gen[g].n_in;
   if ((int64_t)tile * PRT_BLOCK >= n) return;  // uniform per workgroup; never a predecessor
+#ifdef PRT_STAGGER
+  // experiment: de-phase the workgroups that start together (co-resident ones are 256 apart)
+  if (blockIdx.x < 1024) {
+    const int steps = (blockIdx.x >> 8) * PRT_STAGGER;
+    for (int k = 0; k < steps; ++k) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   // A tile that sees an error raised earlier does no work but MUST still publish its (empty)
   // aggregate: tiles behind it may already be waiting on it.
   const bool failed = ctrl->error != 0;
@@ -801,7 +808,13 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   if (live) sh = interact_compute(scene, meta, r, t, prim);
   if (wave == 0) {
     unsigned e_live, e_carry;
+#if defined(PRT_ABLATE) && (PRT_ABLATE & 16)
+    bool ok = true;  // timing experiment: no look-back (rows land uncompacted, results invalid)
+    e_live = (unsigned)tile * PRT_BLOCK; e_carry = (unsigned)tile * PRT_BLOCK;
+    if (lane == 0) tile_store(tiles_cur + tile, tile_pack(TILE_PREFIX, e_live + agg_live, e_carry + agg_carry));
+#else
     bool ok = lookback(tiles_cur, tile, agg_live, agg_carry, e_live, e_carry);
+#endif
     if (ctrl->pad == 1 && tile == 3) ok = false;  // test hook: pretend the spin expired
     if (!ok && lane == 0) atomicExch(&ctrl->error, PRT_ERR_STALL);
     if (lane == 0) { s_excl[0] = e_live; s_excl[1] = e_carry; }
@@ -822,6 +835,16 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     return;
   }
   if (!live) return;
+#if defined(PRT_ABLATE) && (PRT_ABLATE & 32)
+  {  // timing experiment: no stores, but every shaded value stays live
+    const double sum = sh.generation + sh.intensity + sh.wavelength + sh.index_in + sh.id + sh.px +
+                       sh.py + sh.pz + sh.pw + sh.dx + sh.dy + sh.dz + sh.dw + sh.index +
+                       sh.surface_id + r.dx / norm3(r.dx, r.dy, r.dz) + r.dy / norm3(r.dx, r.dy, r.dz) +
+                       r.dz / norm3(r.dx, r.dy, r.dz);
+    if (sum == 12345.678) rows[0] = sum;
+    return;
+  }
+#endif
   interact_store(sh, r, carry, row_base + excl_live + live_rank, excl_carry + carry_rank, next,
                  ld_next, rows, ld_rows, next_generation, relaunch, ray_offset);
   if (!sh.ok) atomicExch(&ctrl->error, PRT_ERR_UNTRACABLE);
@@ -1216,8 +1239,10 @@ static TraceLayout trace_layout(int64_t n) {
   size_t at = 0;
   auto take = [&](size_t bytes) { size_t here = at; at += align_up(bytes, 256); return here; };
   l.ctrl = take(sizeof(TraceCtrl));
-  l.fctrl = take(sizeof(FusedCtrl));
-  l.gen = take((kMaxGenerationSlots + 1) * sizeof(GenCtrl));
+  // the fused path's control header sits right in front of its generation slots so that the
+  // host reads both back with one copy
+  l.fctrl = take(sizeof(GenCtrl) + (kMaxGenerationSlots + 1) * sizeof(GenCtrl));
+  l.gen = l.fctrl + sizeof(GenCtrl);
   l.gen_rows = take(kMaxGenerationSlots * sizeof(int64_t));
   l.tiles_a = take(nb * sizeof(unsigned long long));
   l.tiles_b = take(nb * sizeof(unsigned long long));
@@ -1332,7 +1357,7 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
   hipLaunchKernelGGL(k_fused_init, dim3(64), dim3(256), 0, st, ctrl, gen, n_slots, tiles[0],
                      (int64_t)blocks_for(n), n, rows_cap, test_stall);
 
-  GenCtrl* host_gen = c->host_gen;
+  GenCtrl* host_gen = c->host_gen + 1;  // slot -1 receives the control header
   int64_t bound = n, total_rows = 0;
   int g = 0, error = 0;
   bool done = false;
@@ -1349,14 +1374,18 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
                          tiles[(gg + 1) & 1], (double)(gg + 1), relaunch, ray_offset, keep_absorbed);
     }
     HIP_TRY(hipEventRecord(c->ev1, st));
-    HIP_TRY(hipMemcpyAsync(host_gen, gen + g, (batch + 1) * sizeof(GenCtrl), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(c->host_pinned, ctrl, sizeof(FusedCtrl), hipMemcpyDeviceToHost, st));
+    if (g == 0) {  // header + slots 0..batch are contiguous: one copy
+      HIP_TRY(hipMemcpyAsync(host_gen - 1, ctrl, (batch + 2) * sizeof(GenCtrl), hipMemcpyDeviceToHost, st));
+    } else {
+      HIP_TRY(hipMemcpyAsync(host_gen, gen + g, (batch + 1) * sizeof(GenCtrl), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(host_gen - 1, ctrl, sizeof(FusedCtrl), hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(hipStreamSynchronize(st));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     s->stats[2] += ms;
     s->stats[3] += batch;
-    error = ((const FusedCtrl*)c->host_pinned)->error;
+    error = ((const FusedCtrl*)(host_gen - 1))->error;
     if (error) break;
     for (int b = 0; b < batch; ++b) {
       if (host_gen[b].n_in == 0) { done = true; break; }

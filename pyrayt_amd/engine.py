@@ -165,7 +165,7 @@ class DeviceScene:
         if n == 0 or limit <= 0:
             return torch.empty((RECORD_COLS, 0), dtype=torch.float64, device=dev), []
         cap = int(rows_cap) if rows_cap is not None else n * min(limit, 4)
-        work = torch.empty(int(lib.prt_trace_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        work = self._workspace(torch, n, dev)
         counts = (ctypes.c_int64 * limit)()
         while True:
             rows = torch.empty((RECORD_COLS, cap), dtype=torch.float64, device=dev)
@@ -183,6 +183,14 @@ class DeviceScene:
         while per_generation and per_generation[-1] == 0:
             per_generation.pop()
         return rows[:, :total], per_generation
+
+    def _workspace(self, torch, n, dev):
+        """Scratch for prt_trace (ping-pong ray sets, control words); kept between calls."""
+        need = int(library().prt_trace_workspace_bytes(n))
+        cached = getattr(self, "_work", None)
+        if cached is None or cached.device != dev or cached.numel() < need:
+            self._work = cached = torch.empty(need, dtype=torch.uint8, device=dev)
+        return cached
 
     def trace_stats(self):
         out = (ctypes.c_double * 8)()
