@@ -315,9 +315,14 @@ __device__ __forceinline__ double glass_index(const DevPrim* __restrict__ p, dou
 
 // material.trace for a ray whose origin (px..pw) already sits on the surface.
 // d (4 comps) and index are updated in place.  Returns false for an untracable material.
+// (ux, uy, uz) is the incoming direction already divided by norm3(dx,dy,dz) -- the record row's
+// tilt columns.  When dw == 0, norm4(d) is bit-identical to norm3(d) (adding +0 is exact), so
+// the refraction's own normalisation d / |d| (operations.py:125) IS that vector and its
+// square root and divisions are not repeated.
 __device__ __forceinline__ bool shade(const DevPrim* __restrict__ p, double px, double py,
                                       double pz, double pw, double& dx, double& dy, double& dz,
-                                      double& dw, double wavelength, double& index) {
+                                      double& dw, double wavelength, double& index, double tx,
+                                      double ty, double tz) {
   const int kind = p->mat_kind;
   if (kind == MAT_NONE) return false;
   if (kind == MAT_ABSORBER) {  // materials.py:47-50
@@ -337,8 +342,11 @@ __device__ __forceinline__ bool shade(const DevPrim* __restrict__ p, double px, 
   }
   // glass: operations.py:110-162
   const double n_mat = glass_index(p, wavelength);
-  const double len = norm4(dx, dy, dz, dw);
-  const double vx = dx / len, vy = dy / len, vz = dz / len, vw = dw / len;
+  double vx = tx, vy = ty, vz = tz, vw = dw;  // dw == 0: (+-0) / |d| = +-0
+  if (dw != 0.0) {
+    const double len = norm4(dx, dy, dz, dw);
+    vx = dx / len; vy = dy / len; vz = dz / len; vw = dw / len;
+  }
   const double cos_p = ((vx * nx + vy * ny) + vz * nz) + vw * nw;
   const double cos_n = ((vx * -nx + vy * -ny) + vz * -nz) + vw * -nw;
   const bool leaving = cos_p > 0;
@@ -359,7 +367,9 @@ __device__ __forceinline__ bool shade(const DevPrim* __restrict__ p, double px, 
     ux = vx + k * mx; uy = vy + k * my; uz = vz + k * mz; uw = vw + k * mw;
   }
   const double ulen = norm4(ux, uy, uz, uw);
-  dx = ux / ulen; dy = uy / ulen; dz = uz / ulen; dw = uw / ulen;
+  dx = ux / ulen; dy = uy / ulen; dz = uz / ulen;
+  dw = uw;  // (+-0) / ulen = +-0 for the finite positive ulen of a non-degenerate ray
+  if (uw != 0.0 || !(ulen > 0.0 && ulen < PRT_INF)) dw = uw / ulen;
   index = (radicand > 0) ? n2 : n1;
   return true;
 }

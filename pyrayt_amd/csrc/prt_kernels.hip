@@ -493,6 +493,7 @@ struct Shaded {
   double generation, intensity, wavelength, index_in, id;  // pre-hit metadata
   double px, py, pz, pw;                                    // hit point
   double dx, dy, dz, dw, index;                             // post-interaction direction / index
+  double tx, ty, tz;                                        // unit tilt of the incoming ray
   double surface_id;
   bool ok;                                                  // false: untracable material
 };
@@ -524,6 +525,9 @@ __device__ __forceinline__ Shaded interact_compute(const SceneDev& scene, const 
   s.index = s.index_in;
   s.surface_id = -1.0;
   s.ok = true;
+  // tilt columns: pre-hit direction over its 3-norm (_pyrayt.py:176-177)
+  const double tilt = norm3(r.dx, r.dy, r.dz);
+  s.tx = r.dx / tilt; s.ty = r.dy / tilt; s.tz = r.dz / tilt;
   // material dispatch: the primitive table is wave-uniform data, so lanes that hit the same
   // surface shade together and the loop runs once per distinct surface hit in the wave
   unsigned long long todo = __ballot(true);
@@ -532,7 +536,8 @@ __device__ __forceinline__ Shaded interact_compute(const SceneDev& scene, const 
     const int cur = __shfl(prim, leader);
     if (prim == cur) {
       const DevPrim* __restrict__ p = scene.prims + cur;
-      s.ok = shade(p, s.px, s.py, s.pz, s.pw, s.dx, s.dy, s.dz, s.dw, s.wavelength, s.index);
+      s.ok = shade(p, s.px, s.py, s.pz, s.pw, s.dx, s.dy, s.dz, s.dw, s.wavelength, s.index,
+                   s.tx, s.ty, s.tz);
       s.surface_id = p->surface_id;
     }
     todo &= ~__ballot(prim == cur);
@@ -545,7 +550,6 @@ __device__ __forceinline__ void interact_store(const Shaded& s, const Ray8& r, b
                                                double* __restrict__ rows, int64_t ld_rows,
                                                double next_generation, int relaunch, double ray_offset) {
   // record row (_pyrayt.py:168-186): pre-hit metadata, surface, start, end, unit tilt
-  const double tilt = norm3(r.dx, r.dy, r.dz);
   rows[PRT_COL_GENERATION * ld_rows + row] = s.generation;
   rows[PRT_COL_INTENSITY * ld_rows + row] = s.intensity;
   rows[PRT_COL_WAVELENGTH * ld_rows + row] = s.wavelength;
@@ -558,9 +562,9 @@ __device__ __forceinline__ void interact_store(const Shaded& s, const Ray8& r, b
   rows[PRT_COL_X1 * ld_rows + row] = s.px;
   rows[PRT_COL_Y1 * ld_rows + row] = s.py;
   rows[PRT_COL_Z1 * ld_rows + row] = s.pz;
-  rows[PRT_COL_XTILT * ld_rows + row] = r.dx / tilt;
-  rows[PRT_COL_YTILT * ld_rows + row] = r.dy / tilt;
-  rows[PRT_COL_ZTILT * ld_rows + row] = r.dz / tilt;
+  rows[PRT_COL_XTILT * ld_rows + row] = s.tx;
+  rows[PRT_COL_YTILT * ld_rows + row] = s.ty;
+  rows[PRT_COL_ZTILT * ld_rows + row] = s.tz;
   if (carry) {
     // next state (_pyrayt.py:437-449): generation + 1, re-launch 1e-6 along the new direction
     double qx = s.px, qy = s.py, qz = s.pz, qw = s.pw;
@@ -839,14 +843,19 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   {  // timing experiment: no stores, but every shaded value stays live
     const double sum = sh.generation + sh.intensity + sh.wavelength + sh.index_in + sh.id + sh.px +
                        sh.py + sh.pz + sh.pw + sh.dx + sh.dy + sh.dz + sh.dw + sh.index +
-                       sh.surface_id + r.dx / norm3(r.dx, r.dy, r.dz) + r.dy / norm3(r.dx, r.dy, r.dz) +
-                       r.dz / norm3(r.dx, r.dy, r.dz);
+                       sh.surface_id + sh.tx + sh.ty + sh.tz;
     if (sum == 12345.678) rows[0] = sum;
     return;
   }
 #endif
+#if defined(PRT_ABLATE) && (PRT_ABLATE & 64)
+  // timing experiment: same 28 store instructions, but every tile writes the same 56 KiB (L2 hits)
+  interact_store(sh, r, carry, threadIdx.x, threadIdx.x, next, ld_next, rows, ld_rows,
+                 next_generation, relaunch, ray_offset);
+#else
   interact_store(sh, r, carry, row_base + excl_live + live_rank, excl_carry + carry_rank, next,
                  ld_next, rows, ld_rows, next_generation, relaunch, ray_offset);
+#endif
   if (!sh.ok) atomicExch(&ctrl->error, PRT_ERR_UNTRACABLE);
 }
 
@@ -918,7 +927,9 @@ k_material_trace(const DevPrim* __restrict__ prim, double* __restrict__ rays, in
   if (i >= k) return;
   const Ray8 r = load_ray8(rays, ld, i);
   double dx = r.dx, dy = r.dy, dz = r.dz, dw = r.dw, index = rays[11 * ld + i];
-  shade(prim, r.ox, r.oy, r.oz, r.ow, dx, dy, dz, dw, rays[10 * ld + i], index);
+  const double len3 = norm3(dx, dy, dz);
+  shade(prim, r.ox, r.oy, r.oz, r.ow, dx, dy, dz, dw, rays[10 * ld + i], index, dx / len3, dy / len3,
+        dz / len3);
   rays[4 * ld + i] = dx;
   rays[5 * ld + i] = dy;
   rays[6 * ld + i] = dz;
