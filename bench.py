@@ -71,13 +71,22 @@ def main():
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
         if not distributed and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    n_devices = torch.cuda.device_count()
+    local_device = local_rank % max(1, n_devices)
+    torch.cuda.set_device(local_device)
+    device = torch.device("cuda", local_device)
+    # collectives run over RCCL ("nccl") on device tensors; PRT_DIST_BACKEND=gloo (CPU tensors) only
+    # exists so that the multi-rank code path can be exercised on a single-GPU box
+    backend = os.environ.get("PRT_DIST_BACKEND", "nccl")
+    comm_device = device if backend == "nccl" else torch.device("cpu")
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     # the workload: config 2, this rank's contiguous id range of a (world x rays) job
     n = args.rays
@@ -117,7 +126,7 @@ def main():
 
     rows_per_step = int(rows.shape[1])
     if distributed:
-        agg = torch.tensor([elapsed, float(rows_per_step)], dtype=torch.float64, device=device)
+        agg = torch.tensor([elapsed, float(rows_per_step)], dtype=torch.float64, device=comm_device)
         tmax = agg.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
@@ -132,7 +141,7 @@ def main():
         torch.cuda.synchronize(device)
         dist.barrier()
         g0 = time.perf_counter()
-        full, full_counts = pdist.assemble_rows(rows, counts, limit, dist.group.WORLD, "all")
+        full, full_counts = pdist.assemble_rows(rows.to(comm_device), counts, limit, dist.group.WORLD, "all")
         torch.cuda.synchronize(device)
         dist.barrier()
         gather_s = time.perf_counter() - g0
