@@ -13,6 +13,7 @@ from . import materials
 from . import components
 from .rayset import RaySet
 from .tracer import RayTracer
+from .frame import DeviceFrame
 
-__all__ = ["RayTracer", "RaySet", "materials", "components", "g3d"]
+__all__ = ["RayTracer", "RaySet", "DeviceFrame", "materials", "components", "g3d"]
 __version__ = "0.1.0"
