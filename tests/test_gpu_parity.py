@@ -458,3 +458,49 @@ def test_device_frame_selections_match_pandas():
     assert np.isclose(rms, np.sqrt(((want["y1"] - cy) ** 2 + (want["z1"] - cz) ** 2).mean()))
     tracer.calculate_source_ids()
     assert set(tracer.get_results()["source_id"]) == {0}
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs 3-5 at (per-GPU) full size: size-independent properties + the oracle on a
+# subsample.  Rays are independent, so the rows of any subset of rays must be exactly the rows
+# the full trace recorded for those ids.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,args,limit", [
+    ("config3", (4_000_000,), 10),          # Cooke triplet, 12 primitives, 4M rays
+    ("config4", (1_000_000,), 10),          # prism, 8 wavelengths x 1M rays
+    ("config5", (2_000_000,), 10),          # 16M rays / 8 GPUs
+])
+def test_baseline_configs_at_full_size(name, args, limit):
+    from oracle import c_oracle
+    from pyrayt_amd.engine import DeviceScene
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    CountedObject.reset_ids()
+    parts, rays = scenes.SCENES[name](scenes.product_api(), *args)
+    n = rays.shape[1]
+    snap = SceneSnapshot(parts)
+    ds = DeviceScene(snap)
+    rows, counts = ds.trace(dev(rays), limit)
+    assert rows.shape[1] == sum(counts) > n
+    gens = rows[0]
+    ids = rows[4]
+    # generation-major, ids strictly ascending inside a generation
+    assert bool((gens[1:] >= gens[:-1]).all())
+    start = 0
+    for g, c in enumerate(counts):
+        seg = ids[start:start + c]
+        assert bool((gens[start:start + c] == g).all()) and bool((seg[1:] > seg[:-1]).all())
+        start += c
+    tilt = torch.sqrt(rows[12] ** 2 + rows[13] ** 2 + rows[14] ** 2)
+    assert bool(((tilt - 1).abs() < 1e-12).all())
+    # subsample: every 64th ray through the C oracle
+    pick = np.arange(0, n, 64)
+    want, want_counts = c_oracle.trace(helpers.flat_scene(snap), np.ascontiguousarray(rays[:, pick]), limit)
+    keep = torch.isin(ids, torch.from_numpy(pick.astype(np.float64)).to(ids.device))
+    got = rows[:, keep].cpu().numpy().T
+    helpers.assert_frames_match(got, want, what=f"{name} subsample")
+    # and tracing the subset alone gives exactly those rows (independence of rays)
+    sub_rows, sub_counts = ds.trace(dev(rays[:, pick]), limit)
+    assert sub_counts == want_counts and np.array_equal(sub_rows.cpu().numpy().T, got)
+    ds.close()
