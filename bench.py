@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--rays", type=int, default=RAYS_PER_GPU, help="rays per GPU")
     ap.add_argument("--flags", type=int, default=0, help="PRT_TRACE_* flags")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5"],
+                    help="informational runs of the other BASELINE scenes; the bench line is config2")
     ap.add_argument("--generation-limit", type=int, default=GENERATION_LIMIT,
                     help="experiments only: the north-star workload uses 10")
     ap.add_argument("--cpu-rays", type=int, default=1_000_000,
@@ -91,7 +93,13 @@ def main():
     # the workload: config 2, this rank's contiguous id range of a (world x rays) job
     n = args.rays
     CountedObject.reset_ids()
-    parts, rays = scenes.config2(scenes.product_api(), n, seed=1234 + rank)
+    if args.workload == "config2":
+        parts, rays = scenes.config2(scenes.product_api(), n, seed=1234 + rank)
+    elif args.workload == "config4":
+        parts, rays = scenes.config4(scenes.product_api(), n // 8)
+    else:
+        parts, rays = scenes.SCENES[args.workload](scenes.product_api(), n)
+    n = rays.shape[1]
     rays[12] += rank * n
     snap = SceneSnapshot(parts)
     scene = engine.DeviceScene(snap)
@@ -193,7 +201,8 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": "BASELINE config 2: biconvex_lens(2,2,0.25,aperture=1) + detector baffle, "
+            "workload": ("" if args.workload == "config2" else f"[{args.workload} scene, informational] ") +
+                        "BASELINE config 2: biconvex_lens(2,2,0.25,aperture=1) + detector baffle, "
                         f"{n} rays per GPU from a seeded 6 degree cone at -f, generation_limit "
                         f"{limit}, rays resident in HBM",
             "rays_per_gpu": n,

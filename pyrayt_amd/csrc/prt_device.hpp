@@ -39,7 +39,10 @@ enum { CSG_UNION = 1, CSG_INTERSECT = 2, CSG_DIFFERENCE = 3 };
 enum { PRIM_SPHERE = 0, PRIM_CYLINDER = 1, PRIM_PLANE = 2, PRIM_CUBE = 3, PRIM_PARABOLOID = 4 };
 enum { MAT_NONE = 0, MAT_ABSORBER = 1, MAT_MIRROR = 2, MAT_CONST = 3, MAT_SELLMEIER = 4 };
 
-// One step of the linearised (post-order) component program.
+// One step of the linearised (post-order) component program.  A step is self-contained: a LEAF
+// step carries its primitive's kind, parameters and the three used rows of M^-1, a CSG step its
+// cull box, so the interpreter fetches a whole step with one batch of scalar loads (one round
+// trip to the constant cache per step instead of one per field group it happens to touch).
 struct DevInstr {
   int32_t kind;   // I_*
   int32_t a0;     // LEAF: prim        CSG: operation    ROOT: operand mode
@@ -50,8 +53,9 @@ struct DevInstr {
   int32_t a5;     //                   CSG: right base
   int32_t a6;     //                   CSG: right length
   int32_t a7;     //                   CSG: out base
-  int32_t pad[3];
-  double aabb[6]; // CSG: xmin,xmax,ymin,ymax,zmin,zmax world-space cull box
+  int32_t pad[2]; // CSG: [0] root node of a component, [1] cull box implied (see csg_node)
+  int32_t type;   // LEAF: PRIM_*
+  double data[18];// LEAF: params[0..5], M^-1 rows 0..2 [6..17]   CSG: cull box [0..5]
 };
 
 struct Ray8 {
@@ -182,18 +186,18 @@ __device__ __forceinline__ bool box_touched(const double* __restrict__ span, con
 }
 
 // ---- TracerSurface.intersect: world -> object, primitive test, ascending pair -----------------
-__device__ __forceinline__ void surface_pair(const DevPrim* __restrict__ p, const Ray8& r,
+// `type`, q = params[6] and m = rows 0..2 of M^-1 (12 values) come from the step record.
+__device__ __forceinline__ void surface_pair(int type, const double* __restrict__ q,
+                                             const double* __restrict__ m, const Ray8& r,
                                              double& t0, double& t1) {
-  const double* m = p->minv;
   const double ox = row_dot(m, 0, r.ox, r.oy, r.oz, r.ow);
   const double oy = row_dot(m, 1, r.ox, r.oy, r.oz, r.ow);
   const double oz = row_dot(m, 2, r.ox, r.oy, r.oz, r.ow);
   const double dx = row_dot(m, 0, r.dx, r.dy, r.dz, r.dw);
   const double dy = row_dot(m, 1, r.dx, r.dy, r.dz, r.dw);
   const double dz = row_dot(m, 2, r.dx, r.dy, r.dz, r.dw);
-  const double* q = p->params;
   double h0, h1;
-  switch (p->type) {
+  switch (type) {
     case PRIM_SPHERE: {  // primitives.py:241-271 (no guard on a == 0)
       const double a = (dx * dx + dy * dy) + dz * dz;
       const double b = 2 * ((dx * ox + dy * oy) + dz * oz);
@@ -623,20 +627,20 @@ __device__ __forceinline__ void csg_step(const DevInstr* __restrict__ in, const 
   const bool implied = in->pad[1] != 0;
   produced_root = is_root;
   if (lmode == OPER_REGA && rmode == OPER_REGB) {
-    csg_node<2, 2, true, true>(op, 0, 0, obase, in->aabb, ray, implied, is_root, lists, ra, rb, node_t, node_prim);
+    csg_node<2, 2, true, true>(op, 0, 0, obase, in->data, ray, implied, is_root, lists, ra, rb, node_t, node_prim);
     return;
   }
   if (lmode == OPER_LDS && rmode == OPER_REGB && ml == 4) {
-    csg_node<4, 2, false, true>(op, lbase, 0, obase, in->aabb, ray, implied, is_root, lists, ra, rb, node_t, node_prim);
+    csg_node<4, 2, false, true>(op, lbase, 0, obase, in->data, ray, implied, is_root, lists, ra, rb, node_t, node_prim);
     return;
   }
   if (lmode == OPER_REGA && rmode == OPER_LDS && mr == 4) {
-    csg_node<2, 4, true, false>(op, 0, rbase, obase, in->aabb, ray, implied, is_root, lists, ra, rb, node_t, node_prim);
+    csg_node<2, 4, true, false>(op, 0, rbase, obase, in->data, ray, implied, is_root, lists, ra, rb, node_t, node_prim);
     return;
   }
   const Operand L = {lmode, lbase, ml};
   const Operand R = {rmode, rbase, mr};
-  csg_merge(op, L, R, obase, box_touched(in->aabb, ray), lists, ra, rb);
+  csg_merge(op, L, R, obase, box_touched(in->data, ray), lists, ra, rb);
   if (is_root) {
     const Operand o = {OPER_LDS, obase, ml + mr};
     first_positive(o, lists, ra, rb, node_t, node_prim);
@@ -653,15 +657,16 @@ __device__ __forceinline__ void nearest_hit(const DevPrim* __restrict__ prims,
   best_prim = -1;
   Pair ra = {PRT_INF, PRT_INF, -1}, rb = {PRT_INF, PRT_INF, -1};
   for (int pc = 0; pc < n_instr; ++pc) {
-    const DevInstr* __restrict__ in = code + pc;
+    const DevInstr step = code[pc];  // the whole record, one batch of scalar loads
+    const DevInstr* in = &step;
     const int kind = in->kind;
     if (kind == I_LEAF) {
       const int p = in->a0;
       double t0, t1;
 #if defined(PRT_ABLATE) && (PRT_ABLATE & 4)
-      t0 = ray.ox + prims[p].params[0]; t1 = ray.dx;  // timing experiment: no primitive math
+      t0 = ray.ox + in->data[0]; t1 = ray.dx;  // timing experiment: no primitive math
 #else
-      surface_pair(prims + p, ray, t0, t1);
+      surface_pair(in->type, in->data, in->data + 6, ray, t0, t1);
 #endif
       const int dst = in->a1;
       if (dst == OPER_REGA) {

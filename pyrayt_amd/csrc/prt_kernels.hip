@@ -114,6 +114,10 @@ struct Compiler {
     DevInstr in = blank(I_LEAF);
     in.a0 = s->nodes[node].prim;
     in.a1 = mode;
+    const prt_prim& pr = s->prims[in.a0];
+    in.type = pr.type;
+    for (int k = 0; k < 6; ++k) in.data[k] = pr.params[k];
+    for (int k = 0; k < 12; ++k) in.data[6 + k] = pr.minv[k];  // rows 0..2 of M^-1
     Operand o = {mode, 0, 2};
     if (mode == OPER_LDS) {
       o.base = ceiling - 2;
@@ -164,7 +168,7 @@ struct Compiler {
     in.a1 = L.mode; in.a2 = L.base; in.a3 = L.len;
     in.a4 = R.mode; in.a5 = R.base; in.a6 = R.len;
     in.a7 = base;
-    for (int k = 0; k < 6; ++k) in.aabb[k] = n.aabb[k];
+    for (int k = 0; k < 6; ++k) in.data[k] = n.aabb[k];
     out.push_back(in);
     lowest = std::min(lowest, base);
     return Operand{OPER_LDS, base, L.len + R.len};
@@ -740,6 +744,14 @@ __device__ __forceinline__ bool lookback(unsigned long long* state, int tile, un
   return ok;
 }
 
+#ifdef PRT_TIMING
+// experiment build: s_memtime stamps of every wave of generation 0 at 8 points of k_generation
+__device__ long long g_stamps[16384 * 4 * 8];
+#define STAMP(k) do { if (g == 0 && (threadIdx.x & 63) == 0 && blockIdx.x < 16384) g_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
 // Register-allocated for 4 waves per SIMD (<= 128 VGPRs, no spills).  Measured on MI355X
 // (same box, interleaved runs): 3 and 4 waves/SIMD tie, 5 (96 VGPRs, 60 B/lane of scratch)
 // is 6 % slower, 6 (80 VGPRs) 30 % slower -- spills in the fp64 hot path cost more than the
@@ -780,13 +792,19 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   int prim = -1;
   bool live = false, carry = false;
   Meta5 meta = {0, 0, 0, 0, 0};
+  STAMP(0);
   if (i < n && !failed) {
     r = load_ray8(rays, ld, i);
+#ifdef PRT_TIMING
+    if (r.ox + r.oy + r.oz + r.ow + r.dx + r.dy + r.dz + r.dw == 1.2345e300) t = 0;  // force the wait here
+    STAMP(1);
+#endif
     nearest_hit(scene.prims, scene.code, scene.n_instr, r, lists, t, prim);
     live = is_live(r, prim);
     carry = live && (keep_absorbed || scene.prims[prim].mat_kind != MAT_ABSORBER);
   }
   // workgroup aggregate and ranks: wave ballots + popcounts, four waves combined through LDS
+  STAMP(2);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long m_live = __ballot(live), m_carry = __ballot(carry);
   const unsigned long long below = (1ull << lane) - 1ull;
@@ -802,6 +820,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     agg_live += s_wave_live[w];
     agg_carry += s_wave_carry[w];
   }
+  STAMP(3);
   if (threadIdx.x == 0 && tile > 0)
     tile_store(tiles_cur + tile, tile_pack(TILE_AGGREGATE, agg_live, agg_carry));
   // Shade BEFORE asking where the results go: the predecessors get this long to publish their
@@ -809,7 +828,12 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   Shaded sh;
   sh.ok = true;
   if (live) meta = load_meta(rays, ld, i);  // (loading these up front measured no faster)
+#ifdef PRT_TIMING
+  if (meta.generation + meta.intensity + meta.wavelength + meta.index + meta.id == 1.2345e300) t = 0;
+  STAMP(4);
+#endif
   if (live) sh = interact_compute(scene, meta, r, t, prim);
+  STAMP(5);
   if (wave == 0) {
     unsigned e_live, e_carry;
 #if defined(PRT_ABLATE) && (PRT_ABLATE & 16)
@@ -824,6 +848,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     if (lane == 0) { s_excl[0] = e_live; s_excl[1] = e_carry; }
   }
   __syncthreads();
+  STAMP(6);
   const int64_t excl_live = s_excl[0], excl_carry = s_excl[1];
 
   const int64_t last_tile = (n - 1) / PRT_BLOCK;
@@ -857,6 +882,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
                  ld_next, rows, ld_rows, next_generation, relaunch, ray_offset);
 #endif
   if (!sh.ok) atomicExch(&ctrl->error, PRT_ERR_UNTRACABLE);
+  STAMP(7);
 }
 
 // start of a fused trace: clear the control slots and tile buffer 0
@@ -886,10 +912,11 @@ k_intersect(SceneDev scene, Operand result, const double* __restrict__ rays, int
   // reuse the interpreter: without an I_ROOT it only builds the lists
   Pair ra = {PRT_INF, PRT_INF, -1}, rb = {PRT_INF, PRT_INF, -1};
   for (int pc = 0; pc < scene.n_instr; ++pc) {
-    const DevInstr* __restrict__ in = scene.code + pc;
+    const DevInstr step = scene.code[pc];
+    const DevInstr* in = &step;
     if (in->kind == I_LEAF) {
       double t0, t1;
-      surface_pair(scene.prims + in->a0, r, t0, t1);
+      surface_pair(in->type, in->data, in->data + 6, r, t0, t1);
       if (in->a1 == OPER_REGA) { ra.t0 = t0; ra.t1 = t1; ra.prim = in->a0; }
       else if (in->a1 == OPER_REGB) { rb.t0 = t0; rb.t1 = t1; rb.prim = in->a0; }
       else { lists.put(in->a2, t0, in->a0); lists.put(in->a2 + 1, t1, in->a0); }
@@ -1411,6 +1438,14 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
     if (bound == 0) done = true;
     g += batch;
   }
+#ifdef PRT_TIMING
+  if (const char* path = getenv("PRT_TIMING_FILE")) {
+    std::vector<long long> host(16384 * 4 * 8);
+    if (hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(g_stamps), host.size() * sizeof(long long)) == hipSuccess) {
+      if (FILE* f = fopen(path, "wb")) { fwrite(host.data(), sizeof(long long), host.size(), f); fclose(f); }
+    }
+  }
+#endif
   if (error) return trace_error(error);
   return total_rows;
 }
