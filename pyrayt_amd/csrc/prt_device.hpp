@@ -388,16 +388,17 @@ __device__ __forceinline__ bool shade(const DevPrim* __restrict__ p, double px, 
 extern __shared__ double lds_dyn[];
 
 struct LaneLists {
-  int slots;  // number of slots (rows) per lane
+  int total;  // slots (rows) per lane over all rays a lane carries: the int32 rows start behind them
+  int off;    // first slot of this ray's lists
   __device__ __forceinline__ double get_t(int slot) const {
-    return lds_dyn[slot * PRT_BLOCK + threadIdx.x];
+    return lds_dyn[(off + slot) * PRT_BLOCK + threadIdx.x];
   }
   __device__ __forceinline__ int get_id(int slot) const {
-    return reinterpret_cast<const int*>(lds_dyn + slots * PRT_BLOCK)[slot * PRT_BLOCK + threadIdx.x];
+    return reinterpret_cast<const int*>(lds_dyn + total * PRT_BLOCK)[(off + slot) * PRT_BLOCK + threadIdx.x];
   }
   __device__ __forceinline__ void put(int slot, double v, int i) const {
-    lds_dyn[slot * PRT_BLOCK + threadIdx.x] = v;
-    reinterpret_cast<int*>(lds_dyn + slots * PRT_BLOCK)[slot * PRT_BLOCK + threadIdx.x] = i;
+    lds_dyn[(off + slot) * PRT_BLOCK + threadIdx.x] = v;
+    reinterpret_cast<int*>(lds_dyn + total * PRT_BLOCK)[(off + slot) * PRT_BLOCK + threadIdx.x] = i;
   }
 };
 
@@ -647,58 +648,87 @@ __device__ __forceinline__ void csg_step(const DevInstr* __restrict__ in, const 
   }
 }
 
-// Run the scene program for one ray: nearest positive hit over all components with the
-// strict '<' running minimum of _pyrayt.py:384-386.  `prims`/`code` are wave-uniform.
+// One program step for one ray (state: the two register pairs and the running nearest hit).
+__device__ __forceinline__ void run_step(const DevInstr* in, const Ray8& ray, const LaneLists& lists,
+                                         Pair& ra, Pair& rb, double& best_t, int& best_prim) {
+  const int kind = in->kind;
+  if (kind == I_LEAF) {
+    const int p = in->a0;
+    double t0, t1;
+#if defined(PRT_ABLATE) && (PRT_ABLATE & 4)
+    t0 = ray.ox + in->data[0]; t1 = ray.dx;  // timing experiment: no primitive math
+#else
+    surface_pair(in->type, in->data, in->data + 6, ray, t0, t1);
+#endif
+    const int dst = in->a1;
+    if (dst == OPER_REGA) {
+      ra.t0 = t0; ra.t1 = t1; ra.prim = p;
+    } else if (dst == OPER_REGB) {
+      rb.t0 = t0; rb.t1 = t1; rb.prim = p;
+    } else {
+      lists.put(in->a2, t0, p);
+      lists.put(in->a2 + 1, t1, p);
+    }
+  } else if (kind == I_CSG) {
+    bool is_root;
+    double t = PRT_INF;
+    int prim = -1;
+#if defined(PRT_ABLATE) && (PRT_ABLATE & 2)
+    is_root = in->pad[0] != 0; t = ra.t0 + rb.t0; prim = ra.prim;  // timing experiment: no CSG
+#else
+    csg_step(in, ray, lists, ra, rb, is_root, t, prim);
+#endif
+    if (is_root && t < best_t) {
+      best_t = t;
+      best_prim = prim;
+    }
+  } else {  // I_ROOT: a component that is a single surface (its pair sits in REGA)
+    const Operand o = {in->a0, in->a1, in->a2};
+    double t;
+    int prim;
+    first_positive(o, lists, ra, rb, t, prim);
+    if (t < best_t) {
+      best_t = t;
+      best_prim = prim;
+    }
+  }
+}
+
+// Run the scene program for R rays held by one lane: nearest positive hit over all components
+// with the strict '<' running minimum of _pyrayt.py:384-386.  `code` is wave-uniform; each
+// step record is fetched once (one batch of scalar loads) and applied to the lane's R rays,
+// whose arithmetic is independent and interleaves.
+template <int R>
+__device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code, int n_instr,
+                                              const Ray8 (&ray)[R], int slots, double (&best_t)[R],
+                                              int (&best_prim)[R]) {
+  Pair ra[R], rb[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    best_t[k] = PRT_INF;
+    best_prim[k] = -1;
+    ra[k] = Pair{PRT_INF, PRT_INF, -1};
+    rb[k] = Pair{PRT_INF, PRT_INF, -1};
+  }
+  for (int pc = 0; pc < n_instr; ++pc) {
+    const DevInstr step = code[pc];  // the whole record, one batch of scalar loads
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const LaneLists lists = {R * slots, k * slots};
+      run_step(&step, ray[k], lists, ra[k], rb[k], best_t[k], best_prim[k]);
+    }
+  }
+}
+
 __device__ __forceinline__ void nearest_hit(const DevPrim* __restrict__ prims,
                                             const DevInstr* __restrict__ code, int n_instr,
                                             const Ray8& ray, const LaneLists& lists, double& best_t,
                                             int& best_prim) {
-  best_t = PRT_INF;
-  best_prim = -1;
-  Pair ra = {PRT_INF, PRT_INF, -1}, rb = {PRT_INF, PRT_INF, -1};
-  for (int pc = 0; pc < n_instr; ++pc) {
-    const DevInstr step = code[pc];  // the whole record, one batch of scalar loads
-    const DevInstr* in = &step;
-    const int kind = in->kind;
-    if (kind == I_LEAF) {
-      const int p = in->a0;
-      double t0, t1;
-#if defined(PRT_ABLATE) && (PRT_ABLATE & 4)
-      t0 = ray.ox + in->data[0]; t1 = ray.dx;  // timing experiment: no primitive math
-#else
-      surface_pair(in->type, in->data, in->data + 6, ray, t0, t1);
-#endif
-      const int dst = in->a1;
-      if (dst == OPER_REGA) {
-        ra.t0 = t0; ra.t1 = t1; ra.prim = p;
-      } else if (dst == OPER_REGB) {
-        rb.t0 = t0; rb.t1 = t1; rb.prim = p;
-      } else {
-        lists.put(in->a2, t0, p);
-        lists.put(in->a2 + 1, t1, p);
-      }
-    } else if (kind == I_CSG) {
-      bool is_root;
-      double t = PRT_INF;
-      int prim = -1;
-#if defined(PRT_ABLATE) && (PRT_ABLATE & 2)
-      is_root = in->pad[0] != 0; t = ra.t0 + rb.t0; prim = ra.prim;  // timing experiment: no CSG
-#else
-      csg_step(in, ray, lists, ra, rb, is_root, t, prim);
-#endif
-      if (is_root && t < best_t) {
-        best_t = t;
-        best_prim = prim;
-      }
-    } else {  // I_ROOT: a component that is a single surface (its pair sits in REGA)
-      const Operand o = {in->a0, in->a1, in->a2};
-      double t;
-      int prim;
-      first_positive(o, lists, ra, rb, t, prim);
-      if (t < best_t) {
-        best_t = t;
-        best_prim = prim;
-      }
-    }
-  }
+  (void)prims;
+  const Ray8 rays1[1] = {ray};
+  double t1[1];
+  int p1[1];
+  nearest_hit_n<1>(code, n_instr, rays1, lists.total, t1, p1);
+  best_t = t1[0];
+  best_prim = p1[0];
 }

@@ -356,7 +356,7 @@ static int on_device(prt_scene* s, int device, DeviceCopy** out) {
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ LaneLists lane_lists(int slots) { return LaneLists{slots}; }
+__device__ __forceinline__ LaneLists lane_lists(int slots) { return LaneLists{slots, 0}; }
 
 __device__ __forceinline__ Ray8 load_ray8(const double* __restrict__ rays, int64_t ld, int64_t i) {
   Ray8 r;
@@ -752,12 +752,15 @@ __device__ long long g_stamps[16384 * 4 * 8];
 #define STAMP(k) do {} while (0)
 #endif
 
-// Register-allocated for 4 waves per SIMD (<= 128 VGPRs, no spills).  Measured on MI355X
-// (same box, interleaved runs): 3 and 4 waves/SIMD tie, 5 (96 VGPRs, 60 B/lane of scratch)
-// is 6 % slower, 6 (80 VGPRs) 30 % slower -- spills in the fp64 hot path cost more than the
-// extra occupancy buys.
+#define PARK(k) lds_dyn[(k) * PRT_BLOCK + threadIdx.x]
+
+// Register-allocated for 5 waves per SIMD (96 VGPRs, no spills -- possible because the record
+// columns known before the shading wait in LDS, see PARK).  Measured on MI355X, same box,
+// interleaved: occupancy matters (identical code held to 3 workgroups/CU by LDS padding is 30 %
+// slower than at 4), 5 waves beat 4 by 7 %, and 6 (80 VGPRs, 56 B/lane of scratch) lose 16 %:
+// spills in the fp64 hot path cost more than the extra wave buys.
 #ifndef PRT_GEN_WAVES
-#define PRT_GEN_WAVES 4
+#define PRT_GEN_WAVES 5
 #endif
 __global__ void __launch_bounds__(PRT_BLOCK, PRT_GEN_WAVES)
 k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double* __restrict__ next,
@@ -825,6 +828,9 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     tile_store(tiles_cur + tile, tile_pack(TILE_AGGREGATE, agg_live, agg_carry));
   // Shade BEFORE asking where the results go: the predecessors get this long to publish their
   // aggregates, so the look-back below mostly finds them ready instead of waiting.
+  // Record columns that are known before the shading (metadata, segment start) are parked in
+  // the lane's own LDS slots -- the hit lists are dead by now -- instead of being held in
+  // registers across the fp64-heavy shading.
   Shaded sh;
   sh.ok = true;
   if (live) meta = load_meta(rays, ld, i);  // (loading these up front measured no faster)
@@ -832,7 +838,12 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   if (meta.generation + meta.intensity + meta.wavelength + meta.index + meta.id == 1.2345e300) t = 0;
   STAMP(4);
 #endif
-  if (live) sh = interact_compute(scene, meta, r, t, prim);
+  if (live) {
+    PARK(0) = meta.generation; PARK(1) = meta.intensity; PARK(2) = meta.wavelength;
+    PARK(3) = meta.index; PARK(4) = meta.id;
+    PARK(5) = r.ox; PARK(6) = r.oy; PARK(7) = r.oz;
+    sh = interact_compute(scene, meta, r, t, prim);
+  }
   STAMP(5);
   if (wave == 0) {
     unsigned e_live, e_carry;
@@ -864,6 +875,10 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     return;
   }
   if (!live) return;
+  // un-park the early columns
+  sh.generation = PARK(0); sh.intensity = PARK(1); sh.wavelength = PARK(2);
+  sh.index_in = PARK(3); sh.id = PARK(4);
+  r.ox = PARK(5); r.oy = PARK(6); r.oz = PARK(7);
 #if defined(PRT_ABLATE) && (PRT_ABLATE & 32)
   {  // timing experiment: no stores, but every shaded value stays live
     const double sum = sh.generation + sh.intensity + sh.wavelength + sh.index_in + sh.id + sh.px +
@@ -883,6 +898,111 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
 #endif
   if (!sh.ok) atomicExch(&ctrl->error, PRT_ERR_UNTRACABLE);
   STAMP(7);
+}
+
+// Two rays per lane.  A wave's lifetime in k_generation is mostly latency that does not depend
+// on how much arithmetic it carries (step fetches, uniform branches, barriers, the look-back, the
+// load / store round trips) and the VALUs idle about half the time, so a lane that owns two
+// independent rays amortises all of that over twice the work: a tile is 512 rays (ray slot 0:
+// i = 512*tile + tid, slot 1: i + 256), every program step is fetched once and applied to both.
+#ifndef PRT_GEN2_WAVES
+#define PRT_GEN2_WAVES 3
+#endif
+__global__ void __launch_bounds__(PRT_BLOCK, PRT_GEN2_WAVES)
+k_generation2(SceneDev scene, const double* __restrict__ rays, int64_t ld, double* __restrict__ next,
+              int64_t ld_next, double* __restrict__ rows, int64_t ld_rows, FusedCtrl* __restrict__ ctrl,
+              GenCtrl* __restrict__ gen, int g, unsigned long long* __restrict__ tiles_cur,
+              unsigned long long* __restrict__ tiles_next, double next_generation, int relaunch,
+              double ray_offset, int keep_absorbed) {
+  constexpr int R = 2;
+  constexpr int TILE = R * PRT_BLOCK;
+  __shared__ int s_wave_live[R][4], s_wave_carry[R][4];
+  __shared__ unsigned s_excl[2];
+  const int tile = blockIdx.x;
+  const int64_t n = gen[g].n_in;
+  if ((int64_t)tile * TILE >= n) return;  // uniform per workgroup; never a predecessor
+  const bool failed = ctrl->error != 0;   // still publishes its (empty) aggregate below
+  const int64_t row_base = gen[g].row_base;
+  if (threadIdx.x == 0) tiles_next[tile] = TILE_INVALID;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t idx[R];
+  Ray8 r[R];
+  double t[R];
+  int prim[R];
+  bool live[R], carry[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    idx[k] = (int64_t)tile * TILE + k * PRT_BLOCK + threadIdx.x;
+    r[k] = Ray8{0, 0, 0, 1, 0, 0, 0, 0};
+    if (idx[k] < n && !failed) r[k] = load_ray8(rays, ld, idx[k]);
+  }
+  nearest_hit_n<R>(scene.code, scene.n_instr, r, scene.lds_slots, t, prim);
+  int live_rank[R], carry_rank[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const bool valid = idx[k] < n && !failed;
+    live[k] = valid && is_live(r[k], prim[k]);
+    carry[k] = live[k] && (keep_absorbed || scene.prims[prim[k]].mat_kind != MAT_ABSORBER);
+    const unsigned long long m_live = __ballot(live[k]), m_carry = __ballot(carry[k]);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    live_rank[k] = __popcll(m_live & below);
+    carry_rank[k] = __popcll(m_carry & below);
+    if (lane == 0) {
+      s_wave_live[k][wave] = __popcll(m_live);
+      s_wave_carry[k][wave] = __popcll(m_carry);
+    }
+  }
+  __syncthreads();
+  // order inside the tile: all of ray slot 0 (ids tile*512 ..+255), then slot 1
+  unsigned agg_live = 0, agg_carry = 0;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    live_rank[k] += agg_live;
+    carry_rank[k] += agg_carry;
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) { live_rank[k] += s_wave_live[k][w]; carry_rank[k] += s_wave_carry[k][w]; }
+      agg_live += s_wave_live[k][w];
+      agg_carry += s_wave_carry[k][w];
+    }
+  }
+  if (threadIdx.x == 0 && tile > 0)
+    tile_store(tiles_cur + tile, tile_pack(TILE_AGGREGATE, agg_live, agg_carry));
+  // shade both rays before asking where the results go
+  Shaded sh[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    sh[k].ok = true;
+    if (live[k]) sh[k] = interact_compute(scene, load_meta(rays, ld, idx[k]), r[k], t[k], prim[k]);
+  }
+  if (wave == 0) {
+    unsigned e_live, e_carry;
+    const bool ok = lookback(tiles_cur, tile, agg_live, agg_carry, e_live, e_carry);
+    if (!ok && lane == 0) atomicExch(&ctrl->error, PRT_ERR_STALL);
+    if (lane == 0) { s_excl[0] = e_live; s_excl[1] = e_carry; }
+  }
+  __syncthreads();
+  const int64_t excl_live = s_excl[0], excl_carry = s_excl[1];
+  const int64_t last_tile = (n - 1) / TILE;
+  if (tile == last_tile && threadIdx.x == 0) {
+    const int64_t total_live = excl_live + agg_live, total_carry = excl_carry + agg_carry;
+    gen[g].n_live = total_live;
+    gen[g].n_carry = total_carry;
+    gen[g + 1].n_in = (total_live == 0) ? 0 : total_carry;
+    gen[g + 1].row_base = row_base + total_live;
+  }
+  if (row_base + excl_live + agg_live > ctrl->rows_cap) {  // uniform per workgroup
+    if (threadIdx.x == 0) atomicExch(&ctrl->error, PRT_ERR_ROWS_CAP);
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    if (!live[k]) continue;
+    interact_store(sh[k], r[k], carry[k], row_base + excl_live + live_rank[k],
+                   excl_carry + carry_rank[k], next, ld_next, rows, ld_rows, next_generation,
+                   relaunch, ray_offset);
+    if (!sh[k].ok) atomicExch(&ctrl->error, PRT_ERR_UNTRACABLE);
+  }
 }
 
 // start of a fused trace: clear the control slots and tile buffer 0
@@ -1061,6 +1181,7 @@ k_source(DevSource src, int64_t n_total, int64_t first, int64_t count, int64_t i
 static int raise_lds_limits() {
   HIP_TRY(hipFuncSetAttribute((const void*)k_hit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_generation, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_generation2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_intersect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   return PRT_OK;
 }
@@ -1079,6 +1200,10 @@ extern "C" int prt_device_count(void) {
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + PRT_BLOCK - 1) / PRT_BLOCK); }
 static inline size_t lds_bytes(int slots) { return (size_t)slots * PRT_BLOCK * 12; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+// the fused kernel re-uses the hit-list area as a parking lot for 8 float64 per lane
+static inline size_t lds_bytes_fused(int slots) {
+  return std::max(lds_bytes(slots), (size_t)8 * PRT_BLOCK * sizeof(double));
+}
 
 static SceneDev trace_scene_dev(const prt_scene* s, const DeviceCopy* c) {
   return SceneDev{c->prims, c->trace_code, (int)s->trace_program.code.size(), s->trace_program.lds_slots};
@@ -1386,7 +1511,7 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
   double* buf[2] = {(double*)(w + l.rays_a), (double*)(w + l.rays_b)};
   const int keep_absorbed = (flags & PRT_TRACE_KEEP_ABSORBED) ? 1 : 0;
   SceneDev sd = trace_scene_dev(s, c);
-  const size_t lds = lds_bytes(sd.lds_slots);
+  const size_t lds = lds_bytes_fused(sd.lds_slots);
   const int n_slots = generation_limit + 1;
   // PRT_TEST_STALL=1 makes one tile report an expired look-back so that the tests can exercise
   // the fallback to the three-kernel path.
@@ -1395,6 +1520,10 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
   hipLaunchKernelGGL(k_fused_init, dim3(64), dim3(256), 0, st, ctrl, gen, n_slots, tiles[0],
                      (int64_t)blocks_for(n), n, rows_cap, test_stall);
 
+  size_t lds_pad = 0;  // experiment: PRT_LDS_PAD=<bytes> lowers occupancy without touching the code
+  if (const char* pad_env = getenv("PRT_LDS_PAD")) lds_pad = (size_t)atol(pad_env);
+  const char* rpl_env = getenv("PRT_RAYS_PER_LANE");
+  const bool two_per_lane = rpl_env && rpl_env[0] == '2' && 2 * lds <= kMaxLdsBytes;
   GenCtrl* host_gen = c->host_gen + 1;  // slot -1 receives the control header
   int64_t bound = n, total_rows = 0;
   int g = 0, error = 0;
@@ -1407,9 +1536,16 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
       const double* src = (gg == 0) ? rays : buf[(gg - 1) & 1];
       const int64_t src_ld = (gg == 0) ? ld : n;
       const int relaunch = (gg + 1 != generation_limit) ? 1 : 0;
-      hipLaunchKernelGGL(k_generation, dim3(blocks_for(bound)), dim3(PRT_BLOCK), lds, st, sd, src,
-                         src_ld, buf[gg & 1], n, rows_out, rows_cap, ctrl, gen, gg, tiles[gg & 1],
-                         tiles[(gg + 1) & 1], (double)(gg + 1), relaunch, ray_offset, keep_absorbed);
+      if (two_per_lane) {
+        const unsigned grid2 = (unsigned)((bound + 2 * PRT_BLOCK - 1) / (2 * PRT_BLOCK));
+        hipLaunchKernelGGL(k_generation2, dim3(grid2), dim3(PRT_BLOCK), 2 * lds, st, sd, src, src_ld,
+                           buf[gg & 1], n, rows_out, rows_cap, ctrl, gen, gg, tiles[gg & 1],
+                           tiles[(gg + 1) & 1], (double)(gg + 1), relaunch, ray_offset, keep_absorbed);
+      } else {
+        hipLaunchKernelGGL(k_generation, dim3(blocks_for(bound)), dim3(PRT_BLOCK), lds + lds_pad, st, sd, src,
+                           src_ld, buf[gg & 1], n, rows_out, rows_cap, ctrl, gen, gg, tiles[gg & 1],
+                           tiles[(gg + 1) & 1], (double)(gg + 1), relaunch, ray_offset, keep_absorbed);
+      }
     }
     HIP_TRY(hipEventRecord(c->ev1, st));
     if (g == 0) {  // header + slots 0..batch are contiguous: one copy
