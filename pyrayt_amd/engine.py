@@ -93,13 +93,20 @@ def _check(code):
     return code
 
 
+_torch_ok = None
+
+
 def _torch():
+    global _torch_ok
+    if _torch_ok is not None:
+        return _torch_ok
     import torch
 
     if not torch.cuda.is_available():
         raise EngineUnavailable(
             "no HIP device visible: pyrayt_amd traces on an AMD GPU only (no CPU fallback)"
         )
+    _torch_ok = torch
     return torch
 
 
@@ -186,8 +193,11 @@ class DeviceScene:
 
     def _workspace(self, torch, n, dev):
         """Scratch for prt_trace (ping-pong ray sets, control words); kept between calls."""
-        need = int(library().prt_trace_workspace_bytes(n))
         cached = getattr(self, "_work", None)
+        if cached is not None and cached.device == dev and getattr(self, "_work_n", -1) >= n:
+            return cached
+        need = int(library().prt_trace_workspace_bytes(n))
+        self._work_n = n
         if cached is None or cached.device != dev or cached.numel() < need:
             self._work = cached = torch.empty(need, dtype=torch.uint8, device=dev)
         return cached
