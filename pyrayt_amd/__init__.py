@@ -14,6 +14,7 @@ from . import components
 from .rayset import RaySet
 from .tracer import RayTracer
 from .frame import DeviceFrame
+from .g3d.objects import pin
 
-__all__ = ["RayTracer", "RaySet", "DeviceFrame", "materials", "components", "g3d"]
+__all__ = ["RayTracer", "RaySet", "DeviceFrame", "pin", "materials", "components", "g3d"]
 __version__ = "0.1.0"

@@ -13,6 +13,7 @@ from .objects import (
     Cuboid,
     Cylinder,
     Intersectable,
+    ObjectGroup,
     Paraboloid,
     Sphere,
     TracerSurface,
@@ -22,7 +23,7 @@ from .objects import (
 from . import csg
 
 __all__ = [
-    "BLACK", "CountedObject", "Cuboid", "Cylinder", "Intersectable", "Paraboloid", "Point",
+    "BLACK", "CountedObject", "Cuboid", "Cylinder", "Intersectable", "ObjectGroup", "Paraboloid", "Point",
     "Sphere", "TracerSurface", "Vector", "WorldObject", "XYPlane", "bundle_of_rays", "csg",
     "objects", "shapes",
 ]

@@ -143,6 +143,53 @@ class WorldObject(CountedObject):
         return self._rotation(angle, units, 0, 1)
 
 
+class ObjectGroup(WorldObject):
+    """A list of world objects that move together: a transform applied to the group is applied
+    to every member, groups nest (``world_objects.py:283-295``).  Host-side scene editing only."""
+
+    def __init__(self, members=()):
+        super().__init__()
+        self.data = list(members)
+
+    def append(self, item):
+        self.data.append(item)
+
+    def extend(self, items):
+        self.data.extend(items)
+
+    def __len__(self):
+        return len(self.data)
+
+    def __iter__(self):
+        return iter(self.data)
+
+    def __getitem__(self, index):
+        return self.data[index]
+
+    def _append_world_transform(self, matrix):
+        super()._append_world_transform(matrix)
+        for member in self.data:
+            member.transform(matrix)
+
+
+class pin:
+    """Context manager: whatever is done to the pinned objects' transforms inside the ``with``
+    block is undone on exit (``pyrayt/_pyrayt.py:539-575``).  Lets a design loop move parts,
+    trace, and come back to the starting layout."""
+
+    def __init__(self, *objects_to_pin):
+        self._objects = objects_to_pin
+
+    def __enter__(self):
+        self._start = [obj.get_world_transform() for obj in self._objects]
+        return self._objects
+
+    def __exit__(self, exception_type, exception_value, traceback):
+        for obj, start in zip(self._objects, self._start):
+            change = np.matmul(obj.get_world_transform(), np.linalg.inv(start))
+            obj.transform(np.linalg.inv(change))
+
+
 class Intersectable(WorldObject):
     """Anything a RayTracer can hold as a component (``world_objects.py:298-335``)."""
 
