@@ -655,6 +655,26 @@ __device__ __forceinline__ void run_step(const DevInstr* in, const Ray8& ray, co
   if (kind == I_LEAF) {
     const int p = in->a0;
     double t0, t1;
+#ifndef PRT_NO_LEAF_SKIP
+    if (in->pad[0] == 1) {
+      // right leaf of an INTERSECT / DIFFERENCE node: not worth evaluating for this wave when no
+      // lane's left operand (a3 mode, a4 base, a5 length) holds a positive entry
+      bool has_positive;
+      if (in->a3 == OPER_LDS) {
+        has_positive = false;
+        for (int k = 0; k < in->a5; ++k) {
+          const double v = lists.get_t(in->a4 + k);
+          has_positive = has_positive || (v > 0 && v < PRT_INF);
+        }
+      } else {
+        has_positive = (ra.t0 > 0 && ra.t0 < PRT_INF) || (ra.t1 > 0 && ra.t1 < PRT_INF);
+      }
+      if (__ballot(has_positive) == 0ull) {
+        rb.t0 = PRT_INF; rb.t1 = PRT_INF; rb.prim = p;
+        return;
+      }
+    }
+#endif
 #if defined(PRT_ABLATE) && (PRT_ABLATE & 4)
     t0 = ray.ox + in->data[0]; t1 = ray.dx;  // timing experiment: no primitive math
 #else

@@ -102,6 +102,7 @@ struct Compiler {
   const prt_scene* s;
   std::vector<DevInstr>& out;
   int lowest = 0;
+  bool positive_only = false;  // trace programs: only positive hits are ever looked at
 
   static DevInstr blank(int kind) {
     DevInstr in;
@@ -162,6 +163,16 @@ struct Compiler {
       R = emit(n.right, L.base - m_r);
       base = L.base - m_r;
     }
+    // INTERSECT / DIFFERENCE results lie inside the left solid: when the left list has no positive
+    // entry the node cannot contribute a positive hit whatever the right operand is (entries that
+    // are not positive come in enter/exit pairs and leave the depth seen by positive entries
+    // unchanged), so a right leaf evaluated just before the node is marked skippable.
+    if (positive_only && r_leaf && !out.empty() && out.back().kind == I_LEAF && out.back().a1 == OPER_REGB &&
+        (n.op == PRT_NODE_INTERSECT || n.op == PRT_NODE_DIFFERENCE)) {
+      DevInstr& rl = out.back();
+      rl.pad[0] = 1;
+      rl.a3 = L.mode; rl.a4 = L.base; rl.a5 = L.len;
+    }
     DevInstr in = blank(I_CSG);
     in.pad[1] = box_contains_solid(node) ? 1 : 0;
     in.a0 = n.op;
@@ -179,6 +190,7 @@ static void shift_slots(std::vector<DevInstr>& code, size_t from, int shift) {
   for (size_t k = from; k < code.size(); ++k) {
     DevInstr& in = code[k];
     if (in.kind == I_LEAF && in.a1 == OPER_LDS) in.a2 += shift;
+    if (in.kind == I_LEAF && in.pad[0] == 1 && in.a3 == OPER_LDS) in.a4 += shift;
     if (in.kind == I_CSG) {
       if (in.a1 == OPER_LDS) in.a2 += shift;
       if (in.a4 == OPER_LDS) in.a5 += shift;
@@ -193,6 +205,7 @@ static Operand compile_component(const prt_scene* s, int root_node, std::vector<
                                  bool with_root, int* slots) {
   const size_t from = code.size();
   Compiler c{s, code};
+  c.positive_only = with_root;
   Operand res;
   if (s->nodes[root_node].op == PRT_NODE_LEAF)
     res = c.leaf(root_node, OPER_REGA, 0);
