@@ -219,6 +219,65 @@ int64_t prt_trace(prt_scene* scene, int device, const double* rays, int64_t n, i
  * out[5] = sum of rays handed to the next generation, out[6..7] reserved. */
 int prt_trace_stats(const prt_scene* scene, double* out8);
 
+/* ---- renderers (second consumer of the intersect path) ----------
+ * tinygfx/g3d/renderers.py: an OrthographicCamera grid (world_objects.py:499-537) is pushed
+ * through the components, then Gooch-shaded (ShadedRenderer :129-248) or edge-detected
+ * (EdgeRender :11-126).  Pixels are numbered row-major over the v_pixels x h_pixels picture;
+ * images are (v, h, 4) float64 RGBA, the layout both renderers return. */
+typedef struct prt_camera {
+  double world[16];  /* row-major camera -> world transform (world_objects.py:97-99) */
+  int64_t h_pixels, v_pixels;
+  double h_width, v_width; /* camera-space span of the grid along y (h) and z (v) */
+} prt_camera;
+
+/* OrthographicCamera.generate_rays (world_objects.py:519-537): rays of pixels
+ * [first, first+count) into columns [0, count) of the device (8, ld) block rays_out
+ * (rows 0-3 origin, 4-7 unit direction). */
+int prt_camera_rays(int device, const prt_camera* camera, int64_t first, int64_t count,
+                    double* rays_out, int64_t ld, void* stream);
+
+/* EdgeRender._st_propagate / ShadedRenderer._st_propagate (renderers.py:70-92, 187-209).
+ * Differs from prt_propagate in one rule: a component without a positive hit offers its
+ * smallest parameter (gather from the unmasked list at the argmin of the masked one,
+ * :79-83), so t_out may be negative.  rays (>= 8, n) ld; t_out (n); surf_out (n), -1 = none. */
+int prt_render_hits(prt_scene* scene, int device, const double* rays, int64_t n, int64_t ld,
+                    double* t_out, int64_t* surf_out, void* stream);
+
+/* ShadedRenderer._st_interact (renderers.py:211-236) = TracerSurface.shade
+ * (world_objects.py:385-399) + GoochMaterial.shade (materials/gooch.py:30-65) with one light:
+ *   gooch: device (n_prims, 8) = shade_warm[4] | shade_cool[4] per primitive (gooch.py:36-37)
+ *   light: HOST double[3], world position of the light
+ *   rgba_out: device (n, 4); pixels with surf == -1 get (0,0,0,0).
+ * Upstream's multi-light branch (gooch.py:48-51) does not broadcast for any light count
+ * but 3, where it mixes up coordinates and lights; it is not offered. */
+int prt_gooch_shade(prt_scene* scene, int device, const double* rays, int64_t n, int64_t ld,
+                    const double* t, const int64_t* surf, const double* gooch,
+                    const double* light, double* rgba_out, void* stream);
+
+/* GoochMaterial.shade(rays, normals, light_positions) (materials/gooch.py:30-65) on caller
+ * supplied points and normals, one light:  points, normals: device (>= 3, n) ld;
+ * shade: HOST double[8] = shade_warm | shade_cool; light: HOST double[3];
+ * rgba_out: device (4, n) ld_out -- the (4, n) layout the method returns. */
+int prt_gooch_mix(int device, const double* points, const double* normals, int64_t n, int64_t ld,
+                  const double* shade, const double* light, double* rgba_out, int64_t ld_out,
+                  void* stream);
+
+/* ShadedRenderer.render() / the propagate half of EdgeRender.render() for pixels
+ * [first, first+count) in one kernel: camera ray -> nearest hit -> Gooch colour, nothing read
+ * from HBM but the scene.  Any of rgba_out (count,4) / t_out (count) / surf_out (count) may
+ * be NULL; gooch and light are needed only with rgba_out. */
+int prt_render(prt_scene* scene, int device, const prt_camera* camera, int64_t first,
+               int64_t count, const double* gooch, const double* light, double* rgba_out,
+               double* t_out, int64_t* surf_out, void* stream);
+
+/* EdgeRender._st_interact (renderers.py:94-116): edge = surface id differs from the left or
+ * upper neighbour (outside = -1), grown by `rings` 3x3 binary dilations (upstream:
+ * max(1, int(max(v, h) / 300))); rgba_out (v, h, 4): edges (0,0,0,1), the rest (1,1,1,0).
+ * workspace: device scratch of prt_edge_workspace_bytes(h, v) bytes. */
+int64_t prt_edge_workspace_bytes(int64_t h_pixels, int64_t v_pixels);
+int prt_edge_canvas(int device, const int64_t* surf, int64_t h_pixels, int64_t v_pixels,
+                    int rings, double* rgba_out, void* workspace, void* stream);
+
 /* error codes */
 #define PRT_OK 0
 #define PRT_ERR_ARG (-1)

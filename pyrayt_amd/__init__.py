@@ -11,10 +11,11 @@ HIP library or without a GPU raises.
 from . import g3d
 from . import materials
 from . import components
+from . import utils
 from .rayset import RaySet
 from .tracer import RayTracer
 from .frame import DeviceFrame
 from .g3d.objects import pin
 
-__all__ = ["RayTracer", "RaySet", "DeviceFrame", "pin", "materials", "components", "g3d"]
+__all__ = ["RayTracer", "RaySet", "DeviceFrame", "pin", "materials", "components", "g3d", "utils"]
 __version__ = "0.1.0"

@@ -53,7 +53,7 @@ struct DevInstr {
   int32_t a5;     //                   CSG: right base
   int32_t a6;     //                   CSG: right length
   int32_t a7;     //                   CSG: out base
-  int32_t pad[2]; // CSG: [0] root node of a component, [1] cull box implied (see csg_node)
+  int32_t pad[2]; // CSG: [0] root node of a component, [1] cull box implied (see csg_node); ROOT: [0] == 2 renderer rule
   int32_t type;   // LEAF: PRIM_*
   double data[18];// LEAF: params[0..5], M^-1 rows 0..2 [6..17]   CSG: cull box [0..5]
 };
@@ -476,6 +476,24 @@ __device__ __forceinline__ void first_positive(const Operand& o, const LaneLists
   }
 }
 
+// The renderers pick differently (renderers.py:79-86, 196-203): argmin over the list masked to
+// its positive entries, but the value gathered from the *unmasked* list -- so a list without a
+// positive entry offers its first (smallest, negative) entry, and the strict '<' running minimum
+// then prefers it.  draw(view="xz") looks away from the parts and sees them only this way.
+__device__ __forceinline__ void first_positive_else_first(const Operand& o, const LaneLists& lists,
+                                                          const Pair& ra, const Pair& rb, double& t,
+                                                          int& prim) {
+  t = operand_t(o, lists, ra, rb, 0);
+  prim = (t < PRT_INF) ? operand_id(o, lists, ra, rb, 0) : -1;
+  for (int k = o.len - 1; k >= 0; --k) {
+    const double v = operand_t(o, lists, ra, rb, k);
+    if (v > 0 && v < PRT_INF) {
+      t = v;
+      prim = operand_id(o, lists, ra, rb, k);
+    }
+  }
+}
+
 // The same node, branch-free, for the list shapes the part factories produce (a register
 // pair against a register pair or against a short LDS list).  Instead of walking the merged
 // order it computes, for every entry independently, what the walk would have seen:
@@ -649,6 +667,8 @@ __device__ __forceinline__ void csg_step(const DevInstr* __restrict__ in, const 
 }
 
 // One program step for one ray (state: the two register pairs and the running nearest hit).
+// RENDER selects the renderers' root rule at compile time, so the tracer's kernels carry none of it.
+template <bool RENDER = false>
 __device__ __forceinline__ void run_step(const DevInstr* in, const Ray8& ray, const LaneLists& lists,
                                          Pair& ra, Pair& rb, double& best_t, int& best_prim) {
   const int kind = in->kind;
@@ -706,7 +726,10 @@ __device__ __forceinline__ void run_step(const DevInstr* in, const Ray8& ray, co
     const Operand o = {in->a0, in->a1, in->a2};
     double t;
     int prim;
-    first_positive(o, lists, ra, rb, t, prim);
+    if (RENDER)
+      first_positive_else_first(o, lists, ra, rb, t, prim);
+    else
+      first_positive(o, lists, ra, rb, t, prim);
     if (t < best_t) {
       best_t = t;
       best_prim = prim;
@@ -718,7 +741,7 @@ __device__ __forceinline__ void run_step(const DevInstr* in, const Ray8& ray, co
 // with the strict '<' running minimum of _pyrayt.py:384-386.  `code` is wave-uniform; each
 // step record is fetched once (one batch of scalar loads) and applied to the lane's R rays,
 // whose arithmetic is independent and interleaves.
-template <int R>
+template <int R, bool RENDER = false>
 __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code, int n_instr,
                                               const Ray8 (&ray)[R], int slots, double (&best_t)[R],
                                               int (&best_prim)[R]) {
@@ -735,11 +758,12 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       const LaneLists lists = {R * slots, k * slots};
-      run_step(&step, ray[k], lists, ra[k], rb[k], best_t[k], best_prim[k]);
+      run_step<RENDER>(&step, ray[k], lists, ra[k], rb[k], best_t[k], best_prim[k]);
     }
   }
 }
 
+template <bool RENDER = false>
 __device__ __forceinline__ void nearest_hit(const DevPrim* __restrict__ prims,
                                             const DevInstr* __restrict__ code, int n_instr,
                                             const Ray8& ray, const LaneLists& lists, double& best_t,
@@ -748,7 +772,7 @@ __device__ __forceinline__ void nearest_hit(const DevPrim* __restrict__ prims,
   const Ray8 rays1[1] = {ray};
   double t1[1];
   int p1[1];
-  nearest_hit_n<1>(code, n_instr, rays1, lists.total, t1, p1);
+  nearest_hit_n<1, RENDER>(code, n_instr, rays1, lists.total, t1, p1);
   best_t = t1[0];
   best_prim = p1[0];
 }

@@ -63,6 +63,7 @@ struct Program {
 struct DeviceCopy {
   DevPrim* prims = nullptr;
   DevInstr* trace_code = nullptr;               // all components, each ending in I_ROOT
+  DevInstr* render_code = nullptr;              // same with the renderers' selection rule
   std::vector<DevInstr*> component_code;        // one program per component, no I_ROOT
   int64_t* host_pinned = nullptr;               // 8 x int64 pinned staging
   struct GenCtrl* host_gen = nullptr;           // pinned read-back of one batch of slots
@@ -76,6 +77,7 @@ struct prt_scene {
   std::vector<prt_material> mats;
   std::vector<DevPrim> dev_prims;
   Program trace_program;
+  Program render_program;
   std::vector<Program> component_programs;
   std::vector<Operand> component_result;        // where each component program leaves its list
   std::vector<DeviceCopy> per_device;
@@ -201,24 +203,25 @@ static void shift_slots(std::vector<DevInstr>& code, size_t from, int shift) {
 }
 
 // compile component `root_node`; returns where its result list ends up
+enum { ROOT_NONE = 0, ROOT_TRACE = 1, ROOT_RENDER = 2 };
 static Operand compile_component(const prt_scene* s, int root_node, std::vector<DevInstr>& code,
-                                 bool with_root, int* slots) {
+                                 int root_rule, int* slots) {
   const size_t from = code.size();
   Compiler c{s, code};
-  c.positive_only = with_root;
+  c.positive_only = root_rule == ROOT_TRACE;
   Operand res;
   if (s->nodes[root_node].op == PRT_NODE_LEAF)
     res = c.leaf(root_node, OPER_REGA, 0);
   else
     res = c.emit(root_node, 0);
-  if (with_root) {
-    if (!code.empty() && code.size() > from && code.back().kind == I_CSG) {
-      code.back().pad[0] = 1;  // the node reduces straight to its nearest positive survivor
-    } else {
-      DevInstr in = Compiler::blank(I_ROOT);
-      in.a0 = res.mode; in.a1 = res.base; in.a2 = res.len;
-      code.push_back(in);
-    }
+  if (root_rule == ROOT_TRACE && code.size() > from && code.back().kind == I_CSG) {
+    code.back().pad[0] = 1;  // the node reduces straight to its nearest positive survivor
+  } else if (root_rule != ROOT_NONE) {
+    // the renderers may pick a non-positive entry, so their lists are always materialised
+    DevInstr in = Compiler::blank(I_ROOT);
+    in.a0 = res.mode; in.a1 = res.base; in.a2 = res.len;
+    in.pad[0] = root_rule == ROOT_RENDER ? 2 : 0;
+    code.push_back(in);
   }
   const int shift = -c.lowest;
   shift_slots(code, from, shift);
@@ -287,13 +290,14 @@ extern "C" int prt_scene_create(const prt_prim* prims, int n_prims, const prt_no
     s->dev_prims.push_back(d);
   }
   for (int r : s->roots) {
-    compile_component(s, r, s->trace_program.code, true, &s->trace_program.lds_slots);
+    compile_component(s, r, s->trace_program.code, ROOT_TRACE, &s->trace_program.lds_slots);
+    compile_component(s, r, s->render_program.code, ROOT_RENDER, &s->render_program.lds_slots);
     Program p;
-    Operand res = compile_component(s, r, p.code, false, &p.lds_slots);
+    Operand res = compile_component(s, r, p.code, ROOT_NONE, &p.lds_slots);
     s->component_programs.push_back(p);
     s->component_result.push_back(res);
   }
-  const size_t lds = (size_t)s->trace_program.lds_slots * PRT_BLOCK * 12;
+  const size_t lds = (size_t)std::max(s->trace_program.lds_slots, s->render_program.lds_slots) * PRT_BLOCK * 12;
   if (lds > kMaxLdsBytes) {
     delete s;
     return fail(PRT_ERR_SCENE, "a component has too many surfaces for the per-lane LDS hit lists");
@@ -310,6 +314,7 @@ extern "C" void prt_scene_destroy(prt_scene* s) {
     (void)hipSetDevice((int)d);
     (void)hipFree(c.prims);
     (void)hipFree(c.trace_code);
+    (void)hipFree(c.render_code);
     for (DevInstr* p : c.component_code) (void)hipFree(p);
     if (c.host_pinned) (void)hipHostFree(c.host_pinned);
     if (c.host_gen) (void)hipHostFree(c.host_gen);
@@ -348,6 +353,8 @@ static int on_device(prt_scene* s, int device, DeviceCopy** out) {
     int rc = upload(&c.prims, s->dev_prims);
     if (rc) return rc;
     rc = upload(&c.trace_code, s->trace_program.code);
+    if (rc) return rc;
+    rc = upload(&c.render_code, s->render_program.code);
     if (rc) return rc;
     for (const Program& p : s->component_programs) {
       DevInstr* code = nullptr;
@@ -1190,8 +1197,12 @@ k_source(DevSource src, int64_t n_total, int64_t first, int64_t count, int64_t i
   rays[12 * ld + c] = (double)(id_first + k);
 }
 
+#include "prt_render.hpp"
+
 // deep CSG trees may need more than the default 64 KiB of dynamic LDS per workgroup
 static int raise_lds_limits() {
+  HIP_TRY(hipFuncSetAttribute((const void*)k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_render_hits, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_hit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_generation, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_generation2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
@@ -1630,5 +1641,137 @@ extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64
 extern "C" int prt_trace_stats(const prt_scene* s, double* out8) {
   if (!s || !out8) return fail(PRT_ERR_ARG, "null argument");
   for (int k = 0; k < 8; ++k) out8[k] = s->stats[k];
+  return PRT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// renderers
+// ------------------------------------------------------------------------------------------------
+static int camera_of(const prt_camera* cam, DevCamera* out) {
+  if (!cam) return fail(PRT_ERR_ARG, "camera is null");
+  if (cam->h_pixels < 0 || cam->v_pixels < 0) return fail(PRT_ERR_ARG, "negative camera resolution");
+  std::memcpy(out->world, cam->world, sizeof(out->world));
+  out->h_pixels = cam->h_pixels; out->v_pixels = cam->v_pixels;
+  out->h_width = cam->h_width; out->v_width = cam->v_width;
+  return PRT_OK;
+}
+
+extern "C" int prt_camera_rays(int device, const prt_camera* camera, int64_t first, int64_t count,
+                               double* rays_out, int64_t ld, void* stream) {
+  int devices = 0;
+  HIP_TRY(hipGetDeviceCount(&devices));
+  if (device < 0 || device >= devices) return fail(PRT_ERR_ARG, "device index out of range");
+  DevCamera cam;
+  int rc = camera_of(camera, &cam);
+  if (rc) return rc;
+  if (first < 0 || count < 0 || first + count > cam.h_pixels * cam.v_pixels || ld < count ||
+      (count && !rays_out))
+    return fail(PRT_ERR_ARG, "bad pixel range / output buffer");
+  if (count == 0) return PRT_OK;
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(k_camera, dim3(blocks_for(count)), dim3(PRT_BLOCK), 0, (hipStream_t)stream, cam,
+                     first, count, rays_out, ld);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}
+
+static SceneDev render_scene_dev(const prt_scene* s, const DeviceCopy* c) {
+  return SceneDev{c->prims, c->render_code, (int)s->render_program.code.size(), s->render_program.lds_slots};
+}
+
+extern "C" int prt_render_hits(prt_scene* s, int device, const double* rays, int64_t n, int64_t ld,
+                               double* t_out, int64_t* surf_out, void* stream) {
+  DeviceCopy* c;
+  int rc = on_device(s, device, &c);
+  if (rc) return rc;
+  if (n < 0 || ld < n || (n && (!rays || !t_out || !surf_out)))
+    return fail(PRT_ERR_ARG, "bad ray / output buffers");
+  if (n == 0) return PRT_OK;
+  SceneDev sd = render_scene_dev(s, c);
+  hipLaunchKernelGGL(k_render_hits, dim3(blocks_for(n)), dim3(PRT_BLOCK), lds_bytes(sd.lds_slots),
+                     (hipStream_t)stream, sd, rays, ld, n, t_out, surf_out);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}
+
+extern "C" int prt_gooch_shade(prt_scene* s, int device, const double* rays, int64_t n, int64_t ld,
+                               const double* t, const int64_t* surf, const double* gooch,
+                               const double* light, double* rgba_out, void* stream) {
+  DeviceCopy* c;
+  int rc = on_device(s, device, &c);
+  if (rc) return rc;
+  if (n < 0 || ld < n || !light || (n && (!rays || !t || !surf || !gooch || !rgba_out)))
+    return fail(PRT_ERR_ARG, "bad buffers");
+  if (n == 0) return PRT_OK;
+  hipLaunchKernelGGL(k_gooch, dim3(blocks_for(n)), dim3(PRT_BLOCK), 0, (hipStream_t)stream, c->prims,
+                     (int)s->prims.size(), rays, ld, n, t, surf, gooch, light[0], light[1], light[2],
+                     rgba_out);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}
+
+extern "C" int prt_gooch_mix(int device, const double* points, const double* normals, int64_t n,
+                             int64_t ld, const double* shade, const double* light, double* rgba_out,
+                             int64_t ld_out, void* stream) {
+  int devices = 0;
+  HIP_TRY(hipGetDeviceCount(&devices));
+  if (device < 0 || device >= devices) return fail(PRT_ERR_ARG, "device index out of range");
+  if (n < 0 || ld < n || ld_out < n || !shade || !light || (n && (!points || !normals || !rgba_out)))
+    return fail(PRT_ERR_ARG, "bad buffers");
+  if (n == 0) return PRT_OK;
+  HIP_TRY(hipSetDevice(device));
+  GoochShade g;
+  std::memcpy(g.warm, shade, sizeof(g.warm));
+  std::memcpy(g.cool, shade + 4, sizeof(g.cool));
+  hipLaunchKernelGGL(k_gooch_mix, dim3(blocks_for(n)), dim3(PRT_BLOCK), 0, (hipStream_t)stream, points,
+                     normals, ld, n, g, light[0], light[1], light[2], rgba_out, ld_out);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}
+
+extern "C" int prt_render(prt_scene* s, int device, const prt_camera* camera, int64_t first,
+                          int64_t count, const double* gooch, const double* light, double* rgba_out,
+                          double* t_out, int64_t* surf_out, void* stream) {
+  DeviceCopy* c;
+  int rc = on_device(s, device, &c);
+  if (rc) return rc;
+  DevCamera cam;
+  rc = camera_of(camera, &cam);
+  if (rc) return rc;
+  if (first < 0 || count < 0 || first + count > cam.h_pixels * cam.v_pixels)
+    return fail(PRT_ERR_ARG, "bad pixel range");
+  if (rgba_out && (!gooch || !light)) return fail(PRT_ERR_ARG, "shading needs the gooch table and a light");
+  if (!rgba_out && !t_out && !surf_out) return fail(PRT_ERR_ARG, "no output requested");
+  if (count == 0) return PRT_OK;
+  SceneDev sd = render_scene_dev(s, c);
+  const double lx = light ? light[0] : 0.0, ly = light ? light[1] : 0.0, lz = light ? light[2] : 0.0;
+  hipLaunchKernelGGL(k_render, dim3(blocks_for(count)), dim3(PRT_BLOCK), lds_bytes(sd.lds_slots),
+                     (hipStream_t)stream, sd, cam, first, count, gooch, lx, ly, lz, rgba_out, t_out,
+                     surf_out);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}
+
+extern "C" int64_t prt_edge_workspace_bytes(int64_t h_pixels, int64_t v_pixels) {
+  if (h_pixels < 0 || v_pixels < 0) return PRT_ERR_ARG;
+  return (int64_t)align_up((size_t)(h_pixels * v_pixels) + 1, 256);
+}
+
+extern "C" int prt_edge_canvas(int device, const int64_t* surf, int64_t h_pixels, int64_t v_pixels,
+                               int rings, double* rgba_out, void* workspace, void* stream) {
+  int devices = 0;
+  HIP_TRY(hipGetDeviceCount(&devices));
+  if (device < 0 || device >= devices) return fail(PRT_ERR_ARG, "device index out of range");
+  if (h_pixels < 0 || v_pixels < 0 || rings < 0) return fail(PRT_ERR_ARG, "bad picture size");
+  const int64_t n = h_pixels * v_pixels;
+  if (n == 0) return PRT_OK;
+  if (!surf || !rgba_out || !workspace) return fail(PRT_ERR_ARG, "null buffer");
+  HIP_TRY(hipSetDevice(device));
+  unsigned char* seed = (unsigned char*)workspace;
+  hipLaunchKernelGGL(k_edge_seed, dim3(blocks_for(n)), dim3(PRT_BLOCK), 0, (hipStream_t)stream, surf,
+                     h_pixels, v_pixels, seed);
+  hipLaunchKernelGGL(k_edge_canvas, dim3(blocks_for(n)), dim3(PRT_BLOCK), 0, (hipStream_t)stream,
+                     (const unsigned char*)seed, h_pixels, v_pixels, rings, rgba_out);
+  HIP_TRY(hipGetLastError());
   return PRT_OK;
 }

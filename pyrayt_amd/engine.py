@@ -52,6 +52,13 @@ def _declare(lib):
                               c_int, c_p]),
         "prt_trace_stats": (c_int, [c_p, c_p]),
         "prt_generate_rays": (c_int, [c_int, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p]),
+        "prt_camera_rays": (c_int, [c_int, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
+        "prt_render_hits": (c_int, [c_p, c_int, c_p, c_i64, c_i64, c_p, c_p, c_p]),
+        "prt_gooch_shade": (c_int, [c_p, c_int, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
+        "prt_gooch_mix": (c_int, [c_int, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_p]),
+        "prt_render": (c_int, [c_p, c_int, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
+        "prt_edge_workspace_bytes": (c_i64, [c_i64, c_i64]),
+        "prt_edge_canvas": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = the library does not match prt.h
@@ -65,6 +72,8 @@ EXPORTED_SYMBOLS = (
     "prt_scene_component_rows", "prt_intersect", "prt_propagate", "prt_world_normals",
     "prt_material_trace", "prt_interact_workspace_bytes", "prt_interact",
     "prt_trace_workspace_bytes", "prt_trace", "prt_trace_stats", "prt_generate_rays",
+    "prt_camera_rays", "prt_render_hits", "prt_gooch_shade", "prt_gooch_mix", "prt_render",
+    "prt_edge_workspace_bytes", "prt_edge_canvas",
 )
 
 
@@ -273,6 +282,155 @@ class DeviceScene:
                                                 rays.data_ptr(), k, rays.stride(0),
                                                 _stream_ptr(torch, rays.device)))
         return rays
+
+
+    # --- renderers (include/prt.h: prt_render_hits / prt_gooch_shade / prt_render) ---------------
+    def gooch_table(self, device):
+        torch = _torch()
+        return torch.from_numpy(self.snapshot.gooch_table()).to(device)
+
+    def render_hits(self, rays8):
+        """Nearest hit per ray under the renderers' rule: (t (n) float64, surface (n) int64)."""
+        torch = _torch()
+        n = rays8.shape[1]
+        t = torch.empty(n, dtype=torch.float64, device=rays8.device)
+        surf = torch.empty(n, dtype=torch.int64, device=rays8.device)
+        if n:
+            _check(library().prt_render_hits(self.handle, rays8.device.index or 0, rays8.data_ptr(), n,
+                                             rays8.stride(0), t.data_ptr(), surf.data_ptr(),
+                                             _stream_ptr(torch, rays8.device)))
+        return t, surf
+
+    def gooch_shade(self, rays8, t, surf, light, gooch=None):
+        """(n,4) RGBA of the pixels whose rays hit ``surf`` at ``t``."""
+        torch = _torch()
+        n = rays8.shape[1]
+        gooch = self.gooch_table(rays8.device) if gooch is None else gooch
+        out = torch.empty((n, 4), dtype=torch.float64, device=rays8.device)
+        spot = _light(light)
+        if n:
+            _check(library().prt_gooch_shade(self.handle, rays8.device.index or 0, rays8.data_ptr(), n,
+                                             rays8.stride(0), t.data_ptr(), surf.data_ptr(),
+                                             gooch.data_ptr(), spot.ctypes.data, out.data_ptr(),
+                                             _stream_ptr(torch, rays8.device)))
+        return out
+
+    def render(self, camera, device, light=None, keep_hits=False):
+        """One fused pass over the camera grid.  Returns (rgba (v,h,4) or None, t, surf); ``rgba``
+        is produced when ``light`` is given, ``t`` / ``surf`` (flat, n) when ``keep_hits``."""
+        torch = _torch()
+        rec = camera_record(camera)
+        h, v = int(rec["h_pixels"][0]), int(rec["v_pixels"][0])
+        n = h * v
+        rgba = gooch = t = surf = spot = None
+        if light is not None:
+            spot = _light(light)
+            gooch = self.gooch_table(device)
+            rgba = torch.empty((v, h, 4), dtype=torch.float64, device=device)
+        if keep_hits or light is None:
+            t = torch.empty(n, dtype=torch.float64, device=device)
+            surf = torch.empty(n, dtype=torch.int64, device=device)
+        ptr = lambda x: x.data_ptr() if x is not None else None  # noqa: E731
+        if n:
+            _check(library().prt_render(self.handle, device.index or 0, rec.ctypes.data, 0, n, ptr(gooch),
+                                        spot.ctypes.data if spot is not None else None, ptr(rgba),
+                                        ptr(t), ptr(surf), _stream_ptr(torch, device)))
+        return rgba, t, surf
+
+
+# ---------------------------------------------------------------------------------------------
+# renderer helpers without a scene
+# ---------------------------------------------------------------------------------------------
+CAMERA_DTYPE = np.dtype(
+    [("world", "<f8", (16,)), ("h_pixels", "<i8"), ("v_pixels", "<i8"), ("h_width", "<f8"),
+     ("v_width", "<f8")], align=True)
+assert CAMERA_DTYPE.itemsize == 160
+
+
+def _light(light_positions):
+    """The single light the Gooch shader supports, as a contiguous float64[3]."""
+    spot = np.asarray(light_positions, dtype=float)
+    if spot.ndim != 1 or spot.shape[0] < 3:
+        # upstream's (k, lights) branch (gooch.py:48-51) only broadcasts for exactly three
+        # lights and then pairs coordinates with the wrong lights; it is not reproduced
+        raise ValueError("light_positions must be one (x, y, z[, w]) position")
+    return np.ascontiguousarray(spot[:3])
+
+
+def camera_record(camera):
+    rec = np.zeros(1, dtype=CAMERA_DTYPE)
+    rec["world"][0] = np.asarray(camera.get_world_transform(), dtype=float).reshape(-1)
+    rec["h_pixels"], rec["v_pixels"] = camera.get_resolution()
+    rec["h_width"], rec["v_width"] = camera.get_span()
+    return rec
+
+
+def default_device():
+    torch = _torch()
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def camera_rays(camera, device=None):
+    """CUDA (8, n) float64: origins (rows 0-3) and unit directions (4-7) of every pixel."""
+    torch = _torch()
+    device = default_device() if device is None else device
+    rec = camera_record(camera)
+    n = int(rec["h_pixels"][0]) * int(rec["v_pixels"][0])
+    out = torch.empty((8, n), dtype=torch.float64, device=device)
+    if n:
+        _check(library().prt_camera_rays(device.index or 0, rec.ctypes.data, 0, n, out.data_ptr(),
+                                         out.stride(0), _stream_ptr(torch, device)))
+    return out
+
+
+def edge_canvas(surf, h_pixels, v_pixels, rings):
+    """EdgeRender's picture from the flat (v*h) CUDA int64 surface ids: CUDA (v,h,4) float64."""
+    torch = _torch()
+    lib = library()
+    out = torch.empty((v_pixels, h_pixels, 4), dtype=torch.float64, device=surf.device)
+    if h_pixels * v_pixels:
+        work = torch.empty(lib.prt_edge_workspace_bytes(h_pixels, v_pixels), dtype=torch.uint8,
+                           device=surf.device)
+        _check(lib.prt_edge_canvas(surf.device.index or 0, surf.data_ptr(), h_pixels, v_pixels,
+                                   int(rings), out.data_ptr(), work.data_ptr(),
+                                   _stream_ptr(torch, surf.device)))
+    return out
+
+
+def surface_shade(surface, rays, distances, light_positions):
+    """``surface.shade(rays, distances, light_positions=...)`` -> host (4,n) RGBA."""
+    rays = np.atleast_3d(np.asarray(rays, dtype=float))
+    ds = DeviceScene.from_components([surface])
+    try:
+        torch = _torch()
+        dev = _to_device(rays, 8)
+        t = torch.from_numpy(np.array(np.broadcast_to(
+            np.asarray(distances, dtype=float), (dev.shape[1],)))).cuda()
+        surf = torch.full((dev.shape[1],), surface.get_id(), dtype=torch.int64, device=dev.device)
+        return ds.gooch_shade(dev, t, surf, light_positions).cpu().numpy().T
+    finally:
+        ds.close()
+
+
+def gooch_mix(material, rays, normals, light_positions):
+    """``GoochMaterial.shade(rays, normals, light_positions)`` -> host (4,n) RGBA."""
+    torch = _torch()
+    points = _to_device(np.atleast_3d(np.asarray(rays, dtype=float))[0], 4)
+    normals = np.asarray(normals, dtype=float)
+    normals = _to_device(normals.reshape(normals.shape[0], -1))
+    n = points.shape[1]
+    if normals.shape[1] != n or normals.shape[0] < 3:
+        raise ValueError("normals must be (>=3, n) for (2,4,n) rays")
+    shade = np.ascontiguousarray(np.concatenate(material.shade_pair()))
+    spot = _light(light_positions)
+    out = torch.empty((4, n), dtype=torch.float64, device=points.device)
+    if n:
+        if normals.stride(0) != points.stride(0):
+            raise ValueError("points and normals must share a leading dimension")
+        _check(library().prt_gooch_mix(points.device.index or 0, points.data_ptr(), normals.data_ptr(),
+                                       n, points.stride(0), shade.ctypes.data, spot.ctypes.data,
+                                       out.data_ptr(), out.stride(0), _stream_ptr(torch, points.device)))
+    return out.cpu().numpy()
 
 
 # ---------------------------------------------------------------------------------------------

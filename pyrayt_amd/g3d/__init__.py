@@ -1,11 +1,12 @@
 """pyrayt_amd.g3d -- scene-graph layer (the reference's ``tinygfx.g3d`` names).
 
-Only the objects the ray-propagation hot path consumes are provided: transforms, traceable
-surfaces, CSG nodes.  Renderers, cameras and Gooch shading (``tinygfx/g3d/renderers.py``,
-``materials/``) are out of scope.
+The objects the ray-propagation hot path consumes -- transforms, traceable surfaces, CSG
+nodes -- plus the second consumer of the intersect kernels: the
+orthographic camera, Gooch materials and the two renderers of ``tinygfx/g3d/renderers.py``.
 """
 from . import shapes
 from .shapes import Point, Vector, bundle_of_rays
+from . import materials
 from . import objects
 from .objects import (
     BLACK,
@@ -14,6 +15,7 @@ from .objects import (
     Cylinder,
     Intersectable,
     ObjectGroup,
+    OrthographicCamera,
     Paraboloid,
     Sphere,
     TracerSurface,
@@ -21,9 +23,10 @@ from .objects import (
     XYPlane,
 )
 from . import csg
+from . import renderers
 
 __all__ = [
-    "BLACK", "CountedObject", "Cuboid", "Cylinder", "Intersectable", "ObjectGroup", "Paraboloid", "Point",
-    "Sphere", "TracerSurface", "Vector", "WorldObject", "XYPlane", "bundle_of_rays", "csg",
-    "objects", "shapes",
+    "BLACK", "CountedObject", "Cuboid", "Cylinder", "Intersectable", "ObjectGroup", "OrthographicCamera",
+    "Paraboloid", "Point", "Sphere", "TracerSurface", "Vector", "WorldObject", "XYPlane",
+    "bundle_of_rays", "csg", "materials", "objects", "renderers", "shapes",
 ]

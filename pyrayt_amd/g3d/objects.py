@@ -14,6 +14,7 @@ from itertools import count
 import numpy as np
 
 from . import shapes
+from .materials import gooch
 
 _UNITS = {"deg": np.pi / 180.0, "rad": 1.0}
 
@@ -221,15 +222,9 @@ class Intersectable(WorldObject):
         return engine.component_intersect(self, rays)
 
 
-class _Untracable:
-    """Stand-in for the reference's default ``GoochMaterial`` (``world_objects.py:341``): a
-    surface left with it cannot be traced and a ray hitting it raises AttributeError."""
-
-    def __repr__(self):
-        return "<untracable default material>"
-
-
-BLACK = _Untracable()
+BLACK = gooch.BLACK
+"""Default surface material (``world_objects.py:341``): render-only.  It has no ``trace``, so a
+ray hitting such a surface in a RayTracer raises AttributeError, as upstream."""
 
 
 class TracerSurface(Intersectable):
@@ -256,6 +251,13 @@ class TracerSurface(Intersectable):
         from .. import engine
 
         return engine.surface_normals(self, positions)
+
+    def shade(self, rays, distances, **kwargs):
+        """(4,n) RGBA where the (2,4,n) ``rays`` meet this surface at parameters ``distances``,
+        lit from ``light_positions`` (reference: ``world_objects.py:385-399``); HIP engine."""
+        from .. import engine
+
+        return engine.surface_shade(self, rays, distances, **kwargs)
 
 
 class Sphere(TracerSurface):
@@ -300,3 +302,29 @@ class Cuboid(TracerSurface):
     @classmethod
     def from_length(cls, length, **kwargs):
         return cls.from_sides(length, length, length, **kwargs)
+
+
+class OrthographicCamera(WorldObject):
+    """A v x h grid of parallel rays: the camera sits in its y-z plane and looks along its +x
+    axis (``world_objects.py:499-537``).  Pixels run row-major from (+h/2, +v/2) to
+    (-h/2, -v/2).  The rays are produced on the device (``prt_camera_rays``); a render never
+    materialises them at all (``prt_render``)."""
+
+    def __init__(self, h_pixel_count, h_width, aspect_ratio, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._h_pixels = h_pixel_count
+        self._h_width = h_width
+        self._v_width = aspect_ratio * h_width
+        self._v_pixels = int(aspect_ratio * self._h_pixels)
+
+    def get_resolution(self):
+        return (self._h_pixels, self._v_pixels)
+
+    def get_span(self):
+        return (self._h_width, self._v_width)
+
+    def generate_rays(self):
+        """(2,4,n) world-space rays, one per pixel, unit directions (host array, as upstream)."""
+        from .. import engine
+
+        return engine.camera_rays(self).cpu().numpy().reshape(2, 4, -1)

@@ -13,12 +13,20 @@ from functools import lru_cache
 
 import numpy as np
 
+from .g3d.materials import gooch
+
 # kind codes, must match include/prt.h PRT_MAT_*
 NONE, ABSORBER, MIRROR, CONST_INDEX, SELLMEIER = range(5)
 
 
-class TracableMaterial:
+class TracableMaterial(gooch.Material):
     kind = NONE
+    _base_material = gooch.BLACK
+    """What the renderers draw the material with (``materials.py:11-24``): absorbers black,
+    mirrors and glasses blue."""
+
+    def shade(self, rays, normals, light_positions):
+        return self._base_material.shade(rays, normals, light_positions)
 
     def coefficients(self):
         return ()
@@ -46,10 +54,13 @@ class _ReflectingMaterial(TracableMaterial):
     """Ideal mirror, no change of index or intensity (``materials.py:53-62``)."""
 
     kind = MIRROR
+    _base_material = gooch.BLUE
 
 
 class Glass(TracableMaterial):
     """Refracting material with a wavelength dependent index (``materials.py:65-99``)."""
+
+    _base_material = gooch.BLUE
 
     def index_at(self, wavelength):
         raise NotImplementedError

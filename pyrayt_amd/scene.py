@@ -100,6 +100,18 @@ class SceneSnapshot:
         """((id, surface), ...) exactly like RayTracer._surface_lut (_pyrayt.py:257-260)."""
         return tuple((s.get_id(), s) for s in self.surfaces)
 
+    def gooch_table(self):
+        """(P,8) float64: shade_warm | shade_cool (``materials/gooch.py:36-37``) of every leaf
+        surface's render material, in primitive order.  Tracer materials render with their
+        ``_base_material`` (``pyrayt/materials.py:16-24``)."""
+        table = np.zeros((max(1, len(self.surfaces)), 8))
+        for k, surface in enumerate(self.surfaces):
+            paint = getattr(surface.material, "_base_material", surface.material)
+            if not hasattr(paint, "shade_pair"):
+                raise AttributeError(f"{surface.material!r} cannot be rendered: it has no Gooch shading")
+            table[k, :4], table[k, 4:] = paint.shade_pair()
+        return table
+
     def prim_index(self, surface):
         for i, s in enumerate(self.surfaces):
             if s is surface:

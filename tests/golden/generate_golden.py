@@ -450,8 +450,92 @@ def config2_summary(n=1_000_000):
     print(f"config2 1M summary   rows={frame.shape[0]} q5={q5.tolist()} -> {os.path.basename(path)}")
 
 
+def gooch_record(material):
+    """(shade_warm, shade_cool) of gooch.py:36-37 for a surface material (tracer materials
+    render with their ``_base_material``, pyrayt/materials.py:16-24)."""
+    g = getattr(material, "_base_material", material)
+    warm = (1 - g.alpha) * g.warm_color + g.alpha * g.base_color
+    cool = (1 - g.beta) * g.cool_color + g.beta * g.base_color
+    return np.concatenate((np.asarray(warm, dtype=float), np.asarray(cool, dtype=float)))
+
+
+class _CanvasAxis:
+    """Stands in for a matplotlib axis: keeps what draw() hands to imshow."""
+
+    def imshow(self, image, extent=None, **kwargs):
+        self.image, self.extent = np.array(image, dtype=float), np.array(extent, dtype=float)
+
+    def set_axisbelow(self, flag):
+        pass
+
+
+def render_vectors():
+    """Renderer fixtures: camera grid, nearest hit per pixel, Gooch-shaded and edge canvases
+    (tinygfx/g3d/renderers.py), plus what draw() passes to imshow and pyrayt/utils.py values."""
+    import tinygfx.g3d.renderers as ref_render
+    import pyrayt.utils as ref_utils
+
+    out = {}
+    for name, recipe in scenes.RENDER_SCENES.items():
+        runs = []
+        for stable in (False, True):
+            ref_csg.np = _StableNumpy() if stable else np
+            try:
+                reset_ids()
+                surfaces, camera, light = recipe(API)
+                shaded = ref_render.ShadedRenderer(camera, surfaces, light)
+                canvas = shaded.render()
+                edges = ref_render.EdgeRender(camera, surfaces).render()
+                lut = [surf for comp in surfaces for _, surf in comp.surface_ids]
+                res = {
+                    "cam_world": camera.get_world_transform(),
+                    "cam_pixels": np.array(camera.get_resolution(), dtype=np.int64),
+                    "cam_span": np.array(camera.get_span(), dtype=float),
+                    "light": np.asarray(light, dtype=float),
+                    "rays": np.array(shaded._rays),
+                    "t": shaded._hit_distances.copy(),
+                    "surf": shaded._hit_surfaces.astype(np.int64),
+                    "shaded": canvas, "edges": edges,
+                    "gooch": np.array([gooch_record(s.material) for s in lut]).reshape(-1, 8),
+                }
+                res.update(snapshot(surfaces))
+            finally:
+                ref_csg.np = np
+            runs.append(res)
+        b, a = runs
+        assert all(np.array_equal(a[k], b[k], equal_nan=True) for k in a), (name, "argsort sensitive")
+        for k, v in a.items():
+            out[f"{name}__{k}"] = v
+        hit = a["surf"] >= 0
+        print(f"  render {name:10s} {a['cam_pixels'][0]}x{a['cam_pixels'][1]} px, {int(hit.sum())} hit, "
+              f"{int((a['t'][hit] < 0).sum())} behind the camera, {int(a['edges'][..., 3].sum())} edge px")
+    # draw(): what reaches imshow (renderers.py:251-349)
+    for view in ("xy", "xz"):
+        for shaded in (True, False):
+            reset_ids()
+            axis = _CanvasAxis()
+            ref_render.draw(scenes.optical_bench(API), view=view, axis=axis, shaded=shaded, resolution=64)
+            key = f"draw_{view}_{'shaded' if shaded else 'edges'}"
+            out[key + "__image"], out[key + "__extent"] = axis.image, axis.extent
+    reset_ids()
+    axis = _CanvasAxis()
+    ref_render.draw(scenes.optical_bench(API), view="xy", axis=axis, shaded=True, resolution=48,
+                    bounds=((-3, -2, -1), (4, 2, 1)))
+    out["draw_bounds__image"], out["draw_bounds__extent"] = axis.image, axis.extent
+    # pyrayt/utils.py
+    waves = np.linspace(0.3, 0.8, 201)
+    out["utils__wavelengths"] = waves
+    out["utils__rgb"] = ref_utils.wavelength_to_rgb(waves)
+    out["utils__rgb_gamma"] = ref_utils.wavelength_to_rgb(waves, gamma=1.7)
+    out["utils__lensmakers"] = np.array([ref_utils.lensmakers_equation(2, -2, 1.5, 0.25),
+                                         ref_utils.lensmakers_equation(40, -200, 1.62, 5)])
+    path = os.path.join(HERE, "render.npz")
+    np.savez_compressed(path, **out)
+    print(f"render               -> {os.path.basename(path)} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 def main():
-    which = set(sys.argv[1:]) or {"scenes", "primitives", "csg", "shading", "sources", "summary"}
+    which = set(sys.argv[1:]) or {"scenes", "primitives", "csg", "shading", "sources", "summary", "render"}
     print(f"numpy {np.__version__} pandas {pd.__version__} (reference locks numpy 1.20.2 / pandas 1.2.4)")
     if "scenes" in which:
         scene_fixture("config1", 100, 1000)
@@ -473,6 +557,8 @@ def main():
         source_vectors()
     if "summary" in which:
         config2_summary()
+    if "render" in which:
+        render_vectors()
 
 
 if __name__ == "__main__":

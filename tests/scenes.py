@@ -217,6 +217,93 @@ def stopped_lens(api, n, seed=21):
     return [stop, lens, det], cone_rays(n, (-3.0, 0.0, 0.0), 12.0, seed, wavelength=0.48)
 
 
+# ---------------------------------------------------------------------------------------------
+# renderer views (tinygfx/g3d/renderers.py): (surfaces, camera, light position)
+# ---------------------------------------------------------------------------------------------
+def draw_camera(api, surfaces, view, resolution):
+    """The camera and light ``renderers.draw`` sets up for a view (renderers.py:284-349),
+    restated so that stepwise fixtures can be taken with the same geometry."""
+    cg = api.cg
+    corners = np.hstack([s.bounding_volume.bounding_points[:3] for s in surfaces])
+    mins, maxes = np.min(corners, axis=1), np.max(corners, axis=1)
+    origin = (maxes + mins) / 2
+    light = cg.Point(*maxes)
+    if view == "xy":
+        origin[2] = 1.5 * maxes[2]
+        h_span, v_span = 1.5 * (maxes[:2] - mins[:2])
+        light[2] *= 3
+    else:
+        origin[1] = 1.5 * maxes[1]
+        h_span, v_span = 1.5 * (maxes[[0, 2]] - mins[[0, 2]])
+        light[1] *= -3
+    resolution = resolution if h_span > v_span else int(resolution * h_span / v_span)
+    camera = cg.OrthographicCamera(resolution, h_span, v_span / h_span)
+    if view == "xy":
+        camera.rotate_y(90).rotate_z(90).move(*origin[:3])
+    else:
+        camera.rotate_z(90).move(*origin[:3])
+    return camera, np.asarray(light, dtype=float)
+
+
+def render_spheres(api):
+    """test/test_tinygfx/test_g3d/test_renderers.py:19-24 with coloured Gooch materials."""
+    cg = api.cg
+    gooch = cg.materials.gooch
+    surfaces = (
+        cg.Sphere(1, material=gooch.WHITE).move_x(3).move_y(0.5),
+        cg.Sphere(1, material=gooch.RED).move_x(3).move_y(-0.5),
+    )
+    return surfaces, cg.OrthographicCamera(40, 10, 1), np.array((0.0, 10.0, 10.0))
+
+
+def optical_bench(api):
+    """Lens, stop, curved mirror and detector: every tracer material, CSG parts and a bare plane."""
+    c = api.components
+    lens = c.biconvex_lens(2, 2, 0.25, aperture=1)
+    stop = c.aperture((1.5, 1.5), 0.4).move_x(0.6)
+    mirror = c.spherical_mirror(4.0, 0.3, aperture=1.2).rotate_z(200).move(2.5, 0.4, 0)
+    prism = c.equilateral_prism(0.8, 0.6).move(-1.5, -0.5, 0.1)
+    detector = c.baffle((1, 1)).rotate_z(10).move_x(1.2)
+    return [lens, stop, mirror, prism, detector]
+
+
+def render_bench_xy(api, resolution=96):
+    surfaces = optical_bench(api)
+    camera, light = draw_camera(api, surfaces, "xy", resolution)
+    return surfaces, camera, light
+
+
+def render_bench_xz(api, resolution=96):
+    surfaces = optical_bench(api)
+    camera, light = draw_camera(api, surfaces, "xz", resolution)
+    return surfaces, camera, light
+
+
+def render_inside(api):
+    """A camera in the middle of the scene: some of its rays have all their hits behind them,
+    which the renderers' argmin-over-masked / gather-unmasked rule turns into a negative
+    nearest hit (renderers.py:79-86)."""
+    cg = api.cg
+    gooch = cg.materials.gooch
+    behind = cg.Sphere(1.2, material=gooch.GREEN).move(-3, 0.4, 0.2)
+    ahead = cg.Cuboid.from_sides(1, 1.5, 1, material=gooch.YELLOW).rotate_z(25).move(3, -0.9, 0.3)
+    lens_behind = api.components.biconvex_lens(3, 3, 0.4, aperture=1.6).move(-5, -0.8, -0.5)
+    shell = cg.csg.difference(
+        cg.Sphere(1.0, material=gooch.ORANGE), cg.Sphere(0.8, material=gooch.BLUE).move_x(-0.5)
+    ).move(4, 1.2, -0.4)
+    around = cg.Cylinder(0.9, -0.3, 0.3).rotate_y(90).move(0, 0.2, 1.0)
+    camera = cg.OrthographicCamera(48, 6, 0.75).rotate_z(4).rotate_y(-3)
+    return [behind, ahead, lens_behind, shell, around], camera, np.array((2.0, -4.0, 9.0, 1.0))
+
+
+RENDER_SCENES = {
+    "spheres": render_spheres,
+    "bench_xy": render_bench_xy,
+    "bench_xz": render_bench_xz,
+    "inside": render_inside,
+}
+
+
 SCENES = {
     "stopped_lens": stopped_lens,
     "config1": config1,
