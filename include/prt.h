@@ -120,6 +120,10 @@ int prt_scene_create(const prt_prim* prims, int n_prims, const prt_node* nodes, 
 void prt_scene_destroy(prt_scene* scene);
 /* rows of the hit list component `root` returns from intersect(): 2 * (#leaves under it) */
 int prt_scene_component_rows(const prt_scene* scene, int root);
+/* what the scene compiled to (no counterpart upstream; host-only, needs no GPU):
+ * out8 = { primitives, components, steps of the trace program, LDS hit-list slots per ray of the
+ * trace program, component cull steps in it, steps / slots of the render program, 0 } */
+int prt_scene_info(const prt_scene* scene, int64_t* out8);
 
 /* ---- per-state entry points (drop-ins for the reference's Python methods) ------------------ */
 

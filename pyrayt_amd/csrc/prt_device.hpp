@@ -33,7 +33,7 @@ struct DevPrim {
   int32_t type, mat_kind, normal_scale, pad;
 };
 
-enum { I_LEAF = 0, I_CSG = 1, I_ROOT = 2 };
+enum { I_LEAF = 0, I_CSG = 1, I_ROOT = 2, I_BOX = 3 };
 enum { OPER_REGA = 0, OPER_REGB = 1, OPER_LDS = 2 };
 enum { CSG_UNION = 1, CSG_INTERSECT = 2, CSG_DIFFERENCE = 3 };
 enum { PRIM_SPHERE = 0, PRIM_CYLINDER = 1, PRIM_PLANE = 2, PRIM_CUBE = 3, PRIM_PARABOLOID = 4 };
@@ -666,6 +666,30 @@ __device__ __forceinline__ void csg_step(const DevInstr* __restrict__ in, const 
   }
 }
 
+// Component cull (I_BOX step, trace programs of scenes with several components): can this ray
+// reach the component's box at a parameter in (0, best_t]?  `box` bounds every leaf surface of the
+// component in world space, padded on the host by 1e-3 of its diagonal; every positive finite entry
+// of the component's hit list is a parameter at which the ray is (numerically) on one of those
+// surfaces, so "no" means the component cannot change the running nearest hit: a tie with best_t
+// keeps the earlier component (_pyrayt.py:384), a larger value loses.  The test only ever errs
+// towards "yes": reciprocal by v_rcp_f64 with a 1e-6 relative allowance, NaN compares false.
+__device__ __forceinline__ bool may_reach(const double* __restrict__ box, const Ray8& r, double best_t) {
+  double t_in = 0.0, t_out = best_t;
+  bool never = false;
+  const double o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double inv = __builtin_amdgcn_rcp(d[k]);
+    const double a = (box[2 * k] - o[k]) * inv, b = (box[2 * k + 1] - o[k]) * inv;
+    const bool parallel = fabs(d[k]) < 1e-300;  // the slab either contains the whole ray or none of it
+    never = never || (parallel && (o[k] < box[2 * k] || o[k] > box[2 * k + 1]));
+    t_in = parallel ? t_in : fmax(t_in, fmin(a, b));
+    t_out = parallel ? t_out : fmin(t_out, fmax(a, b));
+  }
+  const double slack = 1e-6 * (fabs(t_in) + fabs(t_out));
+  return !never && !(t_in - slack > t_out + slack);
+}
+
 // One program step for one ray (state: the two register pairs and the running nearest hit).
 // RENDER selects the renderers' root rule at compile time, so the tracer's kernels carry none of it.
 template <bool RENDER = false>
@@ -741,7 +765,8 @@ __device__ __forceinline__ void run_step(const DevInstr* in, const Ray8& ray, co
 // with the strict '<' running minimum of _pyrayt.py:384-386.  `code` is wave-uniform; each
 // step record is fetched once (one batch of scalar loads) and applied to the lane's R rays,
 // whose arithmetic is independent and interleaves.
-template <int R, bool RENDER = false>
+// CULL: the program may contain I_BOX steps (compiled out of the kernels that never see one).
+template <int R, bool RENDER = false, bool CULL = true>
 __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code, int n_instr,
                                               const Ray8 (&ray)[R], int slots, double (&best_t)[R],
                                               int (&best_prim)[R]) {
@@ -755,6 +780,13 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
   }
   for (int pc = 0; pc < n_instr; ++pc) {
     const DevInstr step = code[pc];  // the whole record, one batch of scalar loads
+    if (CULL && !RENDER && step.kind == I_BOX) {
+      bool wanted = false;
+#pragma unroll
+      for (int k = 0; k < R; ++k) wanted = wanted || may_reach(step.data, ray[k], best_t[k]);
+      if (__ballot(wanted) == 0ull) pc += step.a0;  // no lane of the wave needs this component
+      continue;
+    }
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       const LaneLists lists = {R * slots, k * slots};
@@ -763,7 +795,7 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
   }
 }
 
-template <bool RENDER = false>
+template <bool RENDER = false, bool CULL = true>
 __device__ __forceinline__ void nearest_hit(const DevPrim* __restrict__ prims,
                                             const DevInstr* __restrict__ code, int n_instr,
                                             const Ray8& ray, const LaneLists& lists, double& best_t,
@@ -772,7 +804,7 @@ __device__ __forceinline__ void nearest_hit(const DevPrim* __restrict__ prims,
   const Ray8 rays1[1] = {ray};
   double t1[1];
   int p1[1];
-  nearest_hit_n<1, RENDER>(code, n_instr, rays1, lists.total, t1, p1);
+  nearest_hit_n<1, RENDER, CULL>(code, n_instr, rays1, lists.total, t1, p1);
   best_t = t1[0];
   best_prim = p1[0];
 }

@@ -19,6 +19,8 @@
 //   k_intersect / k_normals / k_material_trace   the per-object entry points
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -203,9 +205,104 @@ static void shift_slots(std::vector<DevInstr>& code, size_t from, int shift) {
 }
 
 // compile component `root_node`; returns where its result list ends up
+// ---- world-space bounds of a component's leaf surfaces (for the I_BOX cull step) ---------------
+static bool invert4(const double* m, double* out) {
+  double a[4][8];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) { a[r][c] = m[4 * r + c]; a[r][4 + c] = r == c ? 1.0 : 0.0; }
+  for (int col = 0; col < 4; ++col) {
+    int piv = col;
+    for (int r = col + 1; r < 4; ++r) if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
+    if (!(std::fabs(a[piv][col]) > 1e-300)) return false;
+    for (int c = 0; c < 8; ++c) std::swap(a[col][c], a[piv][c]);
+    const double inv = 1.0 / a[col][col];
+    for (int c = 0; c < 8; ++c) a[col][c] *= inv;
+    for (int r = 0; r < 4; ++r) {
+      if (r == col) continue;
+      const double f = a[r][col];
+      for (int c = 0; c < 8; ++c) a[r][c] -= f * a[col][c];
+    }
+  }
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out[4 * r + c] = a[r][4 + c];
+  return true;
+}
+
+// object-space bounds of a primitive: the extents its intersect routine clips to
+static bool prim_bounds(const prt_prim& p, double lo[3], double hi[3]) {
+  const double* q = p.params;
+  switch (p.type) {
+    case PRT_PRIM_SPHERE: { const double r = std::fabs(q[0]); for (int k = 0; k < 3; ++k) { lo[k] = -r; hi[k] = r; } } return true;
+    case PRT_PRIM_CYLINDER: { const double r = std::fabs(q[0]); lo[0] = lo[1] = -r; hi[0] = hi[1] = r;
+      lo[2] = std::min(q[1], q[2]); hi[2] = std::max(q[1], q[2]); } return true;
+    case PRT_PRIM_PLANE: lo[0] = -std::fabs(q[0]) / 2; hi[0] = std::fabs(q[0]) / 2; lo[1] = -std::fabs(q[1]) / 2;
+      hi[1] = std::fabs(q[1]) / 2; lo[2] = hi[2] = 0.0; return true;
+    case PRT_PRIM_CUBE: for (int k = 0; k < 3; ++k) { lo[k] = std::min(q[2 * k], q[2 * k + 1]); hi[k] = std::max(q[2 * k], q[2 * k + 1]); } return true;
+    case PRT_PRIM_PARABOLOID: { if (!(q[0] > 0) || !(q[1] > 0)) return false; const double rim = std::sqrt(4 * q[0] * q[1]);
+      lo[0] = lo[1] = -rim; hi[0] = hi[1] = rim; lo[2] = 0.0; hi[2] = q[1]; } return true;
+  }
+  return false;
+}
+
+// World-space box (xmin,xmax,ymin,ymax,zmin,zmax) of the solid of `node`: a leaf's is the box of
+// its transformed object-space corners; A&B lies in both operands' boxes, A-B in A's, A|B in their
+// union.  Every entry a node's hit list keeps is a parameter at which the ray crosses the boundary
+// of that solid (array_csg keeps exactly the depth changes into and out of "inside"), hence a point
+// of this box -- which, unlike upstream's own cull box (csg.py:93-116), is only ever used to skip
+// work that cannot matter, never to change a result.
+static bool solid_bounds(const prt_scene* s, int node, double* box) {
+  const prt_node& n = s->nodes[node];
+  if (n.op != PRT_NODE_LEAF) {
+    double l[6], r[6];
+    if (!solid_bounds(s, n.left, l)) return false;
+    if (n.op == PRT_NODE_DIFFERENCE) { std::memcpy(box, l, sizeof(l)); return true; }
+    if (!solid_bounds(s, n.right, r)) return false;
+    for (int k = 0; k < 3; ++k) {
+      const bool both = n.op == PRT_NODE_INTERSECT;
+      box[2 * k] = both ? std::max(l[2 * k], r[2 * k]) : std::min(l[2 * k], r[2 * k]);
+      box[2 * k + 1] = both ? std::min(l[2 * k + 1], r[2 * k + 1]) : std::max(l[2 * k + 1], r[2 * k + 1]);
+    }
+    return true;
+  }
+  const prt_prim& p = s->prims[n.prim];
+  double lo[3], hi[3], world[16];
+  if (!prim_bounds(p, lo, hi) || !invert4(p.minv, world)) return false;
+  for (int k = 0; k < 3; ++k) { box[2 * k] = HUGE_VAL; box[2 * k + 1] = -HUGE_VAL; }
+  for (int corner = 0; corner < 8; ++corner) {
+    const double v[3] = {(corner & 1) ? hi[0] : lo[0], (corner & 2) ? hi[1] : lo[1], (corner & 4) ? hi[2] : lo[2]};
+    const double w = world[12] * v[0] + world[13] * v[1] + world[14] * v[2] + world[15];
+    for (int k = 0; k < 3; ++k) {
+      const double x = (world[4 * k] * v[0] + world[4 * k + 1] * v[1] + world[4 * k + 2] * v[2] + world[4 * k + 3]) / w;
+      if (!std::isfinite(x)) return false;
+      box[2 * k] = std::min(box[2 * k], x);
+      box[2 * k + 1] = std::max(box[2 * k + 1], x);
+    }
+  }
+  return true;
+}
+
 enum { ROOT_NONE = 0, ROOT_TRACE = 1, ROOT_RENDER = 2 };
 static Operand compile_component(const prt_scene* s, int root_node, std::vector<DevInstr>& code,
                                  int root_rule, int* slots) {
+  // a scene of several components gets a cull step in front of each: most rays can reach only one
+  // or two of them (see may_reach); with one or two components the test would cost more than it saves
+  size_t box_at = (size_t)-1;
+  static const bool cull_off = std::getenv("PRT_NO_CULL") != nullptr;  // experiment knob
+  if (root_rule == ROOT_TRACE && s->roots.size() >= 3 && !cull_off) {
+    DevInstr in = Compiler::blank(I_BOX);
+    double* box = in.data;
+    if (solid_bounds(s, root_node, box)) {
+      double diag = 0, reach = 0;
+      for (int k = 0; k < 3; ++k) {
+        const double side = std::max(0.0, box[2 * k + 1] - box[2 * k]);  // an empty overlap has no extent
+        diag += side * side;
+        reach = std::max(reach, std::max(std::fabs(box[2 * k]), std::fabs(box[2 * k + 1])));
+      }
+      const double pad = 1e-3 * std::sqrt(diag) + 1e-9 * reach + 1e-12;
+      for (int k = 0; k < 3; ++k) { box[2 * k] -= pad; box[2 * k + 1] += pad; }
+      box_at = code.size();
+      code.push_back(in);
+    }
+  }
   const size_t from = code.size();
   Compiler c{s, code};
   c.positive_only = root_rule == ROOT_TRACE;
@@ -223,6 +320,7 @@ static Operand compile_component(const prt_scene* s, int root_node, std::vector<
     in.pad[0] = root_rule == ROOT_RENDER ? 2 : 0;
     code.push_back(in);
   }
+  if (box_at != (size_t)-1) code[box_at].a0 = (int)(code.size() - from);  // steps to jump over
   const int shift = -c.lowest;
   shift_slots(code, from, shift);
   if (res.mode == OPER_LDS) res.base += shift;
@@ -322,6 +420,21 @@ extern "C" void prt_scene_destroy(prt_scene* s) {
     if (c.ev1) (void)hipEventDestroy(c.ev1);
   }
   delete s;
+}
+
+extern "C" int prt_scene_info(const prt_scene* s, int64_t* out8) {
+  if (!s || !out8) return fail(PRT_ERR_ARG, "null argument");
+  int64_t culls = 0;
+  for (const DevInstr& in : s->trace_program.code) culls += in.kind == I_BOX ? 1 : 0;
+  out8[0] = (int64_t)s->prims.size();
+  out8[1] = (int64_t)s->roots.size();
+  out8[2] = (int64_t)s->trace_program.code.size();
+  out8[3] = s->trace_program.lds_slots;
+  out8[4] = culls;
+  out8[5] = (int64_t)s->render_program.code.size();
+  out8[6] = s->render_program.lds_slots;
+  out8[7] = 0;
+  return PRT_OK;
 }
 
 extern "C" int prt_scene_component_rows(const prt_scene* s, int root) {
@@ -782,6 +895,9 @@ __device__ long long g_stamps[16384 * 4 * 8];
 #ifndef PRT_GEN_WAVES
 #define PRT_GEN_WAVES 5
 #endif
+// CULL = the trace program carries component cull steps (scenes of three or more components);
+// the instantiation without them is the one the register budget above was tuned for.
+template <bool CULL>
 __global__ void __launch_bounds__(PRT_BLOCK, PRT_GEN_WAVES)
 k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double* __restrict__ next,
              int64_t ld_next, double* __restrict__ rows, int64_t ld_rows, FusedCtrl* __restrict__ ctrl,
@@ -822,7 +938,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     if (r.ox + r.oy + r.oz + r.ow + r.dx + r.dy + r.dz + r.dw == 1.2345e300) t = 0;  // force the wait here
     STAMP(1);
 #endif
-    nearest_hit(scene.prims, scene.code, scene.n_instr, r, lists, t, prim);
+    nearest_hit<false, CULL>(scene.prims, scene.code, scene.n_instr, r, lists, t, prim);
     live = is_live(r, prim);
     carry = live && (keep_absorbed || scene.prims[prim].mat_kind != MAT_ABSORBER);
   }
@@ -1204,7 +1320,8 @@ static int raise_lds_limits() {
   HIP_TRY(hipFuncSetAttribute((const void*)k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_render_hits, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_hit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
-  HIP_TRY(hipFuncSetAttribute((const void*)k_generation, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_generation<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_generation<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_generation2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_intersect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   return PRT_OK;
@@ -1549,6 +1666,8 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
   const char* rpl_env = getenv("PRT_RAYS_PER_LANE");
   const bool two_per_lane = rpl_env && rpl_env[0] == '2' && 2 * lds <= kMaxLdsBytes;
   GenCtrl* host_gen = c->host_gen + 1;  // slot -1 receives the control header
+  bool culls = false;
+  for (const DevInstr& in : s->trace_program.code) culls = culls || in.kind == I_BOX;
   int64_t bound = n, total_rows = 0;
   int g = 0, error = 0;
   bool done = false;
@@ -1566,7 +1685,8 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
                            buf[gg & 1], n, rows_out, rows_cap, ctrl, gen, gg, tiles[gg & 1],
                            tiles[(gg + 1) & 1], (double)(gg + 1), relaunch, ray_offset, keep_absorbed);
       } else {
-        hipLaunchKernelGGL(k_generation, dim3(blocks_for(bound)), dim3(PRT_BLOCK), lds + lds_pad, st, sd, src,
+        auto kernel = culls ? k_generation<true> : k_generation<false>;
+        hipLaunchKernelGGL(kernel, dim3(blocks_for(bound)), dim3(PRT_BLOCK), lds + lds_pad, st, sd, src,
                            src_ld, buf[gg & 1], n, rows_out, rows_cap, ctrl, gen, gg, tiles[gg & 1],
                            tiles[(gg + 1) & 1], (double)(gg + 1), relaunch, ray_offset, keep_absorbed);
       }

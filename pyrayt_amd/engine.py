@@ -40,6 +40,7 @@ def _declare(lib):
         "prt_scene_create": (c_int, [c_p, c_int, c_p, c_int, c_p, c_int, c_p, c_int, ctypes.POINTER(c_p)]),
         "prt_scene_destroy": (None, [c_p]),
         "prt_scene_component_rows": (c_int, [c_p, c_int]),
+        "prt_scene_info": (c_int, [c_p, c_p]),
         "prt_intersect": (c_int, [c_p, c_int, c_int, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
         "prt_propagate": (c_int, [c_p, c_int, c_p, c_i64, c_i64, c_p, c_p, c_p]),
         "prt_world_normals": (c_int, [c_p, c_int, c_int, c_p, c_i64, c_i64, c_p, c_p]),
@@ -69,7 +70,7 @@ def _declare(lib):
 
 EXPORTED_SYMBOLS = (
     "prt_version", "prt_last_error", "prt_device_count", "prt_scene_create", "prt_scene_destroy",
-    "prt_scene_component_rows", "prt_intersect", "prt_propagate", "prt_world_normals",
+    "prt_scene_component_rows", "prt_scene_info", "prt_intersect", "prt_propagate", "prt_world_normals",
     "prt_material_trace", "prt_interact_workspace_bytes", "prt_interact",
     "prt_trace_workspace_bytes", "prt_trace", "prt_trace_stats", "prt_generate_rays",
     "prt_camera_rays", "prt_render_hits", "prt_gooch_shade", "prt_gooch_mix", "prt_render",
@@ -154,6 +155,14 @@ class DeviceScene:
     def component_rows(self, root):
         return _check(library().prt_scene_component_rows(self.handle, root))
 
+    def info(self):
+        """What the scene compiled to (host-only): step / slot / cull-step counts."""
+        out = (ctypes.c_int64 * 8)()
+        _check(library().prt_scene_info(self.handle, out))
+        keys = ("primitives", "components", "trace_steps", "trace_slots", "cull_steps", "render_steps",
+                "render_slots")
+        return dict(zip(keys, (int(v) for v in out)))
+
     def close(self):
         if self._handle:
             library().prt_scene_destroy(self._handle)
@@ -180,7 +189,7 @@ class DeviceScene:
         limit = int(generation_limit)
         if n == 0 or limit <= 0:
             return torch.empty((RECORD_COLS, 0), dtype=torch.float64, device=dev), []
-        cap = int(rows_cap) if rows_cap is not None else n * min(limit, 4)
+        cap = int(rows_cap) if rows_cap is not None else self._rows_cap(torch, n, limit, dev)
         work = self._workspace(torch, n, dev)
         counts = (ctypes.c_int64 * limit)()
         while True:
@@ -191,14 +200,29 @@ class DeviceScene:
                 _stream_ptr(torch, dev),
             )
             if total == ERR_ROWS_CAP and cap < n * limit:
-                cap = min(n * limit, cap * 4)  # rare: more than 4 generations survived
+                cap = min(n * limit, cap * 4)  # only when HBM was too tight for the full block
                 continue
             _check(total)
             break
+        self._cap_hint = (n, limit, cap)
         per_generation = [int(c) for c in counts]
         while per_generation and per_generation[-1] == 0:
             per_generation.pop()
         return rows[:, :total], per_generation
+
+    def _rows_cap(self, torch, n, limit, dev):
+        """Columns of the record block.  n * limit always suffices (one row per ray and generation)
+        and costs nothing until written, so it is used whenever it fits comfortably in free HBM;
+        otherwise start at four generations' worth and let the ROWS_CAP retry grow it (a retry
+        re-runs the trace).  The size that worked is remembered for the next identical call."""
+        hint = getattr(self, "_cap_hint", None)
+        if hint is not None and hint[:2] == (n, limit):
+            return hint[2]
+        full = n * limit
+        free, _ = torch.cuda.mem_get_info(dev)
+        if full * RECORD_COLS * 8 <= free // 3:
+            return full
+        return n * min(limit, 4)
 
     def _workspace(self, torch, n, dev):
         """Scratch for prt_trace (ping-pong ray sets, control words); kept between calls."""

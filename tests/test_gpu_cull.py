@@ -1,0 +1,117 @@
+"""Scenes of many components: the trace program carries a cull step per component (a ray that
+cannot reach a component's box before its current nearest hit skips the component, per wave).
+The step must never change a result: HIP engine vs the C oracle (which has no such step), surface
+ids exact, on scenes built to stress it -- a lens train traversed in both directions, rays born
+inside boxes, incoherent rays over a grid of parts, empty and unioned solids, touching parts."""
+import numpy as np
+import pytest
+
+import helpers
+import scenes
+from oracle import c_oracle
+from test_gpu_fuzz import random_component
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def check(parts, rays, limit, expect_culls=True):
+    from pyrayt_amd.engine import DeviceScene
+    from pyrayt_amd.scene import SceneSnapshot
+
+    snap = SceneSnapshot(parts)
+    flat = helpers.flat_scene(snap)
+    ds = DeviceScene(snap)
+    info = ds.info()
+    assert info["cull_steps"] == (len(parts) if expect_culls else 0), info
+    device_rays = torch.from_numpy(np.ascontiguousarray(rays)).to("cuda:0")
+    t, surf = ds.propagate(device_rays)
+    want_t, want_surf = c_oracle.propagate(flat, rays)
+    assert np.array_equal(surf.cpu().numpy(), want_surf)
+    assert np.allclose(t.cpu().numpy(), want_t, rtol=0, atol=helpers.ATOL)
+    want, want_counts = c_oracle.trace(flat, rays, limit)
+    for flags in (0, 2):
+        rows, counts = ds.trace(device_rays, limit, flags=flags)
+        assert counts == want_counts, flags
+        helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"flags {flags}")
+    ds.close()
+    return want_counts
+
+
+@pytest.fixture()
+def api():
+    import pyrayt_amd.g3d as cg
+
+    cg.CountedObject.reset_ids()
+    return scenes.product_api()
+
+
+def test_lens_train_both_directions(api):
+    c = api.components
+    parts = [c.biconvex_lens(4, 4, 0.25, aperture=1).move_x(1.0 * k) for k in range(6)]
+    parts.append(c.plane_mirror(0.1, aperture=(2.0, 2.0)).move_x(6.5))      # sends the beam back
+    parts.append(c.baffle((3, 3)).move_x(-4))                                # behind the source
+    rays = np.hstack((scenes.cone_rays(6000, (-3.0, 0.0, 0.0), 3.0, 17),
+                      scenes.random_rays(2192, 18, box=7.0, degenerate=True)))
+    rays[12] = np.arange(rays.shape[1])
+    counts = check(parts, rays, 40)
+    assert len(counts) > 20  # forward through six lenses, off the mirror, and back again
+
+
+def test_rays_born_inside_boxes_and_nested_parts(api):
+    cg, m = api.cg, api.materials
+    shell = cg.csg.difference(cg.Sphere(3.0, material=m.glass["BK7"]), cg.Sphere(2.5, material=m.glass["BK7"]))
+    core = cg.Sphere(0.8, material=m.mirror).move(0.3, 0.2, -0.1)
+    bar = cg.Cuboid.from_sides(0.3, 4.0, 0.3, material=m.glass["SF5"]).rotate_z(30)
+    plate = api.components.baffle((8, 8)).move_x(3.5)
+    rays = scenes.random_rays(8192, 23, box=2.4, degenerate=True)
+    check([shell, core, bar, plate], rays, 8)
+
+
+def test_incoherent_rays_over_a_grid_of_parts(api):
+    cg, m = api.cg, api.materials
+    parts = []
+    for ix in range(4):
+        for iy in range(4):
+            kind = (ix + iy) % 3
+            if kind == 0:
+                part = cg.Sphere(0.35, material=m.mirror)
+            elif kind == 1:
+                part = api.components.biconvex_lens(1.5, 1.5, 0.2, aperture=0.7).rotate_z(15 * ix)
+            else:
+                part = cg.Cuboid.from_sides(0.5, 0.4, 0.6, material=m.glass["SF2"]).rotate_x(20 * iy)
+            parts.append(part.move(1.2 * ix - 1.8, 1.2 * iy - 1.8, 0.3 * (ix - iy)))
+    rays = scenes.random_rays(16384, 29, box=3.5, degenerate=True)
+    check(parts, rays, 6)
+
+
+def test_empty_unioned_and_touching_solids(api):
+    cg, m = api.cg, api.materials
+    nothing = cg.csg.intersect(cg.Sphere(1.0, material=m.mirror), cg.Sphere(1.0, material=m.mirror).move_x(5))
+    kissing = cg.csg.intersect(cg.Sphere(1.0, material=m.mirror).move_y(3),
+                               cg.Sphere(1.0, material=m.mirror).move(2.0, 3.0, 0.0))  # touch in one point
+    dumbbell = cg.csg.union(cg.Sphere(0.6, material=m.glass["ideal"]).move_z(-2),
+                            cg.Sphere(0.6, material=m.glass["ideal"]).move_z(2.2))   # disjoint union
+    stack_a = cg.Cuboid.from_sides(1, 1, 1, material=m.mirror).move(-3, 0, 0)
+    stack_b = cg.Cuboid.from_sides(1, 1, 1, material=m.absorber).move(-2, 0, 0)       # shares a face with a
+    rays = scenes.random_rays(8192, 31, box=4.0, degenerate=True)
+    # a beam along the shared face plane and through the touching point
+    rays[0:3, 100:164] = np.array([[-2.5], [-3.0], [0.0]]) + np.random.default_rng(3).uniform(-0.2, 0.2, (3, 64)) * [[0], [0], [1]]
+    rays[4:7, 100:164] = [[0.0], [1.0], [0.0]]
+    check([nothing, kissing, dumbbell, stack_a, stack_b], rays, 6)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_scenes_of_many_components(api, seed):
+    rng = np.random.default_rng(7000 + seed)
+    parts = []
+    for _ in range(int(rng.integers(6, 14))):
+        comp = random_component(rng, api.cg, api.materials, depth=int(rng.integers(0, 3)))
+        parts.append(comp.move(*rng.uniform(-4.0, 4.0, 3)))
+    rays = scenes.random_rays(12_000, seed=7100 + seed, box=5.0, wavelength=0.55)
+    check(parts, rays, 6)
+
+
+def test_two_components_carry_no_cull_steps(api):
+    parts, rays = scenes.config2(api, 2048)
+    check(parts, rays, 10, expect_culls=False)

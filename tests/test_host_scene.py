@@ -177,3 +177,23 @@ def test_object_group_and_pin():
         assert np.allclose(lens.get_position()[:3], (100 * np.cos(np.radians(30)), 0, -100 * np.sin(np.radians(30))))
     assert np.allclose(lens.get_position(), (0, 0, 0, 1))
     assert np.allclose(SceneSnapshot([lens]).prims["minv"], before, atol=1e-12)
+
+
+def test_compiled_programs_carry_cull_steps_only_for_three_or_more_components():
+    """prt_scene_create / prt_scene_info are host-only: the scene compiler runs without a GPU."""
+    import scenes
+    from pyrayt_amd import engine
+    from pyrayt_amd.g3d.objects import CountedObject
+
+    api = scenes.product_api()
+    expected = {"config2": (2, 4, 0), "config3": (5, 12, 5), "stopped_lens": (3, 5, 3)}
+    for name, (components, prims, culls) in expected.items():
+        CountedObject.reset_ids()
+        parts, _ = scenes.SCENES[name](api, 8)
+        ds = engine.DeviceScene.from_components(parts)
+        info = ds.info()
+        ds.close()
+        assert (info["components"], info["primitives"], info["cull_steps"]) == (components, prims, culls), name
+        # one step per leaf, one per CSG node, a root step per single-surface component, + culls
+        assert info["trace_steps"] == info["render_steps"] - components + culls + sum(
+            1 for p in parts if not hasattr(p, "children"))
