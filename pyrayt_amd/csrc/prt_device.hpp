@@ -18,7 +18,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef PRT_BLOCK
 #define PRT_BLOCK 256
+#endif
 #define PRT_INF (__builtin_inf())
 
 // ---- device-side scene ----------------------------------------------------------------------
@@ -534,52 +536,53 @@ __device__ __forceinline__ void csg_node(int op, int l_base, int r_base, int out
     if (RREG) { rv[j] = (j == 0) ? rb.t0 : rb.t1; rid[j] = rb.prim; }
     else { rv[j] = lists.get_t(r_base + j); rid[j] = lists.get_id(r_base + j); }
   }
+  // c(i,j) = L_i sorts before R_j.  Everything the keep rule needs is a parity: with p_i = (number
+  // of R entries before L_i) mod 2 and q_j = (number of L entries before-or-at R_j) mod 2, working the
+  // +-1 depths of array_csg through (own list alternates from +1, or from -1 for the right list
+  // of a DIFFERENCE, whose depth also starts at 1; "depth before" of the first merged entry is the
+  // np.roll wrap value, which the same algebra yields) gives
+  //     UNION       keep L_i = !p_i   keep R_j = !q_j      (depth != 0  xor  before != 0)
+  //     INTERSECT   keep L_i =  p_i   keep R_j =  q_j      (depth == 2  or   before == 2)
+  //     DIFFERENCE  keep L_i = !p_i   keep R_j =  q_j
+  // -- lane masks and scalar logic only; per-lane integers are needed only to place survivors.
   bool c[ML][MR];
-  int r_before[ML], l_before[MR];
+  bool p[ML], q[MR];
 #pragma unroll
-  for (int i = 0; i < ML; ++i) r_before[i] = 0;
+  for (int i = 0; i < ML; ++i) p[i] = false;
 #pragma unroll
-  for (int j = 0; j < MR; ++j) l_before[j] = 0;
+  for (int j = 0; j < MR; ++j) q[j] = false;
 #pragma unroll
   for (int i = 0; i < ML; ++i) {
 #pragma unroll
     for (int j = 0; j < MR; ++j) {
       c[i][j] = lv[i] <= rv[j];
-      l_before[j] += c[i][j] ? 1 : 0;
-      r_before[i] += c[i][j] ? 0 : 1;
+      q[j] = q[j] != c[i][j];
+      p[i] = p[i] == c[i][j];  // flips when R_j is before L_i, i.e. when !c
     }
   }
-  const int diff = (op == CSG_DIFFERENCE) ? 1 : 0;
-  const int r_first = diff ? -1 : 1;
+  const bool flip_l = op != CSG_INTERSECT, flip_r = op == CSG_UNION;
   bool keep_l[ML], keep_r[MR];
 #pragma unroll
-  for (int i = 0; i < ML; ++i) {
-    const int own = (i & 1) ? -1 : 1;
-    const int depth = ((i & 1) ? 0 : 1) + ((r_before[i] & 1) ? r_first : 0) + diff;
-    const int before = depth - own;
-    const bool keep = (op == CSG_UNION) ? ((depth != 0) != (before != 0)) : (depth == 2 || before == 2);
-    keep_l[i] = keep && lv[i] < PRT_INF;
-  }
+  for (int i = 0; i < ML; ++i) keep_l[i] = (p[i] != flip_l) && lv[i] < PRT_INF;
 #pragma unroll
-  for (int j = 0; j < MR; ++j) {
-    const int own = (j & 1) ? -r_first : r_first;
-    const int depth = ((j & 1) ? 0 : r_first) + (l_before[j] & 1) + diff;
-    const int before = depth - own;
-    const bool keep = (op == CSG_UNION) ? ((depth != 0) != (before != 0)) : (depth == 2 || before == 2);
-    keep_r[j] = keep && rv[j] < PRT_INF;
-  }
+  for (int j = 0; j < MR; ++j) keep_r[j] = (q[j] != flip_r) && rv[j] < PRT_INF;
   {
     bool touched = true;
     if (!box_implied) {  // wave-uniform
       touched = box_touched(aabb, ray);
     } else {
+      // list entries are finite or +inf, never NaN (leaves map NaN to +inf): v_min / v_max are exact
       double lo = PRT_INF, hi = -PRT_INF;
 #pragma unroll
-      for (int i = 0; i < ML; ++i)
-        if (keep_l[i]) { lo = dmin(lo, lv[i]); hi = dmax(hi, lv[i]); }
+      for (int i = 0; i < ML; ++i) {
+        lo = fmin(lo, keep_l[i] ? lv[i] : PRT_INF);
+        hi = fmax(hi, keep_l[i] ? lv[i] : -PRT_INF);
+      }
 #pragma unroll
-      for (int j = 0; j < MR; ++j)
-        if (keep_r[j]) { lo = dmin(lo, rv[j]); hi = dmax(hi, rv[j]); }
+      for (int j = 0; j < MR; ++j) {
+        lo = fmin(lo, keep_r[j] ? rv[j] : PRT_INF);
+        hi = fmax(hi, keep_r[j] ? rv[j] : -PRT_INF);
+      }
       const bool any = hi >= lo;  // false when nothing survived (lo = +inf, hi = -inf)
       const bool robust = any && lo > -PRT_INF && (hi - lo) > 1e-6 * ((1.0 + fabs(lo)) + fabs(hi));
       if (any && !robust) touched = box_touched(aabb, ray);
@@ -590,19 +593,22 @@ __device__ __forceinline__ void csg_node(int op, int l_base, int r_base, int out
     for (int j = 0; j < MR; ++j) keep_r[j] = keep_r[j] && touched;
   }
   if (is_root) {
+    // nearest positive survivor; ties go to the lower merged rank, and among equal values the merged
+    // order is "left entries by index, then right entries by index" (stable, left first) -- the
+    // order of this scan, so a strict '<' keeps the right one
     double best = PRT_INF;
-    int best_rank = ML + MR, best_id = -1;
+    int best_id = -1;
 #pragma unroll
     for (int i = 0; i < ML; ++i) {
-      const int rank = i + r_before[i];
-      const bool better = keep_l[i] && lv[i] > 0 && (lv[i] < best || (lv[i] == best && rank < best_rank));
-      if (better) { best = lv[i]; best_rank = rank; best_id = lid[i]; }
+      const bool better = keep_l[i] && lv[i] > 0 && lv[i] < best;
+      best = better ? lv[i] : best;
+      best_id = better ? lid[i] : best_id;
     }
 #pragma unroll
     for (int j = 0; j < MR; ++j) {
-      const int rank = j + l_before[j];
-      const bool better = keep_r[j] && rv[j] > 0 && (rv[j] < best || (rv[j] == best && rank < best_rank));
-      if (better) { best = rv[j]; best_rank = rank; best_id = rid[j]; }
+      const bool better = keep_r[j] && rv[j] > 0 && rv[j] < best;
+      best = better ? rv[j] : best;
+      best_id = better ? rid[j] : best_id;
     }
     node_t = best;
     node_prim = best_id;

@@ -954,7 +954,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   }
   __syncthreads();
   unsigned agg_live = 0, agg_carry = 0;
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < PRT_BLOCK / 64; ++w) {
     if (w < wave) { live_rank += s_wave_live[w]; carry_rank += s_wave_carry[w]; }
     agg_live += s_wave_live[w];
     agg_carry += s_wave_carry[w];
@@ -1096,7 +1096,7 @@ k_generation2(SceneDev scene, const double* __restrict__ rays, int64_t ld, doubl
   for (int k = 0; k < R; ++k) {
     live_rank[k] += agg_live;
     carry_rank[k] += agg_carry;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < PRT_BLOCK / 64; ++w) {
       if (w < wave) { live_rank[k] += s_wave_live[k][w]; carry_rank[k] += s_wave_carry[k][w]; }
       agg_live += s_wave_live[k][w];
       agg_carry += s_wave_carry[k][w];

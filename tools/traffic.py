@@ -14,7 +14,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     scale = KNOWN[c] / (cal_kib * 1024)
     vals = []
     for r in csv.DictReader(open(f"{src}/bench_{c}_counter_collection.csv")):
-        if r["Kernel_Name"].startswith("k_generation") and r["Counter_Name"] == c:
+        if "k_generation" in r["Kernel_Name"] and r["Counter_Name"] == c:
             dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             vals.append((float(r["Counter_Value"]), dur))
     real = [v for v, d in vals if d > 20000]  # launches that found rays (the 4th of a batch exits)
