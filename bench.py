@@ -162,13 +162,18 @@ def main():
     if rank == 0:
         from pyrayt_amd.tracer import rows_to_frame
 
-        torch.cuda.synchronize(device)
-        e0 = time.perf_counter()
-        up = torch.from_numpy(rays).to(device)
-        r2, _ = scene.trace(up, limit, flags=args.flags)
-        frame = rows_to_frame(r2)
-        e1 = time.perf_counter()
-        end_to_end = {"ms": (e1 - e0) * 1e3, "rows_per_s": frame.shape[0] / (e1 - e0)}
+        times = []
+        for _ in range(3):  # the first call also page-locks the host staging block
+            torch.cuda.synchronize(device)
+            e0 = time.perf_counter()
+            up = torch.from_numpy(rays).to(device)
+            r2, _ = scene.trace(up, limit, flags=args.flags)
+            frame = rows_to_frame(r2)
+            times.append(time.perf_counter() - e0)
+            n_rows = frame.shape[0]
+            del frame, r2, up
+        end_to_end = {"ms": min(times[1:]) * 1e3, "rows_per_s": n_rows / min(times[1:]),
+                      "first_call_ms": times[0] * 1e3}
 
     if rank != 0:
         if distributed:

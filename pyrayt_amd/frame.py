@@ -76,8 +76,10 @@ class DeviceFrame:
     # --- export -------------------------------------------------------------------------------------
     def to_numpy(self):
         """(R, 15) float64 view of a host copy (one D2H transfer)."""
-        host = self.rows.cpu() if hasattr(self.rows, "cpu") else self.rows
-        return np.asarray(host.contiguous().numpy() if hasattr(host, "numpy") else host).T
+        from . import engine
+
+        rows = self.rows.contiguous() if hasattr(self.rows, "contiguous") else self.rows
+        return engine.to_host(rows).T
 
     def to_pandas(self):
         values = self.to_numpy()
