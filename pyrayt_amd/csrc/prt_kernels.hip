@@ -1036,6 +1036,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   STAMP(7);
 }
 
+#ifdef PRT_EXPERIMENTS  // measured slower than k_generation; not part of the product build
 // Two rays per lane.  A wave's lifetime in k_generation is mostly latency that does not depend
 // on how much arithmetic it carries (step fetches, uniform branches, barriers, the look-back, the
 // load / store round trips) and the VALUs idle about half the time, so a lane that owns two
@@ -1140,6 +1141,7 @@ k_generation2(SceneDev scene, const double* __restrict__ rays, int64_t ld, doubl
     if (!sh[k].ok) atomicExch(&ctrl->error, PRT_ERR_UNTRACABLE);
   }
 }
+#endif  // PRT_EXPERIMENTS
 
 // start of a fused trace: clear the control slots and tile buffer 0
 __global__ void k_fused_init(FusedCtrl* ctrl, GenCtrl* gen, int n_gen_slots,
@@ -1322,7 +1324,9 @@ static int raise_lds_limits() {
   HIP_TRY(hipFuncSetAttribute((const void*)k_hit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_generation<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_generation<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+#ifdef PRT_EXPERIMENTS
   HIP_TRY(hipFuncSetAttribute((const void*)k_generation2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+#endif
   HIP_TRY(hipFuncSetAttribute((const void*)k_intersect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   return PRT_OK;
 }
@@ -1663,8 +1667,10 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
 
   size_t lds_pad = 0;  // experiment: PRT_LDS_PAD=<bytes> lowers occupancy without touching the code
   if (const char* pad_env = getenv("PRT_LDS_PAD")) lds_pad = (size_t)atol(pad_env);
+#ifdef PRT_EXPERIMENTS
   const char* rpl_env = getenv("PRT_RAYS_PER_LANE");
   const bool two_per_lane = rpl_env && rpl_env[0] == '2' && 2 * lds <= kMaxLdsBytes;
+#endif
   GenCtrl* host_gen = c->host_gen + 1;  // slot -1 receives the control header
   bool culls = false;
   for (const DevInstr& in : s->trace_program.code) culls = culls || in.kind == I_BOX;
@@ -1679,17 +1685,19 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
       const double* src = (gg == 0) ? rays : buf[(gg - 1) & 1];
       const int64_t src_ld = (gg == 0) ? ld : n;
       const int relaunch = (gg + 1 != generation_limit) ? 1 : 0;
+#ifdef PRT_EXPERIMENTS
       if (two_per_lane) {
         const unsigned grid2 = (unsigned)((bound + 2 * PRT_BLOCK - 1) / (2 * PRT_BLOCK));
         hipLaunchKernelGGL(k_generation2, dim3(grid2), dim3(PRT_BLOCK), 2 * lds, st, sd, src, src_ld,
                            buf[gg & 1], n, rows_out, rows_cap, ctrl, gen, gg, tiles[gg & 1],
                            tiles[(gg + 1) & 1], (double)(gg + 1), relaunch, ray_offset, keep_absorbed);
-      } else {
-        auto kernel = culls ? k_generation<true> : k_generation<false>;
-        hipLaunchKernelGGL(kernel, dim3(blocks_for(bound)), dim3(PRT_BLOCK), lds + lds_pad, st, sd, src,
-                           src_ld, buf[gg & 1], n, rows_out, rows_cap, ctrl, gen, gg, tiles[gg & 1],
-                           tiles[(gg + 1) & 1], (double)(gg + 1), relaunch, ray_offset, keep_absorbed);
+        continue;
       }
+#endif
+      auto kernel = culls ? k_generation<true> : k_generation<false>;
+      hipLaunchKernelGGL(kernel, dim3(blocks_for(bound)), dim3(PRT_BLOCK), lds + lds_pad, st, sd, src,
+                         src_ld, buf[gg & 1], n, rows_out, rows_cap, ctrl, gen, gg, tiles[gg & 1],
+                         tiles[(gg + 1) & 1], (double)(gg + 1), relaunch, ray_offset, keep_absorbed);
     }
     HIP_TRY(hipEventRecord(c->ev1, st));
     if (g == 0) {  // header + slots 0..batch are contiguous: one copy

@@ -1,0 +1,28 @@
+#!/bin/bash
+# One GPU-box pass that regenerates everything under profiles/<round>/ from the current build:
+#   bench line, rocprofv3 kernel-trace stats of the same command, HBM traffic (PMC, calibrated),
+#   SQ issue/stall counters of k_generation and k_hit, renderer kernel stats.
+# usage (through gpurun): bash tools/refresh_profiles.sh ; then copy gpurun_out/refresh/* into profiles/
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+out=$R/gpurun_out/refresh
+rm -rf $out $R/gpurun_out/traffic $R/gpurun_out/sq; mkdir -p $out
+cd $R
+python3 bench.py > $out/bench.json 2> $out/bench.err
+python3 bench.py --workload config3 --no-cpu-baseline > $out/bench_config3.json 2>> $out/bench.err
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $out/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o render -- python3 $R/tools/render_bench.py --width 640 8192 --cpu-pixels 20000 > $out/render.log 2>&1
+cd $R
+bash tools/traffic.sh > $out/traffic.log 2>&1
+bash tools/sq.sh gen python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+bash tools/sq.sh hit python3 $R/tools/hit_only.py 6 > /dev/null 2>&1
+python3 tools/sq.py gpurun_out/sq gen > $out/sq_counters.txt
+python3 tools/sq.py gpurun_out/sq hit >> $out/sq_counters.txt
+python3 tools/traffic.py gpurun_out/traffic $out/traffic.json > /dev/null
+cp gpurun_out/traffic/bench_FETCH_SIZE_counter_collection.csv $out/k_generation_pmc_FETCH_SIZE.csv
+cp gpurun_out/traffic/bench_WRITE_SIZE_counter_collection.csv $out/k_generation_pmc_WRITE_SIZE.csv
+cp gpurun_out/traffic/cal_FETCH_SIZE_counter_collection.csv $out/calibration_pmc_FETCH_SIZE.csv
+cp gpurun_out/traffic/cal_WRITE_SIZE_counter_collection.csv $out/calibration_pmc_WRITE_SIZE.csv
+ls -la $out | head -40
+tail -1 $out/bench.json | cut -c1-400
