@@ -189,9 +189,13 @@ def main():
     achieved = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     traffic = None
     traffic_file = os.path.join(ROOT, "profiles", "r1", "traffic.json")
-    if os.path.exists(traffic_file) and args.flags == 0 and n == RAYS_PER_GPU:
+    if os.path.exists(traffic_file) and args.flags == 0 and n == RAYS_PER_GPU and args.workload == "config2":
         with open(traffic_file) as fh:
-            traffic = json.load(fh).get("hbm_bytes_per_launch")
+            measured = json.load(fh)
+        # per launch like `achieved`: a repeated trace launches exactly its working generations
+        # (the library sizes the first batch from the previous trace), a first trace one more
+        blind = launches > len(counts) * args.steps
+        traffic = measured.get("hbm_bytes_per_launch" if blind else "hbm_bytes_per_working_launch")
     line = {
         "metric": "ray-surface intersections/sec, 1M-ray biconvex lens",
         "value": value,

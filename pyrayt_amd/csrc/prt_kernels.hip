@@ -50,6 +50,7 @@ static int fail(int code, const std::string& msg) {
 // ------------------------------------------------------------------------------------------------
 // scene
 // ------------------------------------------------------------------------------------------------
+static const int kMaxBatch = 64;  // generations launched between two host looks at the counts
 struct SceneDev {
   const DevPrim* prims;
   const DevInstr* code;
@@ -85,6 +86,7 @@ struct prt_scene {
   std::vector<DeviceCopy> per_device;
   bool has_untracable = false;
   double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int last_generations = 0;  // working generations of the previous trace: sizes the first batch
 };
 
 static int leaves_under(const prt_scene* s, int node) {
@@ -476,7 +478,7 @@ static int on_device(prt_scene* s, int device, DeviceCopy** out) {
       c.component_code.push_back(code);
     }
     HIP_TRY(hipHostMalloc((void**)&c.host_pinned, 8 * sizeof(int64_t), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void**)&c.host_gen, 16 * 64, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&c.host_gen, (kMaxBatch + 4) * 64, hipHostMallocDefault));  // GenCtrl is 64 B
     int rc_lds = raise_lds_limits();
     if (rc_lds) return rc_lds;
     HIP_TRY(hipEventCreate(&c.ev0));
@@ -799,6 +801,7 @@ struct GenCtrl {
   int64_t n_carry;   // rays handed to the next generation
   uint32_t pad[8];
 };
+static_assert(sizeof(GenCtrl) == 64, "host_gen sizing");
 struct FusedCtrl {
   int32_t error;
   int32_t pad;
@@ -1678,7 +1681,12 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
   int g = 0, error = 0;
   bool done = false;
   while (g < generation_limit && !done) {
-    const int batch = std::min(kGenerationBatch, generation_limit - g);
+    // Generations are launched blind, a batch at a time, and the host looks at the counts once per
+    // batch.  A scene traced before most likely runs as many generations as last time: launching
+    // exactly that many first means neither a launch that finds no rays nor a second round trip.
+    int want = kGenerationBatch;
+    if (g == 0 && s->last_generations > 0) want = std::min(s->last_generations, kMaxBatch);
+    const int batch = std::min(want, generation_limit - g);
     HIP_TRY(hipEventRecord(c->ev0, st));
     for (int b = 0; b < batch; ++b) {
       const int gg = g + b;
@@ -1735,6 +1743,7 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
   }
 #endif
   if (error) return trace_error(error);
+  s->last_generations = (int)s->stats[0];
   return total_rows;
 }
 
