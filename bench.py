@@ -217,6 +217,8 @@ def main():
             "rays_per_gpu": n,
             "rows_per_step_per_gpu": rows_per_step,
             "rows_per_generation": counts,
+            # secondary metric of SURVEY.md section 8d: rays alive at generation entry x primitives
+            "primitive_tests_per_s": ray_generations * len(snap.prims) * world / elapsed,
             "trace_flags": args.flags,
             "parallelism": f"ray data-parallel x{world}, no collective in the timed region",
         },
