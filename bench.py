@@ -146,34 +146,41 @@ def main():
     # frame re-assembly (not in the timed region): one all-gather, checked for row count
     gather = None
     if distributed:
-        torch.cuda.synchronize(device)
-        dist.barrier()
-        g0 = time.perf_counter()
-        full, full_counts = pdist.assemble_rows(rows.to(comm_device), counts, limit, dist.group.WORLD, "all")
-        torch.cuda.synchronize(device)
-        dist.barrier()
-        gather_s = time.perf_counter() - g0
-        assert full.shape[1] == int(total_rows_per_step)
-        gather = {"ms": gather_s * 1e3, "rows": int(full.shape[1]),
-                  "GB_into_each_gpu": full.shape[1] * 120 * (world - 1) / world / 1e9}
+        try:  # an extra: its failure must not cost the benchmark line
+            torch.cuda.synchronize(device)
+            dist.barrier()
+            g0 = time.perf_counter()
+            full, full_counts = pdist.assemble_rows(rows.to(comm_device), counts, limit, dist.group.WORLD, "all")
+            torch.cuda.synchronize(device)
+            dist.barrier()
+            gather_s = time.perf_counter() - g0
+            assert full.shape[1] == int(total_rows_per_step)
+            gather = {"ms": gather_s * 1e3, "rows": int(full.shape[1]),
+                      "GB_into_each_gpu": full.shape[1] * 120 * (world - 1) / world / 1e9}
+            del full
+        except Exception as exc:  # noqa: BLE001
+            gather = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     # PCIe-inclusive end-to-end trace() on rank 0 (H2D rays, trace, D2H rows, DataFrame)
     end_to_end = None
     if rank == 0:
         from pyrayt_amd.tracer import rows_to_frame
 
-        times = []
-        for _ in range(3):  # the first call also page-locks the host staging block
-            torch.cuda.synchronize(device)
-            e0 = time.perf_counter()
-            up = torch.from_numpy(rays).to(device)
-            r2, _ = scene.trace(up, limit, flags=args.flags)
-            frame = rows_to_frame(r2)
-            times.append(time.perf_counter() - e0)
-            n_rows = frame.shape[0]
-            del frame, r2, up
-        end_to_end = {"ms": min(times[1:]) * 1e3, "rows_per_s": n_rows / min(times[1:]),
-                      "first_call_ms": times[0] * 1e3}
+        try:
+            times = []
+            for _ in range(3):  # the first call also page-locks the host staging block
+                torch.cuda.synchronize(device)
+                e0 = time.perf_counter()
+                up = torch.from_numpy(rays).to(device)
+                r2, _ = scene.trace(up, limit, flags=args.flags)
+                frame = rows_to_frame(r2)
+                times.append(time.perf_counter() - e0)
+                n_rows = frame.shape[0]
+                del frame, r2, up
+            end_to_end = {"ms": min(times[1:]) * 1e3, "rows_per_s": n_rows / min(times[1:]),
+                          "first_call_ms": times[0] * 1e3}
+        except Exception as exc:  # noqa: BLE001
+            end_to_end = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     if rank != 0:
         if distributed:
