@@ -55,7 +55,7 @@ struct DevInstr {
   int32_t a5;     //                   CSG: right base
   int32_t a6;     //                   CSG: right length
   int32_t a7;     //                   CSG: out base
-  int32_t pad[2]; // CSG: [0] root node of a component, [1] cull box implied (see csg_node); ROOT: [0] == 2 renderer rule
+  int32_t pad[2]; // CSG: [0] root node of a component, [1] cull box implied (see csg_node); LEAF: [0] == 1 skippable right leaf, == 2 a whole component
   int32_t type;   // LEAF: PRIM_*
   double data[18];// LEAF: params[0..5], M^-1 rows 0..2 [6..17]   CSG: cull box [0..5]
 };
@@ -731,7 +731,19 @@ __device__ __forceinline__ void run_step(const DevInstr* in, const Ray8& ray, co
     surface_pair(in->type, in->data, in->data + 6, ray, t0, t1);
 #endif
     const int dst = in->a1;
-    if (dst == OPER_REGA) {
+    if (in->pad[0] == 2) {
+      // the leaf is a whole component (a bare surface): its sorted pair reduces right here to the
+      // component's candidate -- first positive entry, or for the renderers the first entry when
+      // none is positive -- and meets the running minimum; no list, no separate root step
+      const bool pos0 = t0 > 0 && t0 < PRT_INF, pos1 = t1 > 0 && t1 < PRT_INF;
+      double t = pos0 ? t0 : (pos1 ? t1 : PRT_INF);
+      bool hit = pos0 || pos1;
+      if (RENDER && !hit) { t = t0; hit = t0 < PRT_INF; }
+      if (hit && t < best_t) {
+        best_t = t;
+        best_prim = p;
+      }
+    } else if (dst == OPER_REGA) {
       ra.t0 = t0; ra.t1 = t1; ra.prim = p;
     } else if (dst == OPER_REGB) {
       rb.t0 = t0; rb.t1 = t1; rb.prim = p;
@@ -752,7 +764,7 @@ __device__ __forceinline__ void run_step(const DevInstr* in, const Ray8& ray, co
       best_t = t;
       best_prim = prim;
     }
-  } else {  // I_ROOT: a component that is a single surface (its pair sits in REGA)
+  } else {  // I_ROOT: reduce a component's finished list to its candidate (render programs of CSG components)
     const Operand o = {in->a0, in->a1, in->a2};
     double t;
     int prim;

@@ -65,7 +65,7 @@ struct Program {
 
 struct DeviceCopy {
   DevPrim* prims = nullptr;
-  DevInstr* trace_code = nullptr;               // all components, each ending in I_ROOT
+  DevInstr* trace_code = nullptr;               // all components, each reduced to its candidate hit
   DevInstr* render_code = nullptr;              // same with the renderers' selection rule
   std::vector<DevInstr*> component_code;        // one program per component, no I_ROOT
   int64_t* host_pinned = nullptr;               // 8 x int64 pinned staging
@@ -313,7 +313,9 @@ static Operand compile_component(const prt_scene* s, int root_node, std::vector<
     res = c.leaf(root_node, OPER_REGA, 0);
   else
     res = c.emit(root_node, 0);
-  if (root_rule == ROOT_TRACE && code.size() > from && code.back().kind == I_CSG) {
+  if (root_rule != ROOT_NONE && s->nodes[root_node].op == PRT_NODE_LEAF) {
+    code.back().pad[0] = 2;  // a bare surface: the leaf step itself yields the component's candidate
+  } else if (root_rule == ROOT_TRACE && code.size() > from && code.back().kind == I_CSG) {
     code.back().pad[0] = 1;  // the node reduces straight to its nearest positive survivor
   } else if (root_rule != ROOT_NONE) {
     // the renderers may pick a non-positive entry, so their lists are always materialised

@@ -194,6 +194,7 @@ def test_compiled_programs_carry_cull_steps_only_for_three_or_more_components():
         info = ds.info()
         ds.close()
         assert (info["components"], info["primitives"], info["cull_steps"]) == (components, prims, culls), name
-        # one step per leaf, one per CSG node, a root step per single-surface component, + culls
-        assert info["trace_steps"] == info["render_steps"] - components + culls + sum(
-            1 for p in parts if not hasattr(p, "children"))
+        # one step per leaf and per CSG node (+ culls); render programs add a root step per CSG
+        # component, bare surfaces reduce inside their own leaf step
+        assert info["trace_steps"] == info["render_steps"] - sum(
+            1 for p in parts if hasattr(p, "children")) + culls
