@@ -5,7 +5,7 @@ nodes -- plus the second consumer of the intersect kernels (SURVEY.md section 8f
 orthographic camera, Gooch materials and the two renderers of ``tinygfx/g3d/renderers.py``.
 """
 from . import shapes
-from .shapes import Point, Vector, bundle_of_rays
+from .shapes import HomogeneousCoordinate, Point, Ray, Vector, bundle_of_rays, bundle_rays
 from . import materials
 from . import objects
 from .objects import (
@@ -26,7 +26,7 @@ from . import csg
 from . import renderers
 
 __all__ = [
-    "BLACK", "CountedObject", "Cuboid", "Cylinder", "Intersectable", "ObjectGroup", "OrthographicCamera",
-    "Paraboloid", "Point", "Sphere", "TracerSurface", "Vector", "WorldObject", "XYPlane",
-    "bundle_of_rays", "csg", "materials", "objects", "renderers", "shapes",
+    "BLACK", "CountedObject", "Cuboid", "Cylinder", "HomogeneousCoordinate", "Intersectable", "ObjectGroup",
+    "OrthographicCamera", "Paraboloid", "Point", "Ray", "Sphere", "TracerSurface", "Vector", "WorldObject",
+    "XYPlane", "bundle_of_rays", "bundle_rays", "csg", "materials", "objects", "renderers", "shapes",
 ]

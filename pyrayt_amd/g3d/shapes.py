@@ -22,14 +22,67 @@ def bundle_of_rays(n_rays):
     return block
 
 
-def Point(x=0.0, y=0.0, z=0.0):
-    """Homogeneous point (w = 1), cf. primitives.py:85-89."""
-    return np.array((x, y, z, 1.0), dtype=float)
+def bundle_rays(rays):
+    """Stack single (2,4) rays into a (2,4,n) block (primitives.py:31-32)."""
+    return np.stack(rays, axis=2)
 
 
-def Vector(x=0.0, y=0.0, z=0.0):
-    """Homogeneous vector (w = 0), cf. primitives.py:92-94."""
-    return np.array((x, y, z, 0.0), dtype=float)
+def _named(index):
+    return property(lambda self: self[index], lambda self, value: self.__setitem__(index, value))
+
+
+class HomogeneousCoordinate(np.ndarray):
+    """A float64 4-vector with named x / y / z / w components (primitives.py:35-82)."""
+
+    def __new__(cls, x=0.0, y=0.0, z=0.0, w=0.0):
+        return np.array((x, y, z, w), dtype=float).view(cls)
+
+    x, y, z, w = _named(0), _named(1), _named(2), _named(3)
+
+    def normalize(self):
+        """Scale the xyz part to unit length, in place."""
+        self[:-1] /= np.linalg.norm(self[:-1])
+        return self
+
+
+class Point(HomogeneousCoordinate):
+    """Homogeneous point, w = 1 (primitives.py:85-89)."""
+
+    def __new__(cls, x=0.0, y=0.0, z=0.0, *args, **kwargs):
+        return super().__new__(cls, x, y, z, 1.0)
+
+
+class Vector(HomogeneousCoordinate):
+    """Homogeneous vector, w = 0 (primitives.py:92-94)."""
+
+    def __new__(cls, x=0.0, y=0.0, z=0.0, *args, **kwargs):
+        return super().__new__(cls, x, y, z, 0.0)
+
+
+class Ray(np.ndarray):
+    """One ray as a (2,4) block: row 0 the origin, row 1 the direction (primitives.py:97-122)."""
+
+    def __new__(cls, origin=None, direction=None):
+        ray = np.zeros((2, 4), dtype=float).view(cls)
+        ray[0] = Point() if origin is None else origin
+        ray[1] = Vector(1, 0, 0) if direction is None else direction
+        return ray
+
+    @property
+    def origin(self):
+        return self[0].view(HomogeneousCoordinate)
+
+    @origin.setter
+    def origin(self, value):
+        self[0] = value
+
+    @property
+    def direction(self):
+        return self[1].view(HomogeneousCoordinate)
+
+    @direction.setter
+    def direction(self, value):
+        self[1] = value
 
 
 def box_corners(lo, hi):

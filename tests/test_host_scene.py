@@ -198,3 +198,24 @@ def test_compiled_programs_carry_cull_steps_only_for_three_or_more_components():
         # component, bare surfaces reduce inside their own leaf step
         assert info["trace_steps"] == info["render_steps"] - sum(
             1 for p in parts if hasattr(p, "children")) + culls
+
+
+def test_coordinate_helpers_like_upstream():
+    """tinygfx/g3d/primitives.py:18-122: bundle_of_rays / bundle_rays, Point / Vector / Ray."""
+    import numpy as np
+    import pyrayt_amd.g3d as cg
+
+    p, v = cg.Point(1, 2, 3), cg.Vector(0, 3, 4)
+    assert (p.x, p.y, p.z, p.w) == (1, 2, 3, 1) and v.w == 0 and p.dtype == np.float64
+    assert isinstance(p, cg.HomogeneousCoordinate) and isinstance(p, np.ndarray)
+    assert np.allclose(v.normalize(), (0, 0.6, 0.8, 0)) and v.w == 0
+    p.z = 9
+    assert p[2] == 9
+    ray = cg.Ray()
+    assert np.array_equal(ray, ((0, 0, 0, 1), (1, 0, 0, 0)))
+    ray.direction = cg.Vector(0, 0, 1)
+    ray.origin = cg.Point(1, 1, 1)
+    assert ray.origin.x == 1 and ray.direction.z == 1
+    block = cg.bundle_rays([ray, cg.Ray()])
+    assert block.shape == (2, 4, 2) and np.array_equal(block[:, :, 0], ray)
+    assert np.array_equal(cg.bundle_of_rays(3)[0], np.array([[0, 0, 0], [0, 0, 0], [0, 0, 0], [1, 1, 1]]))
