@@ -1,0 +1,465 @@
+// prt_scene.hpp -- host side of libprt_hip: error plumbing, the scene object behind prt_scene*,
+// the scene compiler (component trees -> linear step programs with LDS slot allocation, cull
+// boxes, root rules) and the per-device upload.  Included by prt_kernels.hip (one translation
+// unit: the kernels and the C-ABI follow there).
+#pragma once
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_error;
+
+static int fail(int code, const std::string& msg) {
+  g_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(PRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// scene
+// ------------------------------------------------------------------------------------------------
+static const int kMaxBatch = 64;  // generations launched between two host looks at the counts
+struct SceneDev {
+  const DevPrim* prims;
+  const DevInstr* code;
+  int n_instr;
+  int lds_slots;
+};
+
+struct Program {
+  std::vector<DevInstr> code;
+  int lds_slots = 0;
+};
+
+struct DeviceCopy {
+  DevPrim* prims = nullptr;
+  DevInstr* trace_code = nullptr;               // all components, each reduced to its candidate hit
+  DevInstr* render_code = nullptr;              // same with the renderers' selection rule
+  std::vector<DevInstr*> component_code;        // one program per component, no I_ROOT
+  int64_t* host_pinned = nullptr;               // 8 x int64 pinned staging
+  struct GenCtrl* host_gen = nullptr;           // pinned read-back of one batch of slots
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct prt_scene {
+  std::vector<prt_prim> prims;
+  std::vector<prt_node> nodes;
+  std::vector<int32_t> roots;
+  std::vector<prt_material> mats;
+  std::vector<DevPrim> dev_prims;
+  Program trace_program;
+  Program render_program;
+  std::vector<Program> component_programs;
+  std::vector<Operand> component_result;        // where each component program leaves its list
+  std::vector<DeviceCopy> per_device;
+  bool has_untracable = false;
+  double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int last_generations = 0;  // working generations of the previous trace: sizes the first batch
+};
+
+static int leaves_under(const prt_scene* s, int node) {
+  const prt_node& n = s->nodes[node];
+  if (n.op == PRT_NODE_LEAF) return 1;
+  return leaves_under(s, n.left) + leaves_under(s, n.right);
+}
+
+// Linearise one component (post-order) and place its hit lists in LDS.
+//
+// Slots are handed out downwards from a ceiling (slot numbers are negative while compiling and
+// shifted afterwards).  A leaf that feeds the CSG step right after it stays in registers
+// (REGA / REGB); every CSG result goes to LDS.  With a register operand of length 2 and the
+// other operand at [b, b+m) the result is written to [b-2, b+m): the merge writes slot
+// b-2+k only after it has consumed k-2 entries of that operand, so it never overwrites an
+// unread entry, and a chain of k leaves needs just 2k slots.  Two LDS operands keep the right
+// one a further len(right) slots down so the same argument holds for the left one.
+struct Compiler {
+  const prt_scene* s;
+  std::vector<DevInstr>& out;
+  int lowest = 0;
+  bool positive_only = false;  // trace programs: only positive hits are ever looked at
+
+  static DevInstr blank(int kind) {
+    DevInstr in;
+    std::memset(&in, 0, sizeof(in));
+    in.kind = kind;
+    return in;
+  }
+
+  Operand leaf(int node, int mode, int ceiling) {
+    DevInstr in = blank(I_LEAF);
+    in.a0 = s->nodes[node].prim;
+    in.a1 = mode;
+    const prt_prim& pr = s->prims[in.a0];
+    in.type = pr.type;
+    for (int k = 0; k < 6; ++k) in.data[k] = pr.params[k];
+    for (int k = 0; k < 12; ++k) in.data[6 + k] = pr.minv[k];  // rows 0..2 of M^-1
+    Operand o = {mode, 0, 2};
+    if (mode == OPER_LDS) {
+      o.base = ceiling - 2;
+      in.a2 = o.base;
+      lowest = std::min(lowest, o.base);
+    }
+    out.push_back(in);
+    return o;
+  }
+
+  // does the upstream cull box of `node` provably contain the node's solid?  (see csg_node)
+  bool box_contains_solid(int node) const {
+    const prt_node& n = s->nodes[node];
+    if (n.op == PRT_NODE_LEAF) return true;
+    if (n.op == PRT_NODE_INTERSECT) return box_contains_solid(n.left) && box_contains_solid(n.right);
+    if (n.op == PRT_NODE_DIFFERENCE) return box_contains_solid(n.left);
+    return false;  // UNION of disjoint operands keeps only the first operand's span (csg.py:98-109)
+  }
+
+  Operand emit(int node, int ceiling) {
+    const prt_node& n = s->nodes[node];
+    if (n.op == PRT_NODE_LEAF) return leaf(node, OPER_LDS, ceiling);
+    const bool l_leaf = s->nodes[n.left].op == PRT_NODE_LEAF;
+    const bool r_leaf = s->nodes[n.right].op == PRT_NODE_LEAF;
+    Operand L, R;
+    int base;
+    if (l_leaf && r_leaf) {
+      L = leaf(n.left, OPER_REGA, 0);
+      R = leaf(n.right, OPER_REGB, 0);
+      base = ceiling - 4;
+    } else if (r_leaf) {
+      L = emit(n.left, ceiling);
+      R = leaf(n.right, OPER_REGB, 0);
+      base = L.base - 2;
+    } else if (l_leaf) {
+      R = emit(n.right, ceiling);  // evaluation order of pure children is free
+      L = leaf(n.left, OPER_REGA, 0);
+      base = R.base - 2;
+    } else {
+      L = emit(n.left, ceiling);
+      const int m_r = 2 * leaves_under(s, n.right);
+      R = emit(n.right, L.base - m_r);
+      base = L.base - m_r;
+    }
+    // INTERSECT / DIFFERENCE results lie inside the left solid: when the left list has no positive
+    // entry the node cannot contribute a positive hit whatever the right operand is (entries that
+    // are not positive come in enter/exit pairs and leave the depth seen by positive entries
+    // unchanged), so a right leaf evaluated just before the node is marked skippable.
+    if (positive_only && r_leaf && !out.empty() && out.back().kind == I_LEAF && out.back().a1 == OPER_REGB &&
+        (n.op == PRT_NODE_INTERSECT || n.op == PRT_NODE_DIFFERENCE)) {
+      DevInstr& rl = out.back();
+      rl.pad[0] = 1;
+      rl.a3 = L.mode; rl.a4 = L.base; rl.a5 = L.len;
+    }
+    DevInstr in = blank(I_CSG);
+    in.pad[1] = box_contains_solid(node) ? 1 : 0;
+    in.a0 = n.op;
+    in.a1 = L.mode; in.a2 = L.base; in.a3 = L.len;
+    in.a4 = R.mode; in.a5 = R.base; in.a6 = R.len;
+    in.a7 = base;
+    for (int k = 0; k < 6; ++k) in.data[k] = n.aabb[k];
+    out.push_back(in);
+    lowest = std::min(lowest, base);
+    return Operand{OPER_LDS, base, L.len + R.len};
+  }
+};
+
+static void shift_slots(std::vector<DevInstr>& code, size_t from, int shift) {
+  for (size_t k = from; k < code.size(); ++k) {
+    DevInstr& in = code[k];
+    if (in.kind == I_LEAF && in.a1 == OPER_LDS) in.a2 += shift;
+    if (in.kind == I_LEAF && in.pad[0] == 1 && in.a3 == OPER_LDS) in.a4 += shift;
+    if (in.kind == I_CSG) {
+      if (in.a1 == OPER_LDS) in.a2 += shift;
+      if (in.a4 == OPER_LDS) in.a5 += shift;
+      in.a7 += shift;
+    }
+    if (in.kind == I_ROOT && in.a0 == OPER_LDS) in.a1 += shift;
+  }
+}
+
+// compile component `root_node`; returns where its result list ends up
+// ---- world-space bounds of a component's leaf surfaces (for the I_BOX cull step) ---------------
+static bool invert4(const double* m, double* out) {
+  double a[4][8];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) { a[r][c] = m[4 * r + c]; a[r][4 + c] = r == c ? 1.0 : 0.0; }
+  for (int col = 0; col < 4; ++col) {
+    int piv = col;
+    for (int r = col + 1; r < 4; ++r) if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
+    if (!(std::fabs(a[piv][col]) > 1e-300)) return false;
+    for (int c = 0; c < 8; ++c) std::swap(a[col][c], a[piv][c]);
+    const double inv = 1.0 / a[col][col];
+    for (int c = 0; c < 8; ++c) a[col][c] *= inv;
+    for (int r = 0; r < 4; ++r) {
+      if (r == col) continue;
+      const double f = a[r][col];
+      for (int c = 0; c < 8; ++c) a[r][c] -= f * a[col][c];
+    }
+  }
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out[4 * r + c] = a[r][4 + c];
+  return true;
+}
+
+// object-space bounds of a primitive: the extents its intersect routine clips to
+static bool prim_bounds(const prt_prim& p, double lo[3], double hi[3]) {
+  const double* q = p.params;
+  switch (p.type) {
+    case PRT_PRIM_SPHERE: { const double r = std::fabs(q[0]); for (int k = 0; k < 3; ++k) { lo[k] = -r; hi[k] = r; } } return true;
+    case PRT_PRIM_CYLINDER: { const double r = std::fabs(q[0]); lo[0] = lo[1] = -r; hi[0] = hi[1] = r;
+      lo[2] = std::min(q[1], q[2]); hi[2] = std::max(q[1], q[2]); } return true;
+    case PRT_PRIM_PLANE: lo[0] = -std::fabs(q[0]) / 2; hi[0] = std::fabs(q[0]) / 2; lo[1] = -std::fabs(q[1]) / 2;
+      hi[1] = std::fabs(q[1]) / 2; lo[2] = hi[2] = 0.0; return true;
+    case PRT_PRIM_CUBE: for (int k = 0; k < 3; ++k) { lo[k] = std::min(q[2 * k], q[2 * k + 1]); hi[k] = std::max(q[2 * k], q[2 * k + 1]); } return true;
+    case PRT_PRIM_PARABOLOID: { if (!(q[0] > 0) || !(q[1] > 0)) return false; const double rim = std::sqrt(4 * q[0] * q[1]);
+      lo[0] = lo[1] = -rim; hi[0] = hi[1] = rim; lo[2] = 0.0; hi[2] = q[1]; } return true;
+  }
+  return false;
+}
+
+// World-space box (xmin,xmax,ymin,ymax,zmin,zmax) of the solid of `node`: a leaf's is the box of
+// its transformed object-space corners; A&B lies in both operands' boxes, A-B in A's, A|B in their
+// union.  Every entry a node's hit list keeps is a parameter at which the ray crosses the boundary
+// of that solid (array_csg keeps exactly the depth changes into and out of "inside"), hence a point
+// of this box -- which, unlike upstream's own cull box (csg.py:93-116), is only ever used to skip
+// work that cannot matter, never to change a result.
+static bool solid_bounds(const prt_scene* s, int node, double* box) {
+  const prt_node& n = s->nodes[node];
+  if (n.op != PRT_NODE_LEAF) {
+    double l[6], r[6];
+    if (!solid_bounds(s, n.left, l)) return false;
+    if (n.op == PRT_NODE_DIFFERENCE) { std::memcpy(box, l, sizeof(l)); return true; }
+    if (!solid_bounds(s, n.right, r)) return false;
+    for (int k = 0; k < 3; ++k) {
+      const bool both = n.op == PRT_NODE_INTERSECT;
+      box[2 * k] = both ? std::max(l[2 * k], r[2 * k]) : std::min(l[2 * k], r[2 * k]);
+      box[2 * k + 1] = both ? std::min(l[2 * k + 1], r[2 * k + 1]) : std::max(l[2 * k + 1], r[2 * k + 1]);
+    }
+    return true;
+  }
+  const prt_prim& p = s->prims[n.prim];
+  double lo[3], hi[3], world[16];
+  if (!prim_bounds(p, lo, hi) || !invert4(p.minv, world)) return false;
+  for (int k = 0; k < 3; ++k) { box[2 * k] = HUGE_VAL; box[2 * k + 1] = -HUGE_VAL; }
+  for (int corner = 0; corner < 8; ++corner) {
+    const double v[3] = {(corner & 1) ? hi[0] : lo[0], (corner & 2) ? hi[1] : lo[1], (corner & 4) ? hi[2] : lo[2]};
+    const double w = world[12] * v[0] + world[13] * v[1] + world[14] * v[2] + world[15];
+    for (int k = 0; k < 3; ++k) {
+      const double x = (world[4 * k] * v[0] + world[4 * k + 1] * v[1] + world[4 * k + 2] * v[2] + world[4 * k + 3]) / w;
+      if (!std::isfinite(x)) return false;
+      box[2 * k] = std::min(box[2 * k], x);
+      box[2 * k + 1] = std::max(box[2 * k + 1], x);
+    }
+  }
+  return true;
+}
+
+enum { ROOT_NONE = 0, ROOT_TRACE = 1, ROOT_RENDER = 2 };
+static Operand compile_component(const prt_scene* s, int root_node, std::vector<DevInstr>& code,
+                                 int root_rule, int* slots) {
+  // a scene of several components gets a cull step in front of each: most rays can reach only one
+  // or two of them (see may_reach); with one or two components the test would cost more than it saves
+  size_t box_at = (size_t)-1;
+  static const bool cull_off = std::getenv("PRT_NO_CULL") != nullptr;  // experiment knob
+  if (root_rule == ROOT_TRACE && s->roots.size() >= 3 && !cull_off) {
+    DevInstr in = Compiler::blank(I_BOX);
+    double* box = in.data;
+    if (solid_bounds(s, root_node, box)) {
+      double diag = 0, reach = 0;
+      for (int k = 0; k < 3; ++k) {
+        const double side = std::max(0.0, box[2 * k + 1] - box[2 * k]);  // an empty overlap has no extent
+        diag += side * side;
+        reach = std::max(reach, std::max(std::fabs(box[2 * k]), std::fabs(box[2 * k + 1])));
+      }
+      const double pad = 1e-3 * std::sqrt(diag) + 1e-9 * reach + 1e-12;
+      for (int k = 0; k < 3; ++k) { box[2 * k] -= pad; box[2 * k + 1] += pad; }
+      box_at = code.size();
+      code.push_back(in);
+    }
+  }
+  const size_t from = code.size();
+  Compiler c{s, code};
+  c.positive_only = root_rule == ROOT_TRACE;
+  Operand res;
+  if (s->nodes[root_node].op == PRT_NODE_LEAF)
+    res = c.leaf(root_node, OPER_REGA, 0);
+  else
+    res = c.emit(root_node, 0);
+  if (root_rule != ROOT_NONE && s->nodes[root_node].op == PRT_NODE_LEAF) {
+    code.back().pad[0] = 2;  // a bare surface: the leaf step itself yields the component's candidate
+  } else if (root_rule == ROOT_TRACE && code.size() > from && code.back().kind == I_CSG) {
+    code.back().pad[0] = 1;  // the node reduces straight to its nearest positive survivor
+  } else if (root_rule != ROOT_NONE) {
+    // the renderers may pick a non-positive entry, so their lists are always materialised
+    DevInstr in = Compiler::blank(I_ROOT);
+    in.a0 = res.mode; in.a1 = res.base; in.a2 = res.len;
+    in.pad[0] = root_rule == ROOT_RENDER ? 2 : 0;
+    code.push_back(in);
+  }
+  if (box_at != (size_t)-1) code[box_at].a0 = (int)(code.size() - from);  // steps to jump over
+  const int shift = -c.lowest;
+  shift_slots(code, from, shift);
+  if (res.mode == OPER_LDS) res.base += shift;
+  *slots = std::max(*slots, shift);
+  return res;
+}
+
+static int validate_tree(const prt_scene* s, int node, int depth, std::vector<char>& seen) {
+  if (node < 0 || node >= (int)s->nodes.size() || depth > 64 || seen[node]) return PRT_ERR_SCENE;
+  seen[node] = 1;
+  const prt_node& n = s->nodes[node];
+  if (n.op == PRT_NODE_LEAF) {
+    if (n.prim < 0 || n.prim >= (int)s->prims.size()) return PRT_ERR_SCENE;
+    return PRT_OK;
+  }
+  if (n.op < PRT_NODE_UNION || n.op > PRT_NODE_DIFFERENCE) return PRT_ERR_SCENE;
+  int rc = validate_tree(s, n.left, depth + 1, seen);
+  if (rc) return rc;
+  return validate_tree(s, n.right, depth + 1, seen);
+}
+
+static const size_t kMaxLdsBytes = 150 * 1024;  // one workgroup per CU at the very most (160 KiB LDS)
+
+extern "C" int prt_scene_create(const prt_prim* prims, int n_prims, const prt_node* nodes,
+                                int n_nodes, const int32_t* roots, int n_roots,
+                                const prt_material* mats, int n_mats, prt_scene** out) {
+  if (!out) return fail(PRT_ERR_ARG, "out is null");
+  *out = nullptr;
+  if (n_prims < 0 || n_nodes < 0 || n_roots < 0 || n_mats < 0 ||
+      (n_prims && !prims) || (n_nodes && !nodes) || (n_roots && !roots) || (n_mats && !mats))
+    return fail(PRT_ERR_ARG, "null array with non-zero count");
+  prt_scene* s = new prt_scene();
+  s->prims.assign(prims, prims + n_prims);
+  s->nodes.assign(nodes, nodes + n_nodes);
+  s->roots.assign(roots, roots + n_roots);
+  s->mats.assign(mats, mats + n_mats);
+  std::vector<char> seen(n_nodes, 0);
+  for (int r : s->roots) {
+    if (validate_tree(s, r, 0, seen) != PRT_OK) {
+      delete s;
+      return fail(PRT_ERR_SCENE, "malformed component tree (bad index, cycle, shared node or op)");
+    }
+  }
+  for (const prt_prim& p : s->prims) {
+    if (p.type < PRT_PRIM_SPHERE || p.type > PRT_PRIM_PARABOLOID || p.material < 0 ||
+        p.material >= n_mats) {
+      delete s;
+      return fail(PRT_ERR_SCENE, "primitive with unknown type or material index");
+    }
+    const prt_material& m = s->mats[p.material];
+    if (m.kind < PRT_MAT_NONE || m.kind > PRT_MAT_SELLMEIER) {
+      delete s;
+      return fail(PRT_ERR_SCENE, "unknown material kind");
+    }
+    DevPrim d;
+    std::memset(&d, 0, sizeof(d));
+    std::memcpy(d.minv, p.minv, sizeof(d.minv));
+    std::memcpy(d.params, p.params, sizeof(d.params));
+    std::memcpy(d.coef, m.coef, sizeof(d.coef));
+    d.surface_id = (double)p.surface_id;
+    d.type = p.type;
+    d.mat_kind = m.kind;
+    d.normal_scale = p.normal_scale < 0 ? -1 : 1;
+    if (m.kind == PRT_MAT_NONE) s->has_untracable = true;
+    s->dev_prims.push_back(d);
+  }
+  for (int r : s->roots) {
+    compile_component(s, r, s->trace_program.code, ROOT_TRACE, &s->trace_program.lds_slots);
+    compile_component(s, r, s->render_program.code, ROOT_RENDER, &s->render_program.lds_slots);
+    Program p;
+    Operand res = compile_component(s, r, p.code, ROOT_NONE, &p.lds_slots);
+    s->component_programs.push_back(p);
+    s->component_result.push_back(res);
+  }
+  const size_t lds = (size_t)std::max(s->trace_program.lds_slots, s->render_program.lds_slots) * PRT_BLOCK * 12;
+  if (lds > kMaxLdsBytes) {
+    delete s;
+    return fail(PRT_ERR_SCENE, "a component has too many surfaces for the per-lane LDS hit lists");
+  }
+  *out = s;
+  return PRT_OK;
+}
+
+extern "C" void prt_scene_destroy(prt_scene* s) {
+  if (!s) return;
+  for (size_t d = 0; d < s->per_device.size(); ++d) {
+    DeviceCopy& c = s->per_device[d];
+    if (!c.prims && !c.trace_code) continue;
+    (void)hipSetDevice((int)d);
+    (void)hipFree(c.prims);
+    (void)hipFree(c.trace_code);
+    (void)hipFree(c.render_code);
+    for (DevInstr* p : c.component_code) (void)hipFree(p);
+    if (c.host_pinned) (void)hipHostFree(c.host_pinned);
+    if (c.host_gen) (void)hipHostFree(c.host_gen);
+    if (c.ev0) (void)hipEventDestroy(c.ev0);
+    if (c.ev1) (void)hipEventDestroy(c.ev1);
+  }
+  delete s;
+}
+
+extern "C" int prt_scene_info(const prt_scene* s, int64_t* out8) {
+  if (!s || !out8) return fail(PRT_ERR_ARG, "null argument");
+  int64_t culls = 0;
+  for (const DevInstr& in : s->trace_program.code) culls += in.kind == I_BOX ? 1 : 0;
+  out8[0] = (int64_t)s->prims.size();
+  out8[1] = (int64_t)s->roots.size();
+  out8[2] = (int64_t)s->trace_program.code.size();
+  out8[3] = s->trace_program.lds_slots;
+  out8[4] = culls;
+  out8[5] = (int64_t)s->render_program.code.size();
+  out8[6] = s->render_program.lds_slots;
+  out8[7] = 0;
+  return PRT_OK;
+}
+
+extern "C" int prt_scene_component_rows(const prt_scene* s, int root) {
+  if (!s || root < 0 || root >= (int)s->roots.size()) return fail(PRT_ERR_ARG, "bad component index");
+  return 2 * leaves_under(s, s->roots[root]);
+}
+
+template <typename T>
+static int upload(T** dst, const std::vector<T>& src) {
+  *dst = nullptr;
+  const size_t bytes = std::max<size_t>(1, src.size()) * sizeof(T);
+  HIP_TRY(hipMalloc((void**)dst, bytes));
+  if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return PRT_OK;
+}
+
+static int raise_lds_limits();  // defined after the kernels
+
+// make sure the scene tables exist on `device` and make it current
+static int on_device(prt_scene* s, int device, DeviceCopy** out) {
+  if (!s) return fail(PRT_ERR_ARG, "scene is null");
+  int count = 0;
+  HIP_TRY(hipGetDeviceCount(&count));
+  if (device < 0 || device >= count) return fail(PRT_ERR_ARG, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  if ((int)s->per_device.size() <= device) s->per_device.resize(device + 1);
+  DeviceCopy& c = s->per_device[device];
+  if (!c.prims) {
+    int rc = upload(&c.prims, s->dev_prims);
+    if (rc) return rc;
+    rc = upload(&c.trace_code, s->trace_program.code);
+    if (rc) return rc;
+    rc = upload(&c.render_code, s->render_program.code);
+    if (rc) return rc;
+    for (const Program& p : s->component_programs) {
+      DevInstr* code = nullptr;
+      rc = upload(&code, p.code);
+      if (rc) return rc;
+      c.component_code.push_back(code);
+    }
+    HIP_TRY(hipHostMalloc((void**)&c.host_pinned, 8 * sizeof(int64_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&c.host_gen, (kMaxBatch + 4) * 64, hipHostMallocDefault));  // GenCtrl is 64 B
+    int rc_lds = raise_lds_limits();
+    if (rc_lds) return rc_lds;
+    HIP_TRY(hipEventCreate(&c.ev0));
+    HIP_TRY(hipEventCreate(&c.ev1));
+  }
+  *out = &c;
+  return PRT_OK;
+}
+
