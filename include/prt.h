@@ -282,6 +282,37 @@ int64_t prt_edge_workspace_bytes(int64_t h_pixels, int64_t v_pixels);
 int prt_edge_canvas(int device, const int64_t* surf, int64_t h_pixels, int64_t v_pixels,
                     int rings, double* rgba_out, void* workspace, void* stream);
 
+/* ---- tinygfx/g3d/operations.py as functions -------------
+ * The vector helpers the primitives and materials are written with, callable on their own like
+ * upstream's (`cg.reflect`, `cg.refract`, ...).  Column vectors: (rows, n) blocks with leading
+ * dimension ld, rows in 1..4 (homogeneous 4-vectors upstream). */
+
+/* reflect(vectors, normals) (operations.py:86-107): out = v - 2 n (v.n) */
+int prt_reflect(int device, const double* vectors, const double* normals, int rows, int64_t n,
+                int64_t ld, double* out, int64_t ld_out, void* stream);
+
+/* refract(vectors, normals, n1, n2, n_global) (operations.py:110-162).  `vectors` is normalised
+ * IN PLACE, as upstream does (:125); n1, n2: device (n) per-ray indices; out: refracted (or
+ * totally reflected) unit directions; index_out (n): n2 (n_global when leaving) or n1 on TIR. */
+int prt_refract(int device, double* vectors, const double* normals, const double* n1,
+                const double* n2, double n_global, int rows, int64_t n, int64_t ld, double* out,
+                int64_t ld_out, double* index_out, void* stream);
+
+/* binomial_root(a, b, c) (operations.py:28-63) -> roots_out (2, n): the degenerate branches of
+ * the reference included (|a| <= 1e-8 linear, then |b| <= 1e-8 -> +-inf by the sign of c). */
+int prt_binomial_root(int device, const double* a, const double* b, const double* c, int64_t n,
+                      double* roots_out, int64_t ld_out, void* stream);
+
+/* smallest_positive_root(a, b, c) (operations.py:4-25) -> out (n), +inf where there is none */
+int prt_smallest_positive_root(int device, const double* a, const double* b, const double* c,
+                               int64_t n, double* out, void* stream);
+
+/* element_wise_dot(m1, m2, axis) (operations.py:66-83) in strided form:
+ * out[o] = sum_{r < reduce_len} m1[o*out_stride + r*reduce_stride] * m2[same], o < out_len.
+ * axis 0 of a (k, n) block: reduce_len k, reduce_stride ld, out_len n, out_stride 1. */
+int prt_dot(int device, const double* m1, const double* m2, int64_t reduce_len,
+            int64_t reduce_stride, int64_t out_len, int64_t out_stride, double* out, void* stream);
+
 /* error codes */
 #define PRT_OK 0
 #define PRT_ERR_ARG (-1)

@@ -319,6 +319,49 @@ __device__ __forceinline__ double glass_index(const DevPrim* __restrict__ p, dou
               (k[2] * w2) / (w2 - k[5]));
 }
 
+// operations.reflect (operations.py:104-107): v - (2 n) (v.n), in place
+__device__ __forceinline__ void reflect4(double& dx, double& dy, double& dz, double& dw, double nx,
+                                         double ny, double nz, double nw) {
+  const double dot = ((dx * nx + dy * ny) + dz * nz) + dw * nw;
+  dx = dx - (2 * nx) * dot;
+  dy = dy - (2 * ny) * dot;
+  dz = dz - (2 * nz) * dot;
+  dw = dw - (2 * nw) * dot;
+}
+
+// operations.refract (operations.py:110-162) for a direction v that is already normalised
+// (:125): exit detection by the sign of v.n, vector Snell with the total-internal-reflection
+// fallback, renormalisation, index update.  n1 = index the ray travels in, n2 = index of the
+// medium behind the surface, n_global = index used instead of n2 when the ray is leaving.
+__device__ __forceinline__ void refract4(double vx, double vy, double vz, double vw, double nx,
+                                         double ny, double nz, double nw, double n1, double n2_in,
+                                         double n_global, double& ox, double& oy, double& oz,
+                                         double& ow, double& index_out) {
+  const double cos_p = ((vx * nx + vy * ny) + vz * nz) + vw * nw;
+  const double cos_n = ((vx * -nx + vy * -ny) + vz * -nz) + vw * -nw;
+  const bool leaving = cos_p > 0;
+  const double n2 = leaving ? n_global : n2_in;
+  const double mx = leaving ? -nx : nx, my = leaving ? -ny : ny, mz = leaving ? -nz : nz,
+               mw = leaving ? -nw : nw;
+  const double r = n1 / n2;
+  const double cos1 = leaving ? cos_p : cos_n;
+  const double radicand = 1 - (r * r) * (1 - cos1 * cos1);
+  const double cos2 = sqrt(dmax(0.0, radicand));
+  double ux, uy, uz, uw;
+  if (radicand > 0) {
+    const double k = r * cos1 - cos2;
+    ux = r * vx + k * mx; uy = r * vy + k * my; uz = r * vz + k * mz; uw = r * vw + k * mw;
+  } else {  // total internal reflection
+    const double k = 2 * cos1;
+    ux = vx + k * mx; uy = vy + k * my; uz = vz + k * mz; uw = vw + k * mw;
+  }
+  const double ulen = norm4(ux, uy, uz, uw);
+  ox = ux / ulen; oy = uy / ulen; oz = uz / ulen;
+  ow = uw;  // (+-0) / ulen = +-0 for the finite positive ulen of a non-degenerate ray
+  if (uw != 0.0 || !(ulen > 0.0 && ulen < PRT_INF)) ow = uw / ulen;
+  index_out = (radicand > 0) ? n2 : n1;
+}
+
 // material.trace for a ray whose origin (px..pw) already sits on the surface.
 // d (4 comps) and index are updated in place.  Returns false for an untracable material.
 // (ux, uy, uz) is the incoming direction already divided by norm3(dx,dy,dz) -- the record row's
@@ -338,45 +381,18 @@ __device__ __forceinline__ bool shade(const DevPrim* __restrict__ p, double px, 
   double nx, ny, nz;
   world_normal(p, px, py, pz, pw, nx, ny, nz);
   const double nw = 0.0 * (double)p->normal_scale;
-  if (kind == MAT_MIRROR) {  // operations.py:104-107: v - (2 n) (v.n)
-    const double dot = ((dx * nx + dy * ny) + dz * nz) + dw * nw;
-    dx = dx - (2 * nx) * dot;
-    dy = dy - (2 * ny) * dot;
-    dz = dz - (2 * nz) * dot;
-    dw = dw - (2 * nw) * dot;
+  if (kind == MAT_MIRROR) {
+    reflect4(dx, dy, dz, dw, nx, ny, nz, nw);
     return true;
   }
-  // glass: operations.py:110-162
+  // glass: operations.py:110-162, n_global = 1 always
   const double n_mat = glass_index(p, wavelength);
   double vx = tx, vy = ty, vz = tz, vw = dw;  // dw == 0: (+-0) / |d| = +-0
   if (dw != 0.0) {
     const double len = norm4(dx, dy, dz, dw);
     vx = dx / len; vy = dy / len; vz = dz / len; vw = dw / len;
   }
-  const double cos_p = ((vx * nx + vy * ny) + vz * nz) + vw * nw;
-  const double cos_n = ((vx * -nx + vy * -ny) + vz * -nz) + vw * -nw;
-  const bool leaving = cos_p > 0;
-  const double n2 = leaving ? 1.0 : n_mat;  // n_global = 1 always
-  const double mx = leaving ? -nx : nx, my = leaving ? -ny : ny, mz = leaving ? -nz : nz,
-               mw = leaving ? -nw : nw;
-  const double n1 = index;
-  const double r = n1 / n2;
-  const double cos1 = leaving ? cos_p : cos_n;
-  const double radicand = 1 - (r * r) * (1 - cos1 * cos1);
-  const double cos2 = sqrt(dmax(0.0, radicand));
-  double ux, uy, uz, uw;
-  if (radicand > 0) {
-    const double k = r * cos1 - cos2;
-    ux = r * vx + k * mx; uy = r * vy + k * my; uz = r * vz + k * mz; uw = r * vw + k * mw;
-  } else {  // total internal reflection
-    const double k = 2 * cos1;
-    ux = vx + k * mx; uy = vy + k * my; uz = vz + k * mz; uw = vw + k * mw;
-  }
-  const double ulen = norm4(ux, uy, uz, uw);
-  dx = ux / ulen; dy = uy / ulen; dz = uz / ulen;
-  dw = uw;  // (+-0) / ulen = +-0 for the finite positive ulen of a non-degenerate ray
-  if (uw != 0.0 || !(ulen > 0.0 && ulen < PRT_INF)) dw = uw / ulen;
-  index = (radicand > 0) ? n2 : n1;
+  refract4(vx, vy, vz, vw, nx, ny, nz, nw, index, n_mat, 1.0, dx, dy, dz, dw, index);
   return true;
 }
 

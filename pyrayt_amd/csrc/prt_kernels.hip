@@ -772,6 +772,7 @@ k_material_trace(const DevPrim* __restrict__ prim, double* __restrict__ rays, in
 
 #include "prt_sources.hpp"
 #include "prt_render.hpp"
+#include "prt_ops.hpp"
 
 // deep CSG trees may need more than the default 64 KiB of dynamic LDS per workgroup
 static int raise_lds_limits() {
@@ -1362,6 +1363,76 @@ extern "C" int prt_edge_canvas(int device, const int64_t* surf, int64_t h_pixels
                      h_pixels, v_pixels, seed);
   hipLaunchKernelGGL(k_edge_canvas, dim3(blocks_for(n)), dim3(PRT_BLOCK), 0, (hipStream_t)stream,
                      (const unsigned char*)seed, h_pixels, v_pixels, rings, rgba_out);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tinygfx/g3d/operations.py as entry points
+// ------------------------------------------------------------------------------------------------
+static int ops_device(int device) {
+  int devices = 0;
+  HIP_TRY(hipGetDeviceCount(&devices));
+  if (device < 0 || device >= devices) return fail(PRT_ERR_ARG, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  return PRT_OK;
+}
+
+extern "C" int prt_reflect(int device, const double* vectors, const double* normals, int rows, int64_t n,
+                           int64_t ld, double* out, int64_t ld_out, void* stream) {
+  if (rows < 1 || rows > 4 || n < 0 || ld < n || ld_out < n || (n && (!vectors || !normals || !out)))
+    return fail(PRT_ERR_ARG, "bad buffers (vectors of 1..4 components)");
+  int rc = ops_device(device);
+  if (rc || n == 0) return rc;
+  hipLaunchKernelGGL(k_reflect, dim3(blocks_for(n)), dim3(PRT_BLOCK), 0, (hipStream_t)stream, vectors, normals,
+                     rows, ld, n, out, ld_out);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}
+
+extern "C" int prt_refract(int device, double* vectors, const double* normals, const double* n1,
+                           const double* n2, double n_global, int rows, int64_t n, int64_t ld, double* out,
+                           int64_t ld_out, double* index_out, void* stream) {
+  if (rows < 1 || rows > 4 || n < 0 || ld < n || ld_out < n ||
+      (n && (!vectors || !normals || !n1 || !n2 || !out || !index_out)))
+    return fail(PRT_ERR_ARG, "bad buffers (vectors of 1..4 components)");
+  int rc = ops_device(device);
+  if (rc || n == 0) return rc;
+  hipLaunchKernelGGL(k_refract, dim3(blocks_for(n)), dim3(PRT_BLOCK), 0, (hipStream_t)stream, vectors, normals,
+                     n1, n2, n_global, rows, ld, n, out, ld_out, index_out);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}
+
+extern "C" int prt_binomial_root(int device, const double* a, const double* b, const double* c, int64_t n,
+                                 double* roots_out, int64_t ld_out, void* stream) {
+  if (n < 0 || ld_out < n || (n && (!a || !b || !c || !roots_out))) return fail(PRT_ERR_ARG, "bad buffers");
+  int rc = ops_device(device);
+  if (rc || n == 0) return rc;
+  hipLaunchKernelGGL(k_binomial_root, dim3(blocks_for(n)), dim3(PRT_BLOCK), 0, (hipStream_t)stream, a, b, c, n,
+                     roots_out, ld_out);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}
+
+extern "C" int prt_smallest_positive_root(int device, const double* a, const double* b, const double* c,
+                                          int64_t n, double* out, void* stream) {
+  if (n < 0 || (n && (!a || !b || !c || !out))) return fail(PRT_ERR_ARG, "bad buffers");
+  int rc = ops_device(device);
+  if (rc || n == 0) return rc;
+  hipLaunchKernelGGL(k_smallest_positive_root, dim3(blocks_for(n)), dim3(PRT_BLOCK), 0, (hipStream_t)stream, a,
+                     b, c, n, out);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}
+
+extern "C" int prt_dot(int device, const double* m1, const double* m2, int64_t reduce_len,
+                       int64_t reduce_stride, int64_t out_len, int64_t out_stride, double* out, void* stream) {
+  if (reduce_len < 0 || out_len < 0 || (out_len && (!m1 || !m2 || !out))) return fail(PRT_ERR_ARG, "bad buffers");
+  int rc = ops_device(device);
+  if (rc || out_len == 0) return rc;
+  hipLaunchKernelGGL(k_dot, dim3(blocks_for(out_len)), dim3(PRT_BLOCK), 0, (hipStream_t)stream, m1, m2,
+                     reduce_len, reduce_stride, out_len, out_stride, out);
   HIP_TRY(hipGetLastError());
   return PRT_OK;
 }

@@ -60,6 +60,11 @@ def _declare(lib):
         "prt_render": (c_int, [c_p, c_int, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
         "prt_edge_workspace_bytes": (c_i64, [c_i64, c_i64]),
         "prt_edge_canvas": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_p]),
+        "prt_reflect": (c_int, [c_int, c_p, c_p, c_int, c_i64, c_i64, c_p, c_i64, c_p]),
+        "prt_refract": (c_int, [c_int, c_p, c_p, c_p, c_p, c_d, c_int, c_i64, c_i64, c_p, c_i64, c_p, c_p]),
+        "prt_binomial_root": (c_int, [c_int, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p]),
+        "prt_smallest_positive_root": (c_int, [c_int, c_p, c_p, c_p, c_i64, c_p, c_p]),
+        "prt_dot": (c_int, [c_int, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = the library does not match prt.h
@@ -74,7 +79,8 @@ EXPORTED_SYMBOLS = (
     "prt_material_trace", "prt_interact_workspace_bytes", "prt_interact",
     "prt_trace_workspace_bytes", "prt_trace", "prt_trace_stats", "prt_generate_rays",
     "prt_camera_rays", "prt_render_hits", "prt_gooch_shade", "prt_gooch_mix", "prt_render",
-    "prt_edge_workspace_bytes", "prt_edge_canvas",
+    "prt_edge_workspace_bytes", "prt_edge_canvas", "prt_reflect", "prt_refract", "prt_binomial_root",
+    "prt_smallest_positive_root", "prt_dot",
 )
 
 
@@ -561,3 +567,65 @@ def generate_rays(sources, rays_per_source, device, lo=0, hi=None):
         _check(lib.prt_generate_rays(device.index or 0, rec.ctypes.data, n, a - k * n, b - a, a,
                                      out.data_ptr(), out.stride(0), a - lo, _stream_ptr(torch, device)))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# tinygfx/g3d/operations.py as functions (host arrays in, host arrays out)
+# ---------------------------------------------------------------------------------------------
+def _ops_rows(matrix):
+    if not 1 <= matrix.shape[0] <= 4:
+        raise ValueError("vectors must have between 1 and 4 components")
+    return matrix.shape[0]
+
+
+def ops_reflect(vectors, normals):
+    torch = _torch()
+    v, nrm = _to_device(vectors), _to_device(normals)
+    out = torch.empty_like(v)
+    n = v.shape[1]
+    _check(library().prt_reflect(v.device.index or 0, v.data_ptr(), nrm.data_ptr(), _ops_rows(v), n,
+                                 v.stride(0), out.data_ptr(), out.stride(0), _stream_ptr(torch, v.device)))
+    return out.cpu().numpy()
+
+
+def ops_refract(vectors, normals, n1, n2, n_global):
+    torch = _torch()
+    v, nrm = _to_device(vectors), _to_device(normals)
+    a, b = _to_device(n1, 1)[0], _to_device(n2, 1)[0]
+    out = torch.empty_like(v)
+    n = v.shape[1]
+    index = torch.empty(n, dtype=torch.float64, device=v.device)
+    _check(library().prt_refract(v.device.index or 0, v.data_ptr(), nrm.data_ptr(), a.data_ptr(), b.data_ptr(),
+                                 n_global, _ops_rows(v), n, v.stride(0), out.data_ptr(), out.stride(0),
+                                 index.data_ptr(), _stream_ptr(torch, v.device)))
+    return out.cpu().numpy(), index.cpu().numpy(), v.cpu().numpy()
+
+
+def ops_polynomial(entry, a, b, c):
+    torch = _torch()
+    da, db, dc = (_to_device(x, 1)[0] for x in (a, b, c))
+    n = da.shape[0]
+    lib = library()
+    if entry == "prt_binomial_root":
+        out = torch.empty((2, n), dtype=torch.float64, device=da.device)
+        _check(lib.prt_binomial_root(da.device.index or 0, da.data_ptr(), db.data_ptr(), dc.data_ptr(), n,
+                                     out.data_ptr(), out.stride(0), _stream_ptr(torch, da.device)))
+    else:
+        out = torch.empty(n, dtype=torch.float64, device=da.device)
+        _check(lib.prt_smallest_positive_root(da.device.index or 0, da.data_ptr(), db.data_ptr(), dc.data_ptr(),
+                                              n, out.data_ptr(), _stream_ptr(torch, da.device)))
+    return out.cpu().numpy()
+
+
+def ops_dot(m1, m2, axis):
+    torch = _torch()
+    a, b = _to_device(m1), _to_device(m2)
+    rows, cols = a.shape
+    if axis == 0:
+        reduce_len, reduce_stride, out_len, out_stride = rows, a.stride(0), cols, 1
+    else:
+        reduce_len, reduce_stride, out_len, out_stride = cols, 1, rows, a.stride(0)
+    out = torch.empty(out_len, dtype=torch.float64, device=a.device)
+    _check(library().prt_dot(a.device.index or 0, a.data_ptr(), b.data_ptr(), reduce_len, reduce_stride,
+                             out_len, out_stride, out.data_ptr(), _stream_ptr(torch, a.device)))
+    return out.cpu().numpy()

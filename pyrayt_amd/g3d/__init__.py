@@ -4,6 +4,8 @@ The objects the ray-propagation hot path consumes -- transforms, traceable surfa
 nodes -- plus the second consumer of the intersect kernels: the
 orthographic camera, Gooch materials and the two renderers of ``tinygfx/g3d/renderers.py``.
 """
+from . import operations
+from .operations import binomial_root, element_wise_dot, reflect, refract, smallest_positive_root
 from . import shapes
 from .shapes import HomogeneousCoordinate, Point, Ray, Vector, bundle_of_rays, bundle_rays
 from . import materials
@@ -28,5 +30,6 @@ from . import renderers
 __all__ = [
     "BLACK", "CountedObject", "Cuboid", "Cylinder", "HomogeneousCoordinate", "Intersectable", "ObjectGroup",
     "OrthographicCamera", "Paraboloid", "Point", "Ray", "Sphere", "TracerSurface", "Vector", "WorldObject",
-    "XYPlane", "bundle_of_rays", "bundle_rays", "csg", "materials", "objects", "renderers", "shapes",
+    "XYPlane", "binomial_root", "bundle_of_rays", "bundle_rays", "csg", "element_wise_dot", "materials",
+    "objects", "operations", "reflect", "refract", "renderers", "shapes", "smallest_positive_root",
 ]

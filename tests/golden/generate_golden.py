@@ -450,6 +450,59 @@ def config2_summary(n=1_000_000):
     print(f"config2 1M summary   rows={frame.shape[0]} q5={q5.tolist()} -> {os.path.basename(path)}")
 
 
+def operations_vectors():
+    """tinygfx/g3d/operations.py as functions: the quadratic helpers incl. their degenerate
+    branches, the column dot product, reflect / refract in every broadcasting form they accept."""
+    out = {}
+    rng = np.random.default_rng(41)
+    k = 1024
+    a = rng.normal(size=k)
+    b = rng.normal(size=k) * 3
+    c = rng.normal(size=k) * 2
+    a[:64] = 0.0                       # linear
+    a[64:96] = rng.uniform(-1e-8, 1e-8, 32)
+    b[:16] = 0.0                       # constant only
+    b[16:32] = rng.uniform(-1e-8, 1e-8, 16)
+    c[:8] = np.abs(c[:8])              # ... with c > 0 and c <= 0
+    c[8:16] = -np.abs(c[8:16])
+    c[100:110] = 0.0
+    out["quad_a"], out["quad_b"], out["quad_c"] = a, b, c
+    with np.errstate(all="ignore"):
+        out["binomial_root"] = ref_ops.binomial_root(a.copy(), b.copy(), c.copy())
+        out["smallest_positive_root"] = ref_ops.smallest_positive_root(a.copy(), b.copy(), c.copy())
+    # known answers of test_operations.py:150-164
+    out["binomial_known"] = np.hstack((ref_ops.binomial_root(np.array([0.0]), np.array([1.0]), np.array([-2.0])),
+                                       ref_ops.binomial_root(np.array([0.0]), np.array([0.0]), np.array([-1.0]))))
+    m1, m2 = rng.normal(size=(4, k)), rng.normal(size=(4, k))
+    out["dot_m1"], out["dot_m2"] = m1, m2
+    out["dot_axis0"] = ref_ops.element_wise_dot(m1, m2, axis=0)
+    out["dot_axis1"] = ref_ops.element_wise_dot(m1, m2, axis=1)
+    out["dot_1d"] = np.float64(ref_ops.element_wise_dot(m1[:, 0], m2[:, 0]))
+    v = np.zeros((4, k))
+    v[:3] = rng.normal(size=(3, k))
+    nrm = np.zeros((4, k))
+    nrm[:3] = rng.normal(size=(3, k))
+    nrm[:3] /= np.linalg.norm(nrm[:3], axis=0)
+    out["vectors"], out["normals"] = v, nrm
+    out["reflect_full"] = ref_ops.reflect(v.copy(), nrm.copy())
+    out["reflect_one_normal"] = ref_ops.reflect(v.copy(), nrm[:, 3].copy())
+    out["reflect_1d"] = ref_ops.reflect(v[:, 5].copy(), nrm[:, 5].copy())
+    n1 = rng.choice([1.0, 1.5, 1.6, 1.3], k)
+    n2 = rng.choice([1.5, 1.6, 1.7, 1.0], k)
+    out["n1"], out["n2"] = n1, n2
+    vin = v.copy()
+    refr, n_out = ref_ops.refract(vin, nrm.copy(), n1.copy(), n2.copy())
+    out["refract_vectors_after"] = vin          # upstream normalises its argument in place
+    out["refracted"], out["n_refracted"] = refr, n_out
+    refr, n_out = ref_ops.refract(v.copy(), nrm.copy(), 1.0, 1.5)
+    out["refracted_scalar_index"], out["n_refracted_scalar_index"] = refr, n_out
+    refr, n_out = ref_ops.refract(v.copy(), nrm.copy(), n1.copy(), n2.copy(), n_global=1.33)
+    out["refracted_world_133"], out["n_refracted_world_133"] = refr, n_out
+    path = os.path.join(HERE, "operations.npz")
+    np.savez_compressed(path, **out)
+    print(f"operations           -> {os.path.basename(path)} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 def gooch_record(material):
     """(shade_warm, shade_cool) of gooch.py:36-37 for a surface material (tracer materials
     render with their ``_base_material``, pyrayt/materials.py:16-24)."""
@@ -535,7 +588,7 @@ def render_vectors():
 
 
 def main():
-    which = set(sys.argv[1:]) or {"scenes", "primitives", "csg", "shading", "sources", "summary", "render"}
+    which = set(sys.argv[1:]) or {"scenes", "primitives", "csg", "shading", "sources", "summary", "render", "operations"}
     print(f"numpy {np.__version__} pandas {pd.__version__} (reference locks numpy 1.20.2 / pandas 1.2.4)")
     if "scenes" in which:
         scene_fixture("config1", 100, 1000)
@@ -559,6 +612,8 @@ def main():
         config2_summary()
     if "render" in which:
         render_vectors()
+    if "operations" in which:
+        operations_vectors()
 
 
 if __name__ == "__main__":

@@ -44,7 +44,8 @@ def test_library_exports_every_declared_symbol(lib_path):
     for path in re.findall(r"(pyrayt/[\w/]+\.py|tinygfx/[\w/]+\.py)", text):
         assert path in ("pyrayt/_pyrayt.py", "pyrayt/materials.py", "tinygfx/g3d/world_objects.py",
                         "tinygfx/g3d/csg.py", "tinygfx/g3d/primitives.py", "pyrayt/components.py",
-                        "tinygfx/g3d/renderers.py", "tinygfx/g3d/materials/gooch.py"), path
+                        "tinygfx/g3d/renderers.py", "tinygfx/g3d/materials/gooch.py",
+                        "tinygfx/g3d/operations.py"), path
 
 
 def test_scene_create_validates_without_a_gpu(lib_path):
