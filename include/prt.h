@@ -313,6 +313,15 @@ int prt_smallest_positive_root(int device, const double* a, const double* b, con
 int prt_dot(int device, const double* m1, const double* m2, int64_t reduce_len,
             int64_t reduce_stride, int64_t out_len, int64_t out_stride, double* out, void* stream);
 
+/* csg.array_csg(array1, array2, operation, sort_output) (tinygfx/g3d/csg.py:13-61): the interval
+ * algebra of a CSG node on two (m, n) blocks of ascending hit lists (m even: enter/exit pairs), one
+ * column per ray; op = PRT_NODE_UNION / INTERSECT / DIFFERENCE.  out (m_left + m_right, n): with
+ * sort_output the surviving entries ascending followed by +inf, otherwise the merged order with
+ * rejected entries set to +inf.  Ties merge left-first (the stable order of SURVEY.md Q8). */
+int prt_array_csg(int device, const double* left, int m_left, const double* right, int m_right,
+                  int64_t n, int64_t ld, int op, int sort_output, double* out, int64_t ld_out,
+                  void* stream);
+
 /* error codes */
 #define PRT_OK 0
 #define PRT_ERR_ARG (-1)

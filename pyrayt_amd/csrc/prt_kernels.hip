@@ -1436,3 +1436,19 @@ extern "C" int prt_dot(int device, const double* m1, const double* m2, int64_t r
   HIP_TRY(hipGetLastError());
   return PRT_OK;
 }
+
+extern "C" int prt_array_csg(int device, const double* left, int m_left, const double* right, int m_right,
+                             int64_t n, int64_t ld, int op, int sort_output, double* out, int64_t ld_out,
+                             void* stream) {
+  if (m_left < 0 || m_right < 0 || (m_left & 1) || (m_right & 1))
+    return fail(PRT_ERR_ARG, "hit lists hold enter/exit pairs: an even number of rows each");
+  if (op < PRT_NODE_UNION || op > PRT_NODE_DIFFERENCE) return fail(PRT_ERR_ARG, "operation is invalid");
+  if (n < 0 || ld < n || ld_out < n || (n && ((m_left && !left) || (m_right && !right) || !out)))
+    return fail(PRT_ERR_ARG, "bad buffers");
+  int rc = ops_device(device);
+  if (rc || n == 0 || m_left + m_right == 0) return rc;
+  hipLaunchKernelGGL(k_array_csg, dim3(blocks_for(n)), dim3(PRT_BLOCK), 0, (hipStream_t)stream, left, m_left,
+                     right, m_right, ld, n, op, sort_output, out, ld_out);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}

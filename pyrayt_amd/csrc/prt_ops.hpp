@@ -73,3 +73,39 @@ k_dot(const double* __restrict__ m1, const double* __restrict__ m2, int64_t red_
   }
   out[o] = acc;
 }
+
+// csg.array_csg (csg.py:13-61) on two blocks of ascending hit lists, one column per ray: stable
+// merge (ties: left first), +-1 by list-position parity (right list negated and depth starting at
+// 1 for DIFFERENCE), keep rule with the np.roll wrap-around -- the walk csg_merge does for the
+// trace, here straight from global memory.  sort_output: survivors first, ascending, then +inf;
+// otherwise every merged position keeps its value or +inf.
+__global__ void __launch_bounds__(PRT_BLOCK)
+k_array_csg(const double* __restrict__ left, int m_left, const double* __restrict__ right, int m_right,
+            int64_t ld, int64_t n, int op, int sort_output, double* __restrict__ out, int64_t ld_out) {
+  const int64_t col = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+  if (col >= n) return;
+  const int total = m_left + m_right;
+  int i = 0, j = 0, kept = 0;
+  int depth = (op == CSG_DIFFERENCE) ? 1 : 0;
+  int prev = depth;  // depth of the last merged entry: the +-1 of complete lists cancel
+  double a = m_left ? left[col] : PRT_INF, b = m_right ? right[col] : PRT_INF;
+  for (int s = 0; s < total; ++s) {
+    const bool take_left = (i < m_left) && ((j >= m_right) || (a <= b));
+    const double v = take_left ? a : b;
+    const int pos = take_left ? i : j;
+    int step = (pos & 1) ? -1 : 1;
+    if (op == CSG_DIFFERENCE && !take_left) step = -step;
+    depth += step;
+    const bool keep = (op == CSG_UNION) ? ((depth != 0) != (prev != 0)) : (depth == 2 || prev == 2);
+    prev = depth;
+    if (take_left) { ++i; a = (i < m_left) ? left[(int64_t)i * ld + col] : PRT_INF; }
+    else { ++j; b = (j < m_right) ? right[(int64_t)j * ld + col] : PRT_INF; }
+    if (sort_output) {
+      if (keep && v < PRT_INF) { out[(int64_t)kept * ld_out + col] = v; ++kept; }
+    } else {
+      out[(int64_t)s * ld_out + col] = keep ? v : PRT_INF;
+    }
+  }
+  if (sort_output)
+    for (int k = kept; k < total; ++k) out[(int64_t)k * ld_out + col] = PRT_INF;
+}

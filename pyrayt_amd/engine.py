@@ -65,6 +65,7 @@ def _declare(lib):
         "prt_binomial_root": (c_int, [c_int, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p]),
         "prt_smallest_positive_root": (c_int, [c_int, c_p, c_p, c_p, c_i64, c_p, c_p]),
         "prt_dot": (c_int, [c_int, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
+        "prt_array_csg": (c_int, [c_int, c_p, c_int, c_p, c_int, c_i64, c_i64, c_int, c_int, c_p, c_i64, c_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = the library does not match prt.h
@@ -80,7 +81,7 @@ EXPORTED_SYMBOLS = (
     "prt_trace_workspace_bytes", "prt_trace", "prt_trace_stats", "prt_generate_rays",
     "prt_camera_rays", "prt_render_hits", "prt_gooch_shade", "prt_gooch_mix", "prt_render",
     "prt_edge_workspace_bytes", "prt_edge_canvas", "prt_reflect", "prt_refract", "prt_binomial_root",
-    "prt_smallest_positive_root", "prt_dot",
+    "prt_smallest_positive_root", "prt_dot", "prt_array_csg",
 )
 
 
@@ -628,4 +629,17 @@ def ops_dot(m1, m2, axis):
     out = torch.empty(out_len, dtype=torch.float64, device=a.device)
     _check(library().prt_dot(a.device.index or 0, a.data_ptr(), b.data_ptr(), reduce_len, reduce_stride,
                              out_len, out_stride, out.data_ptr(), _stream_ptr(torch, a.device)))
+    return out.cpu().numpy()
+
+
+def ops_array_csg(left, right, op, sort_output):
+    torch = _torch()
+    a, b = _to_device(left), _to_device(right)
+    if a.shape[1] != b.shape[1]:
+        raise ValueError("both arrays must describe the same rays (equal trailing dimension)")
+    n = a.shape[1]
+    out = torch.empty((a.shape[0] + b.shape[0], n), dtype=torch.float64, device=a.device)
+    _check(library().prt_array_csg(a.device.index or 0, a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], n,
+                                   max(a.stride(0), n), int(op), int(bool(sort_output)), out.data_ptr(),
+                                   max(out.stride(0), n), _stream_ptr(torch, a.device)))
     return out.cpu().numpy()

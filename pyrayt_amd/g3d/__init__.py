@@ -23,6 +23,7 @@ from .objects import (
     TracerSurface,
     WorldObject,
     XYPlane,
+    bounding_box,
 )
 from . import csg
 from . import renderers
@@ -30,6 +31,6 @@ from . import renderers
 __all__ = [
     "BLACK", "CountedObject", "Cuboid", "Cylinder", "HomogeneousCoordinate", "Intersectable", "ObjectGroup",
     "OrthographicCamera", "Paraboloid", "Point", "Ray", "Sphere", "TracerSurface", "Vector", "WorldObject",
-    "XYPlane", "binomial_root", "bundle_of_rays", "bundle_rays", "csg", "element_wise_dot", "materials",
+    "XYPlane", "binomial_root", "bounding_box", "bundle_of_rays", "bundle_rays", "csg", "element_wise_dot", "materials",
     "objects", "operations", "reflect", "refract", "renderers", "shapes", "smallest_positive_root",
 ]

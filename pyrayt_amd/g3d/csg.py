@@ -97,6 +97,22 @@ class CSGSurface(Intersectable):
         self._r_child.transform(matrix)
 
 
+def array_csg(array1, array2, operation, sort_output=True):
+    """The CSG interval algebra on two arrays of sorted hits (one column per ray, or 1-D for a single
+    ray): entries of the merged list that are not crossings of the combined solid's boundary become
+    +inf (``tinygfx/g3d/csg.py:13-61``).  Runs on the HIP engine (``prt_array_csg``)."""
+    from .. import engine
+
+    if not isinstance(operation, Operation):
+        raise ValueError(f"operation {operation} is invalid")
+    left = np.asarray(array1, dtype=float)
+    right = np.asarray(array2, dtype=float)
+    single = left.ndim == 1
+    out = engine.ops_array_csg(left.reshape(left.shape[0], -1), right.reshape(right.shape[0], -1),
+                               operation.value, sort_output)
+    return out[:, 0] if single else out
+
+
 def union(s0, s1):
     return CSGSurface(s0, s1, Operation.UNION)
 

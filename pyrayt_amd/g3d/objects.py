@@ -8,6 +8,7 @@ bounding boxes (``:15-23,348-358``).  The per-ray work -- ``intersect`` (``:360-
 ``get_world_normals`` (``:401-418``) -- is executed by the HIP engine; the methods here just
 hand the call to it.
 """
+import collections
 import copy
 from itertools import count
 
@@ -67,6 +68,13 @@ class WorldObject(CountedObject):
 
     def get_position(self):
         return np.matmul(self._world, shapes.Point(0, 0, 0))
+
+    def get_quaternion(self):
+        """The rotation part of the world transform as an (x, y, z, w) quaternion
+        (``world_objects.py:156-160``)."""
+        from scipy.spatial import transform
+
+        return transform.Rotation.from_matrix(self._world[:-1, :-1]).as_quat()
 
     def get_orientation(self):
         axis = np.matmul(self._world, shapes.Vector(0, 0, 1))
@@ -144,28 +152,12 @@ class WorldObject(CountedObject):
         return self._rotation(angle, units, 0, 1)
 
 
-class ObjectGroup(WorldObject):
+class ObjectGroup(WorldObject, collections.UserList):
     """A list of world objects that move together: a transform applied to the group is applied
     to every member, groups nest (``world_objects.py:283-295``).  Host-side scene editing only."""
 
-    def __init__(self, members=()):
-        super().__init__()
-        self.data = list(members)
-
-    def append(self, item):
-        self.data.append(item)
-
-    def extend(self, items):
-        self.data.extend(items)
-
-    def __len__(self):
-        return len(self.data)
-
-    def __iter__(self):
-        return iter(self.data)
-
-    def __getitem__(self, index):
-        return self.data[index]
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)  # WorldObject state, then UserList's ``data``
 
     def _append_world_transform(self, matrix):
         super()._append_world_transform(matrix)
@@ -196,6 +188,12 @@ class Intersectable(WorldObject):
 
     _normal_scale = 1
 
+    def attach_to(self, parent_object):
+        """Remember the object this one is a part of (``world_objects.py:315-317``).  Upstream also
+        chains its change-watch lists through here; nothing is cached on this side -- bounding
+        boxes are derived when asked for -- so the link itself is all there is to keep."""
+        self._parent = parent_object
+
     def invert_normals(self):
         self._normal_scale = -1
 
@@ -220,6 +218,11 @@ class Intersectable(WorldObject):
         from .. import engine
 
         return engine.component_intersect(self, rays)
+
+
+def bounding_box(point_set):
+    """Axis-aligned box that contains a (3+, k) point set (``world_objects.py:15-23``)."""
+    return shapes.AxisBox.around(np.asarray(point_set, dtype=float))
 
 
 BLACK = gooch.BLACK

@@ -219,3 +219,28 @@ def test_coordinate_helpers_like_upstream():
     block = cg.bundle_rays([ray, cg.Ray()])
     assert block.shape == (2, 4, 2) and np.array_equal(block[:, :, 0], ray)
     assert np.array_equal(cg.bundle_of_rays(3)[0], np.array([[0, 0, 0], [0, 0, 0], [0, 0, 0], [1, 1, 1]]))
+
+
+def test_group_is_a_list_and_small_world_object_helpers():
+    """world_objects.py:15-23 (bounding_box), :156-160 (get_quaternion), :283-295 (ObjectGroup is a
+    UserList), :315-317 (attach_to)."""
+    import numpy as np
+    import pyrayt_amd.g3d as cg
+
+    a, b, c = cg.Sphere(1), cg.Sphere(2), cg.Cuboid()
+    group = cg.ObjectGroup([a, b])
+    group.append(c)
+    group.insert(0, cg.XYPlane())
+    assert len(group) == 4 and group.index(a) == 1 and group.count(b) == 1
+    group.move_x(2).rotate_z(90)
+    assert np.allclose(c.get_position(), (0, 2, 0, 1)) and np.allclose(group.get_position(), (0, 2, 0, 1))
+    assert group.pop() is c and len(group) == 3
+    group.reverse()
+    assert group[0] is b
+    quat = cg.Sphere().rotate_z(90).get_quaternion()
+    assert np.allclose(quat, (0, 0, np.sqrt(0.5), np.sqrt(0.5)))
+    box = cg.bounding_box(np.array([[0.0, 1, 2], [3, -1, 2], [0, 0, 5], [1, 1, 1]]))
+    assert box.axis_spans.tolist() == [[0.0, 2.0], [-1.0, 3.0], [0.0, 5.0]]
+    part = cg.Sphere()
+    part.attach_to(group)
+    assert part._parent is group
