@@ -322,6 +322,17 @@ int prt_array_csg(int device, const double* left, int m_left, const double* righ
                   int64_t n, int64_t ld, int op, int sort_output, double* out, int64_t ld_out,
                   void* stream);
 
+/* primitive.intersect(rays) / primitive.normal(points) in OBJECT space (tinygfx/g3d/primitives.py:
+ * Sphere :220-296, Paraboloid :299-419, Plane :422-498, Cube :501-602, Cylinder :621-741), i.e. the
+ * shape routines without a world transform: type = PRT_PRIM_*, params as in prt_prim.
+ *   rays (>= 7, n) ld (rows 0-2 origin, 4-6 direction; w rows are not read) -> hits_out (2, n):
+ *   the raw pair in upstream's order -- not sorted, NaN where upstream yields NaN
+ *   points (>= 3, n) ld -> normals_out (4, n): unit normal, w = 0 */
+int prt_primitive_intersect(int device, int type, const double* params, const double* rays,
+                            int64_t n, int64_t ld, double* hits_out, int64_t ld_out, void* stream);
+int prt_primitive_normal(int device, int type, const double* params, const double* points,
+                         int64_t n, int64_t ld, double* normals_out, int64_t ld_out, void* stream);
+
 /* error codes */
 #define PRT_OK 0
 #define PRT_ERR_ARG (-1)

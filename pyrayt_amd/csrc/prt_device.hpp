@@ -187,18 +187,12 @@ __device__ __forceinline__ bool box_touched(const double* __restrict__ span, con
   return is_finite(h0) || is_finite(h1);
 }
 
-// ---- TracerSurface.intersect: world -> object, primitive test, ascending pair -----------------
-// `type`, q = params[6] and m = rows 0..2 of M^-1 (12 values) come from the step record.
-__device__ __forceinline__ void surface_pair(int type, const double* __restrict__ q,
-                                             const double* __restrict__ m, const Ray8& r,
-                                             double& t0, double& t1) {
-  const double ox = row_dot(m, 0, r.ox, r.oy, r.oz, r.ow);
-  const double oy = row_dot(m, 1, r.ox, r.oy, r.oz, r.ow);
-  const double oz = row_dot(m, 2, r.ox, r.oy, r.oz, r.ow);
-  const double dx = row_dot(m, 0, r.dx, r.dy, r.dz, r.dw);
-  const double dy = row_dot(m, 1, r.dx, r.dy, r.dz, r.dw);
-  const double dz = row_dot(m, 2, r.dx, r.dy, r.dz, r.dw);
-  double h0, h1;
+// ---- primitive.intersect in object space (primitives.py Sphere :241-271, Cylinder :650-712,
+// Plane :436-492, Cube :516-581, Paraboloid :320-399): the raw pair, in upstream's order, NaN where
+// upstream yields NaN (0/0 of a zero direction)
+__device__ __forceinline__ void primitive_pair(int type, const double* __restrict__ q, double ox,
+                                               double oy, double oz, double dx, double dy,
+                                               double dz, double& h0, double& h1) {
   switch (type) {
     case PRIM_SPHERE: {  // primitives.py:241-271 (no guard on a == 0)
       const double a = (dx * dx + dy * dy) + dz * dz;
@@ -255,10 +249,63 @@ __device__ __forceinline__ void surface_pair(int type, const double* __restrict_
       overlap(p0, p1, c0, c1, h0, h1);
     } break;
   }
+}
+
+// ---- TracerSurface.intersect: world -> object, primitive test, ascending pair -----------------
+// `type`, q = params[6] and m = rows 0..2 of M^-1 (12 values) come from the step record.
+__device__ __forceinline__ void surface_pair(int type, const double* __restrict__ q,
+                                             const double* __restrict__ m, const Ray8& r,
+                                             double& t0, double& t1) {
+  const double ox = row_dot(m, 0, r.ox, r.oy, r.oz, r.ow);
+  const double oy = row_dot(m, 1, r.ox, r.oy, r.oz, r.ow);
+  const double oz = row_dot(m, 2, r.ox, r.oy, r.oz, r.ow);
+  const double dx = row_dot(m, 0, r.dx, r.dy, r.dz, r.dw);
+  const double dy = row_dot(m, 1, r.dx, r.dy, r.dz, r.dw);
+  const double dz = row_dot(m, 2, r.dx, r.dy, r.dz, r.dw);
+  double h0, h1;
+  primitive_pair(type, q, ox, oy, oz, dx, dy, dz, h0, h1);
   h0 = nan_to_inf(h0);
   h1 = nan_to_inf(h1);
   t0 = dmin(h0, h1);
   t1 = dmax(h0, h1);
+}
+
+// ---- primitive.normal in object space (primitives.py Sphere :273-296, Paraboloid :401-419,
+// Plane :494-498, Cube :583-602, Cylinder :714-741): unit normal (w = 0) at an object-space point.
+// For the stand-alone entry point only.  world_normal() below carries the same switch inline on
+// purpose: routing it through this function changes the register allocation of the generation
+// kernel enough to spill (measured: 12 B of scratch per lane), so the two are kept side by side.
+__device__ __forceinline__ void object_normal(int type, const double* __restrict__ q, double lx,
+                                              double ly, double lz, double& ax, double& ay,
+                                              double& az) {
+  bool normalise = true;
+  switch (type) {
+    case PRIM_SPHERE:  // primitives.py:291-293
+      ax = lx; ay = ly; az = lz;
+      break;
+    case PRIM_CYLINDER:  // :722-738
+      ax = lx; ay = ly; az = 0.0;
+      if (close_to(lz, q[1])) { ax = 0.0; ay = 0.0; az = -1.0; }
+      if (close_to(lz, q[2])) { ax = 0.0; ay = 0.0; az = 1.0; }
+      break;
+    case PRIM_PLANE:  // :496-498
+      ax = 0.0; ay = 0.0; az = 1.0;
+      normalise = false;
+      break;
+    case PRIM_CUBE:  // :593-599 (a point on no face gives 0/0 = NaN, as upstream)
+      ax = close_to(lx, q[1]) ? 1.0 : (close_to(lx, q[0]) ? -1.0 : 0.0);
+      ay = close_to(ly, q[3]) ? 1.0 : (close_to(ly, q[2]) ? -1.0 : 0.0);
+      az = close_to(lz, q[5]) ? 1.0 : (close_to(lz, q[4]) ? -1.0 : 0.0);
+      break;
+    default:  // PRIM_PARABOLOID :405-418
+      ax = lx; ay = ly; az = -2 * q[0];
+      if (close_to(lz, q[1])) { ax = 0.0; ay = 0.0; az = 1.0; }
+      break;
+  }
+  if (normalise) {
+    const double len = norm4(ax, ay, az, 0.0);
+    ax /= len; ay /= len; az /= len;
+  }
 }
 
 // ---- TracerSurface.get_world_normals (world_objects.py:401-418) -------------------------------

@@ -1452,3 +1452,38 @@ extern "C" int prt_array_csg(int device, const double* left, int m_left, const d
   HIP_TRY(hipGetLastError());
   return PRT_OK;
 }
+
+static int primitive_args(int type, const double* params, PrimParams* out) {
+  if (type < PRT_PRIM_SPHERE || type > PRT_PRIM_PARABOLOID) return fail(PRT_ERR_ARG, "unknown primitive type");
+  if (!params) return fail(PRT_ERR_ARG, "params is null");
+  std::memcpy(out->q, params, sizeof(out->q));
+  return PRT_OK;
+}
+
+extern "C" int prt_primitive_intersect(int device, int type, const double* params, const double* rays,
+                                       int64_t n, int64_t ld, double* hits_out, int64_t ld_out, void* stream) {
+  PrimParams q;
+  int rc = primitive_args(type, params, &q);
+  if (rc) return rc;
+  if (n < 0 || ld < n || ld_out < n || (n && (!rays || !hits_out))) return fail(PRT_ERR_ARG, "bad buffers");
+  rc = ops_device(device);
+  if (rc || n == 0) return rc;
+  hipLaunchKernelGGL(k_primitive_intersect, dim3(blocks_for(n)), dim3(PRT_BLOCK), 0, (hipStream_t)stream, type, q,
+                     rays, ld, n, hits_out, ld_out);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}
+
+extern "C" int prt_primitive_normal(int device, int type, const double* params, const double* points,
+                                    int64_t n, int64_t ld, double* normals_out, int64_t ld_out, void* stream) {
+  PrimParams q;
+  int rc = primitive_args(type, params, &q);
+  if (rc) return rc;
+  if (n < 0 || ld < n || ld_out < n || (n && (!points || !normals_out))) return fail(PRT_ERR_ARG, "bad buffers");
+  rc = ops_device(device);
+  if (rc || n == 0) return rc;
+  hipLaunchKernelGGL(k_primitive_normal, dim3(blocks_for(n)), dim3(PRT_BLOCK), 0, (hipStream_t)stream, type, q,
+                     points, ld, n, normals_out, ld_out);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}

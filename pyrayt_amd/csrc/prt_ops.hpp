@@ -109,3 +109,32 @@ k_array_csg(const double* __restrict__ left, int m_left, const double* __restric
   if (sort_output)
     for (int k = kept; k < total; ++k) out[(int64_t)k * ld_out + col] = PRT_INF;
 }
+
+// primitive.intersect / primitive.normal in object space (primitives.py): the raw pair in
+// upstream's order (no sort, NaN kept), the unit object-space normal
+struct PrimParams { double q[6]; };
+
+__global__ void __launch_bounds__(PRT_BLOCK)
+k_primitive_intersect(int type, PrimParams params, const double* __restrict__ rays, int64_t ld, int64_t n,
+                      double* __restrict__ out, int64_t ld_out) {
+  const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  double h0, h1;
+  primitive_pair(type, params.q, rays[i], rays[ld + i], rays[2 * ld + i], rays[4 * ld + i], rays[5 * ld + i],
+                 rays[6 * ld + i], h0, h1);
+  out[i] = h0;
+  out[ld_out + i] = h1;
+}
+
+__global__ void __launch_bounds__(PRT_BLOCK)
+k_primitive_normal(int type, PrimParams params, const double* __restrict__ pts, int64_t ld, int64_t n,
+                   double* __restrict__ out, int64_t ld_out) {
+  const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  double ax, ay, az;
+  object_normal(type, params.q, pts[i], pts[ld + i], pts[2 * ld + i], ax, ay, az);
+  out[i] = ax;
+  out[ld_out + i] = ay;
+  out[2 * ld_out + i] = az;
+  out[3 * ld_out + i] = 0.0;
+}

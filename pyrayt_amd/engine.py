@@ -65,6 +65,8 @@ def _declare(lib):
         "prt_binomial_root": (c_int, [c_int, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p]),
         "prt_smallest_positive_root": (c_int, [c_int, c_p, c_p, c_p, c_i64, c_p, c_p]),
         "prt_dot": (c_int, [c_int, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
+        "prt_primitive_intersect": (c_int, [c_int, c_int, c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
+        "prt_primitive_normal": (c_int, [c_int, c_int, c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
         "prt_array_csg": (c_int, [c_int, c_p, c_int, c_p, c_int, c_i64, c_i64, c_int, c_int, c_p, c_i64, c_p]),
     }
     for name, (res, args) in sig.items():
@@ -81,7 +83,8 @@ EXPORTED_SYMBOLS = (
     "prt_trace_workspace_bytes", "prt_trace", "prt_trace_stats", "prt_generate_rays",
     "prt_camera_rays", "prt_render_hits", "prt_gooch_shade", "prt_gooch_mix", "prt_render",
     "prt_edge_workspace_bytes", "prt_edge_canvas", "prt_reflect", "prt_refract", "prt_binomial_root",
-    "prt_smallest_positive_root", "prt_dot", "prt_array_csg",
+    "prt_smallest_positive_root", "prt_dot", "prt_array_csg", "prt_primitive_intersect",
+    "prt_primitive_normal",
 )
 
 
@@ -642,4 +645,17 @@ def ops_array_csg(left, right, op, sort_output):
     _check(library().prt_array_csg(a.device.index or 0, a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], n,
                                    max(a.stride(0), n), int(op), int(bool(sort_output)), out.data_ptr(),
                                    max(out.stride(0), n), _stream_ptr(torch, a.device)))
+    return out.cpu().numpy()
+
+
+def ops_primitive(entry, kind, params, block, out_rows):
+    """prt_primitive_intersect / prt_primitive_normal on a host (rows, n) block."""
+    torch = _torch()
+    data = _to_device(block)
+    n = data.shape[1]
+    packed = np.ascontiguousarray(np.asarray(params, dtype=float))
+    out = torch.empty((out_rows, n), dtype=torch.float64, device=data.device)
+    _check(getattr(library(), entry)(data.device.index or 0, int(kind), packed.ctypes.data, data.data_ptr(), n,
+                                     max(data.stride(0), n), out.data_ptr(), max(out.stride(0), n),
+                                     _stream_ptr(torch, data.device)))
     return out.cpu().numpy()

@@ -5,6 +5,7 @@ nodes -- plus the second consumer of the intersect kernels (SURVEY.md section 8f
 orthographic camera, Gooch materials and the two renderers of ``tinygfx/g3d/renderers.py``.
 """
 from . import operations
+from . import primitives
 from .operations import binomial_root, element_wise_dot, reflect, refract, smallest_positive_root
 from . import shapes
 from .shapes import HomogeneousCoordinate, Point, Ray, Vector, bundle_of_rays, bundle_rays
@@ -32,5 +33,5 @@ __all__ = [
     "BLACK", "CountedObject", "Cuboid", "Cylinder", "HomogeneousCoordinate", "Intersectable", "ObjectGroup",
     "OrthographicCamera", "Paraboloid", "Point", "Ray", "Sphere", "TracerSurface", "Vector", "WorldObject",
     "XYPlane", "binomial_root", "bounding_box", "bundle_of_rays", "bundle_rays", "csg", "element_wise_dot", "materials",
-    "objects", "operations", "reflect", "refract", "renderers", "shapes", "smallest_positive_root",
+    "objects", "operations", "primitives", "reflect", "refract", "renderers", "shapes", "smallest_positive_root",
 ]

@@ -129,6 +129,28 @@ class Shape:
     def packed_params(self):
         return list(self.params) + [0.0] * (6 - len(self.params))
 
+    def intersect(self, rays):
+        """(2, n) ray parameters where the (2,4) ray / (2,4,n) rays meet the shape in its own
+        coordinate frame: the raw pair of the reference's ``primitive.intersect`` -- not sorted,
+        +inf for a miss.  HIP engine (``prt_primitive_intersect``)."""
+        from .. import engine
+
+        block = np.atleast_3d(np.asarray(rays, dtype=float)).reshape(8, -1)
+        return engine.ops_primitive("prt_primitive_intersect", self.kind, self.packed_params(), block, 2)
+
+    def normal(self, intersections):
+        """Unit object-space normal(s) (w = 0) at a (4,) point or (4, n) points assumed to lie on the
+        shape.  HIP engine (``prt_primitive_normal``)."""
+        from .. import engine
+
+        points = np.asarray(intersections, dtype=float)
+        if points.ndim not in (1, 2):
+            raise AttributeError(
+                f"Argument intersections has too many dimensions, expect 1 or 2, got {points.ndim}")
+        out = engine.ops_primitive("prt_primitive_normal", self.kind, self.packed_params(),
+                                   points.reshape(points.shape[0], -1), 4)
+        return out[:, 0] if points.ndim == 1 else out
+
 
 class SphereShape(Shape):
     kind = SPHERE

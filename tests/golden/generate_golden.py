@@ -450,6 +450,35 @@ def config2_summary(n=1_000_000):
     print(f"config2 1M summary   rows={frame.shape[0]} q5={q5.tolist()} -> {os.path.basename(path)}")
 
 
+def raw_primitive_vectors():
+    """primitive.intersect / primitive.normal in object space, as upstream's classes return them:
+    the unsorted pair (NaN for zero directions included) and the unit normals at the hit points."""
+    import tinygfx.g3d.primitives as prims
+
+    recipes = {
+        "sphere": (prims.Sphere, (1.3,)), "sphere_unit": (prims.Sphere, ()),
+        "cylinder": (prims.Cylinder, (0.8, -0.5, 1.2)), "plane": (prims.Plane, (3.0, 2.0)),
+        "cube": (prims.Cube, ((-1.0, -0.5, -0.25), (0.5, 1.5, 2.0))), "paraboloid": (prims.Paraboloid, (0.7, 1.5)),
+    }
+    out = {}
+    for k, (name, (cls, args)) in enumerate(recipes.items()):
+        shape = cls(*args)
+        rays = scenes.random_rays(3000, seed=900 + k, box=2.5)[:8].reshape(2, 4, -1)
+        with np.errstate(all="ignore"):
+            hits = shape.intersect(rays.copy())
+            nearest = np.where(np.isfinite(hits), hits, np.inf).min(axis=0)
+            on = np.isfinite(nearest)
+            points = (rays[0] + nearest * rays[1])[:, on]
+            normals = shape.normal(points.copy())
+        out[f"{name}__rays"], out[f"{name}__hits"] = rays, hits
+        out[f"{name}__points"], out[f"{name}__normals"] = points, normals
+        print(f"  raw {name:12s} {int(on.sum()):5d} of {rays.shape[-1]} rays hit, "
+              f"{int(np.isnan(hits).any(axis=0).sum())} NaN columns")
+    path = os.path.join(HERE, "primitives_raw.npz")
+    np.savez_compressed(path, **out)
+    print(f"raw primitives       -> {os.path.basename(path)} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 def operations_vectors():
     """tinygfx/g3d/operations.py as functions: the quadratic helpers incl. their degenerate
     branches, the column dot product, reflect / refract in every broadcasting form they accept."""
@@ -588,7 +617,7 @@ def render_vectors():
 
 
 def main():
-    which = set(sys.argv[1:]) or {"scenes", "primitives", "csg", "shading", "sources", "summary", "render", "operations"}
+    which = set(sys.argv[1:]) or {"scenes", "primitives", "csg", "shading", "sources", "summary", "render", "operations", "raw"}
     print(f"numpy {np.__version__} pandas {pd.__version__} (reference locks numpy 1.20.2 / pandas 1.2.4)")
     if "scenes" in which:
         scene_fixture("config1", 100, 1000)
@@ -614,6 +643,8 @@ def main():
         render_vectors()
     if "operations" in which:
         operations_vectors()
+    if "raw" in which:
+        raw_primitive_vectors()
 
 
 if __name__ == "__main__":
