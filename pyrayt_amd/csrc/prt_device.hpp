@@ -266,8 +266,8 @@ __device__ __forceinline__ void surface_pair(int type, const double* __restrict_
   primitive_pair(type, q, ox, oy, oz, dx, dy, dz, h0, h1);
   h0 = nan_to_inf(h0);
   h1 = nan_to_inf(h1);
-  t0 = dmin(h0, h1);
-  t1 = dmax(h0, h1);
+  t0 = fmin(h0, h1);  // NaN-free here: v_min / v_max order the pair like np.sort (signed zeros compare equal)
+  t1 = fmax(h0, h1);
 }
 
 // ---- primitive.normal in object space (primitives.py Sphere :273-296, Paraboloid :401-419,
