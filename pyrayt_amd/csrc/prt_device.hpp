@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "prt_math.hpp"
+
 #ifndef PRT_BLOCK
 #define PRT_BLOCK 256
 #endif
@@ -35,7 +37,7 @@ struct DevPrim {
   int32_t type, mat_kind, normal_scale, pad;
 };
 
-enum { I_LEAF = 0, I_CSG = 1, I_ROOT = 2, I_BOX = 3 };
+enum { I_LEAF = 0, I_CSG = 1, I_ROOT = 2, I_BOX = 3, I_CHAIN = 4 };
 enum { OPER_REGA = 0, OPER_REGB = 1, OPER_LDS = 2 };
 enum { CSG_UNION = 1, CSG_INTERSECT = 2, CSG_DIFFERENCE = 3 };
 enum { PRIM_SPHERE = 0, PRIM_CYLINDER = 1, PRIM_PLANE = 2, PRIM_CUBE = 3, PRIM_PARABOLOID = 4 };
@@ -58,6 +60,32 @@ struct DevInstr {
   int32_t pad[2]; // CSG: [0] root node of a component, [1] cull box implied (see csg_node); LEAF: [0] == 1 skippable right leaf, == 2 a whole component
   int32_t type;   // LEAF: PRIM_*
   double data[18];// LEAF: params[0..5], M^-1 rows 0..2 [6..17]   CSG: cull box [0..5]
+};
+
+// A whole component in one step (trace programs): a left-deep chain of two or three leaf surfaces,
+//     (leaf0 op1 leaf1)            or            ((leaf0 op1 leaf1) op2 leaf2),
+// which is what every part factory builds (components.py:73-198, 269-468).  The record takes three
+// DevInstr slots; `shape` selects a body compiled for the leaves' primitive types, so the whole
+// component is one basic block per stage: no step dispatch, no hit lists in LDS, and the
+// independent transform -> quadratic -> sqrt -> divide chains of sibling leaves interleave.
+struct DevChain {
+  int32_t kind;          // I_CHAIN
+  int32_t shape;         // CHAIN_* below
+  int32_t n_leaves;      // 2 or 3
+  int32_t op1, op2;      // CSG_*
+  int32_t prim[3];
+  int32_t implied1, implied2;  // cull box implied by the survivors (see csg_keep)
+  int32_t pad[2];
+  double box1[6], box2[6];     // upstream cull boxes of the two nodes (csg.py:126-128)
+  double leaf[3][18];          // params[0..5], M^-1 rows 0..2 [6..17]
+};
+static_assert(sizeof(DevChain) == 3 * sizeof(DevInstr), "a chain record spans three step slots");
+enum { CHAIN_SLOTS = 3 };
+// leaf types per shape, in chain order (S sphere, C cylinder, P plane, Q cube, B paraboloid)
+enum {
+  CHAIN_SSC = 0, CHAIN_SSQ, CHAIN_CSS, CHAIN_QSS, CHAIN_QQQ,                        // three leaves
+  CHAIN_SC, CHAIN_SQ, CHAIN_CS, CHAIN_QS, CHAIN_CB, CHAIN_QB, CHAIN_PC, CHAIN_PQ, CHAIN_BC,  // two
+  CHAIN_SHAPES
 };
 
 struct Ray8 {
@@ -106,14 +134,32 @@ __device__ __forceinline__ double norm3(double x, double y, double z) {
   return sqrt((x * x + y * y) + z * z);
 }
 
+// Quotients that share a denominator: one refined reciprocal for all of them (prt_math.hpp), the
+// same bits as separate `/`.  Used for the three-component normalisations; -DPRT_PLAIN_DIV3 builds
+// the A/B partner.
+__device__ __forceinline__ void div2(double n0, double n1, double d, double& q0, double& q1) {
+#ifndef PRT_SHARED_DIV2  // measured: for pairs the operand checks cost what the shared reciprocal saves
+  q0 = n0 / d; q1 = n1 / d;
+#else
+  prt_div2(n0, n1, d, q0, q1);
+#endif
+}
+__device__ __forceinline__ void div3(double n0, double n1, double n2, double d, double& q0, double& q1,
+                                     double& q2) {
+#if defined(PRT_PLAIN_DIV) || defined(PRT_PLAIN_DIV3)
+  q0 = n0 / d; q1 = n1 / d; q2 = n2 / d;
+#else
+  prt_div3(n0, n1, n2, d, q0, q1, q2);
+#endif
+}
+
 // ---- quadratic with the reference's degenerate branches (operations.py:28-63) ----------------
 __device__ __forceinline__ void binomial_root(double a, double b, double c, double& p0, double& p1) {
   const double disc = b * b - 4 * a * c;
   const bool lin = near0(a);
   const double s = sqrt(dmax(0.0, disc));
   const double den = 2 * a + (lin ? 1.0 : 0.0);
-  p0 = (-b + s) / den;
-  p1 = (-b - s) / den;
+  div2(-b + s, -b - s, den, p0, p1);
   if (!(disc >= 0)) { p0 = PRT_INF; p1 = PRT_INF; }
   if (lin) {
     const double root = -c / (b + (b == 0 ? 1.0 : 0.0));
@@ -130,8 +176,7 @@ __device__ __forceinline__ void z_slab(double oz, double dz, double lo, double h
                                        double& c1) {
   const bool par = near0(dz);
   const double den = dz + (par ? 1.0 : 0.0);
-  c0 = (lo - oz) / den;
-  c1 = (hi - oz) / den;
+  div2(lo - oz, hi - oz, den, c0, c1);
   if (par) {
     c0 = (oz >= lo && oz <= hi) ? -PRT_INF : PRT_INF;
     c1 = PRT_INF;
@@ -153,8 +198,8 @@ __device__ __forceinline__ void axis_slab(double o, double d, double lo, double 
                                           double& s_lo, double& s_hi) {
   const bool z = near0(d);
   const double den = d + (z ? 1.0 : 0.0);
-  double first = -(o - lo) / den;
-  double second = -(o - hi) / den;
+  double first, second;
+  div2(-(o - lo), -(o - hi), den, first, second);
   if (z) {
     first = inside ? -PRT_INF : PRT_INF;
     second = PRT_INF;
@@ -201,8 +246,7 @@ __device__ __forceinline__ void primitive_pair(int type, const double* __restric
       const double disc = b * b - 4 * a * c;
       const double s = sqrt(dmax(0.0, disc));
       const double den = 2 * a;
-      h0 = (-b + s) / den;
-      h1 = (-b - s) / den;
+      div2(-b + s, -b - s, den, h0, h1);
       if (!(disc >= 0)) { h0 = PRT_INF; h1 = PRT_INF; }
     } break;
     case PRIM_CYLINDER: {  // primitives.py:650-712
@@ -238,7 +282,8 @@ __device__ __forceinline__ void primitive_pair(int type, const double* __restric
       const bool lin = near0(a);
       const double s = sqrt(dmax(0.0, disc));
       const double den = 2 * a + (lin ? 1.0 : 0.0);
-      double p0 = (-b + s) / den, p1 = (-b - s) / den;
+      double p0, p1;
+      div2(-b + s, -b - s, den, p0, p1);
       if (!(disc >= 0)) { p0 = PRT_INF; p1 = PRT_INF; }
       if (lin) {
         p0 = -c / (b + (near0(b) ? 1.0 : 0.0));
@@ -304,7 +349,7 @@ __device__ __forceinline__ void object_normal(int type, const double* __restrict
   }
   if (normalise) {
     const double len = norm4(ax, ay, az, 0.0);
-    ax /= len; ay /= len; az /= len;
+    div3(ax, ay, az, len, ax, ay, az);
   }
 }
 
@@ -345,16 +390,21 @@ __device__ __forceinline__ void world_normal(const DevPrim* __restrict__ p, doub
   }
   if (normalise) {
     const double len = norm4(ax, ay, az, 0.0);
+#ifdef PRT_SHARED_DIV_OBJNORMAL  // measured: the branch diamond here costs the generation kernel 20 B/lane of scratch
+    div3(ax, ay, az, len, ax, ay, az);
+#else
     ax /= len; ay /= len; az /= len;
+#endif
   }
   double wx = col_dot(m, 0, ax, ay, az, 0.0);
   double wy = col_dot(m, 1, ax, ay, az, 0.0);
   double wz = col_dot(m, 2, ax, ay, az, 0.0);
   const double len = norm4(wx, wy, wz, 0.0);
   const double sgn = (double)p->normal_scale;
-  nx = (wx / len) * sgn;
-  ny = (wy / len) * sgn;
-  nz = (wz / len) * sgn;
+  div3(wx, wy, wz, len, wx, wy, wz);
+  nx = wx * sgn;
+  ny = wy * sgn;
+  nz = wz * sgn;
 }
 
 // ---- materials --------------------------------------------------------------------------------
@@ -403,7 +453,7 @@ __device__ __forceinline__ void refract4(double vx, double vy, double vz, double
     ux = vx + k * mx; uy = vy + k * my; uz = vz + k * mz; uw = vw + k * mw;
   }
   const double ulen = norm4(ux, uy, uz, uw);
-  ox = ux / ulen; oy = uy / ulen; oz = uz / ulen;
+  div3(ux, uy, uz, ulen, ox, oy, oz);
   ow = uw;  // (+-0) / ulen = +-0 for the finite positive ulen of a non-degenerate ray
   if (uw != 0.0 || !(ulen > 0.0 && ulen < PRT_INF)) ow = uw / ulen;
   index_out = (radicand > 0) ? n2 : n1;
@@ -581,6 +631,95 @@ __device__ __forceinline__ void first_positive_else_first(const Operand& o, cons
 // no survivor gets the all-inf list either way.  Only rays whose survivors are (nearly)
 // coincident -- tangent rays, a Plane's double hit (t,t) -- take the exact six-division test.
 // UNION nodes always take it (their upstream box can be smaller than the solid).
+// keep flags of one node (the part of csg_node below that needs no list storage): c(i,j), the
+// parities, the keep rule per operation and the (lazily evaluated) cull box.  Neither list has to
+// be sorted or compacted for this: every quantity is a count of entries of the *other* list that
+// sort before an entry, and a dropped entry left in place as +inf sorts before nothing finite.
+template <int ML, int MR>
+__device__ __forceinline__ void csg_keep(int op, const double (&lv)[ML], const double (&rv)[MR],
+                                         const double* __restrict__ aabb, const Ray8& ray,
+                                         bool box_implied, bool (&keep_l)[ML], bool (&keep_r)[MR],
+                                         bool (&c)[ML][MR]) {
+  // c(i,j) = L_i sorts before R_j.  Everything the keep rule needs is a parity: with p_i = (number
+  // of R entries before L_i) mod 2 and q_j = (number of L entries before-or-at R_j) mod 2, working the
+  // +-1 depths of array_csg through (own list alternates from +1, or from -1 for the right list
+  // of a DIFFERENCE, whose depth also starts at 1; "depth before" of the first merged entry is the
+  // np.roll wrap value, which the same algebra yields) gives
+  //     UNION       keep L_i = !p_i   keep R_j = !q_j      (depth != 0  xor  before != 0)
+  //     INTERSECT   keep L_i =  p_i   keep R_j =  q_j      (depth == 2  or   before == 2)
+  //     DIFFERENCE  keep L_i = !p_i   keep R_j =  q_j
+  // -- lane masks and scalar logic only; per-lane integers are needed only to place survivors.
+  bool p[ML], q[MR];
+#pragma unroll
+  for (int i = 0; i < ML; ++i) p[i] = false;
+#pragma unroll
+  for (int j = 0; j < MR; ++j) q[j] = false;
+#pragma unroll
+  for (int i = 0; i < ML; ++i) {
+#pragma unroll
+    for (int j = 0; j < MR; ++j) {
+      c[i][j] = lv[i] <= rv[j];
+      q[j] = q[j] != c[i][j];
+      p[i] = p[i] == c[i][j];  // flips when R_j is before L_i, i.e. when !c
+    }
+  }
+  const bool flip_l = op != CSG_INTERSECT, flip_r = op == CSG_UNION;
+#pragma unroll
+  for (int i = 0; i < ML; ++i) keep_l[i] = (p[i] != flip_l) && lv[i] < PRT_INF;
+#pragma unroll
+  for (int j = 0; j < MR; ++j) keep_r[j] = (q[j] != flip_r) && rv[j] < PRT_INF;
+  bool touched = true;
+  if (!box_implied) {  // wave-uniform
+    touched = box_touched(aabb, ray);
+  } else {
+    // list entries are finite or +inf, never NaN (leaves map NaN to +inf): v_min / v_max are exact
+    double lo = PRT_INF, hi = -PRT_INF;
+#pragma unroll
+    for (int i = 0; i < ML; ++i) {
+      lo = fmin(lo, keep_l[i] ? lv[i] : PRT_INF);
+      hi = fmax(hi, keep_l[i] ? lv[i] : -PRT_INF);
+    }
+#pragma unroll
+    for (int j = 0; j < MR; ++j) {
+      lo = fmin(lo, keep_r[j] ? rv[j] : PRT_INF);
+      hi = fmax(hi, keep_r[j] ? rv[j] : -PRT_INF);
+    }
+    const bool any = hi >= lo;  // false when nothing survived (lo = +inf, hi = -inf)
+    const bool robust = any && lo > -PRT_INF && (hi - lo) > 1e-6 * ((1.0 + fabs(lo)) + fabs(hi));
+    if (any && !robust) touched = box_touched(aabb, ray);
+  }
+#pragma unroll
+  for (int i = 0; i < ML; ++i) keep_l[i] = keep_l[i] && touched;
+#pragma unroll
+  for (int j = 0; j < MR; ++j) keep_r[j] = keep_r[j] && touched;
+}
+
+// nearest positive survivor of a node; ties go to the lower merged rank, and among equal values the
+// merged order is "left entries by index, then right entries by index" (stable, left first) -- the
+// order of this scan, so a strict '<' keeps the right one
+template <int ML, int MR>
+__device__ __forceinline__ void csg_root_pick(const double (&lv)[ML], const int (&lid)[ML],
+                                              const bool (&keep_l)[ML], const double (&rv)[MR],
+                                              const int (&rid)[MR], const bool (&keep_r)[MR],
+                                              double& node_t, int& node_prim) {
+  double best = PRT_INF;
+  int best_id = -1;
+#pragma unroll
+  for (int i = 0; i < ML; ++i) {
+    const bool better = keep_l[i] && lv[i] > 0 && lv[i] < best;
+    best = better ? lv[i] : best;
+    best_id = better ? lid[i] : best_id;
+  }
+#pragma unroll
+  for (int j = 0; j < MR; ++j) {
+    const bool better = keep_r[j] && rv[j] > 0 && rv[j] < best;
+    best = better ? rv[j] : best;
+    best_id = better ? rid[j] : best_id;
+  }
+  node_t = best;
+  node_prim = best_id;
+}
+
 template <int ML, int MR, bool LREG, bool RREG>
 __device__ __forceinline__ void csg_node(int op, int l_base, int r_base, int out_base,
                                          const double* __restrict__ aabb, const Ray8& ray,
@@ -599,82 +738,11 @@ __device__ __forceinline__ void csg_node(int op, int l_base, int r_base, int out
     if (RREG) { rv[j] = (j == 0) ? rb.t0 : rb.t1; rid[j] = rb.prim; }
     else { rv[j] = lists.get_t(r_base + j); rid[j] = lists.get_id(r_base + j); }
   }
-  // c(i,j) = L_i sorts before R_j.  Everything the keep rule needs is a parity: with p_i = (number
-  // of R entries before L_i) mod 2 and q_j = (number of L entries before-or-at R_j) mod 2, working the
-  // +-1 depths of array_csg through (own list alternates from +1, or from -1 for the right list
-  // of a DIFFERENCE, whose depth also starts at 1; "depth before" of the first merged entry is the
-  // np.roll wrap value, which the same algebra yields) gives
-  //     UNION       keep L_i = !p_i   keep R_j = !q_j      (depth != 0  xor  before != 0)
-  //     INTERSECT   keep L_i =  p_i   keep R_j =  q_j      (depth == 2  or   before == 2)
-  //     DIFFERENCE  keep L_i = !p_i   keep R_j =  q_j
-  // -- lane masks and scalar logic only; per-lane integers are needed only to place survivors.
   bool c[ML][MR];
-  bool p[ML], q[MR];
-#pragma unroll
-  for (int i = 0; i < ML; ++i) p[i] = false;
-#pragma unroll
-  for (int j = 0; j < MR; ++j) q[j] = false;
-#pragma unroll
-  for (int i = 0; i < ML; ++i) {
-#pragma unroll
-    for (int j = 0; j < MR; ++j) {
-      c[i][j] = lv[i] <= rv[j];
-      q[j] = q[j] != c[i][j];
-      p[i] = p[i] == c[i][j];  // flips when R_j is before L_i, i.e. when !c
-    }
-  }
-  const bool flip_l = op != CSG_INTERSECT, flip_r = op == CSG_UNION;
   bool keep_l[ML], keep_r[MR];
-#pragma unroll
-  for (int i = 0; i < ML; ++i) keep_l[i] = (p[i] != flip_l) && lv[i] < PRT_INF;
-#pragma unroll
-  for (int j = 0; j < MR; ++j) keep_r[j] = (q[j] != flip_r) && rv[j] < PRT_INF;
-  {
-    bool touched = true;
-    if (!box_implied) {  // wave-uniform
-      touched = box_touched(aabb, ray);
-    } else {
-      // list entries are finite or +inf, never NaN (leaves map NaN to +inf): v_min / v_max are exact
-      double lo = PRT_INF, hi = -PRT_INF;
-#pragma unroll
-      for (int i = 0; i < ML; ++i) {
-        lo = fmin(lo, keep_l[i] ? lv[i] : PRT_INF);
-        hi = fmax(hi, keep_l[i] ? lv[i] : -PRT_INF);
-      }
-#pragma unroll
-      for (int j = 0; j < MR; ++j) {
-        lo = fmin(lo, keep_r[j] ? rv[j] : PRT_INF);
-        hi = fmax(hi, keep_r[j] ? rv[j] : -PRT_INF);
-      }
-      const bool any = hi >= lo;  // false when nothing survived (lo = +inf, hi = -inf)
-      const bool robust = any && lo > -PRT_INF && (hi - lo) > 1e-6 * ((1.0 + fabs(lo)) + fabs(hi));
-      if (any && !robust) touched = box_touched(aabb, ray);
-    }
-#pragma unroll
-    for (int i = 0; i < ML; ++i) keep_l[i] = keep_l[i] && touched;
-#pragma unroll
-    for (int j = 0; j < MR; ++j) keep_r[j] = keep_r[j] && touched;
-  }
+  csg_keep<ML, MR>(op, lv, rv, aabb, ray, box_implied, keep_l, keep_r, c);
   if (is_root) {
-    // nearest positive survivor; ties go to the lower merged rank, and among equal values the merged
-    // order is "left entries by index, then right entries by index" (stable, left first) -- the
-    // order of this scan, so a strict '<' keeps the right one
-    double best = PRT_INF;
-    int best_id = -1;
-#pragma unroll
-    for (int i = 0; i < ML; ++i) {
-      const bool better = keep_l[i] && lv[i] > 0 && lv[i] < best;
-      best = better ? lv[i] : best;
-      best_id = better ? lid[i] : best_id;
-    }
-#pragma unroll
-    for (int j = 0; j < MR; ++j) {
-      const bool better = keep_r[j] && rv[j] > 0 && rv[j] < best;
-      best = better ? rv[j] : best;
-      best_id = better ? rid[j] : best_id;
-    }
-    node_t = best;
-    node_prim = best_id;
+    csg_root_pick<ML, MR>(lv, lid, keep_l, rv, rid, keep_r, node_t, node_prim);
     return;
   }
   int kept = 0;
@@ -757,6 +825,68 @@ __device__ __forceinline__ bool may_reach(const double* __restrict__ box, const 
   }
   const double slack = 1e-6 * (fabs(t_in) + fabs(t_out));
   return !never && !(t_in - slack > t_out + slack);
+}
+
+// ---- chain steps (I_CHAIN) ----------------------------------------------------------------------
+// The component's candidate for the running nearest hit, computed entirely in registers.  The first
+// node's survivors are not compacted: a dropped entry stays in place as +inf (see csg_keep), and the
+// scan order "left operand's entries, then right operand's" is the stable merged order among equal
+// values at every level, so ties resolve as in csg_node.  When no lane of the wave holds a positive
+// survivor after the first node, the third leaf is not evaluated (an INTERSECT / DIFFERENCE result
+// lies inside its left operand: the same argument as the interpreter's right-leaf skip).
+template <int T0, int T1, int T2>
+__device__ __forceinline__ void chain_candidate(const DevChain* __restrict__ ch, const Ray8& ray,
+                                                double& best_t, int& best_prim) {
+  double lv[2], rv[2];
+  surface_pair(T0, ch->leaf[0], ch->leaf[0] + 6, ray, lv[0], lv[1]);
+  surface_pair(T1, ch->leaf[1], ch->leaf[1] + 6, ray, rv[0], rv[1]);
+  bool keep_l[2], keep_r[2], c1[2][2];
+  csg_keep<2, 2>(ch->op1, lv, rv, ch->box1, ray, ch->implied1 != 0, keep_l, keep_r, c1);
+  const int id0 = ch->prim[0], id1 = ch->prim[1];
+  double t;
+  int prim;
+  if (T2 < 0) {
+    const int lid[2] = {id0, id0}, rid[2] = {id1, id1};
+    csg_root_pick<2, 2>(lv, lid, keep_l, rv, rid, keep_r, t, prim);
+  } else {
+    const double l4[4] = {keep_l[0] ? lv[0] : PRT_INF, keep_l[1] ? lv[1] : PRT_INF,
+                          keep_r[0] ? rv[0] : PRT_INF, keep_r[1] ? rv[1] : PRT_INF};
+    bool positive = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) positive = positive || (l4[k] > 0 && l4[k] < PRT_INF);
+    if (ch->op2 != CSG_UNION && __ballot(positive) == 0ull) return;
+    double r2[2];
+    surface_pair(T2 < 0 ? 0 : T2, ch->leaf[2], ch->leaf[2] + 6, ray, r2[0], r2[1]);
+    bool keep4[4], keep2[2], c2[4][2];
+    csg_keep<4, 2>(ch->op2, l4, r2, ch->box2, ray, ch->implied2 != 0, keep4, keep2, c2);
+    const int id2 = ch->prim[2];
+    const int lid[4] = {id0, id0, id1, id1}, rid[2] = {id2, id2};
+    csg_root_pick<4, 2>(l4, lid, keep4, r2, rid, keep2, t, prim);
+  }
+  if (t < best_t) {
+    best_t = t;
+    best_prim = prim;
+  }
+}
+
+__device__ __forceinline__ void chain_step(const DevChain* __restrict__ ch, int shape, const Ray8& ray,
+                                           double& best_t, int& best_prim) {
+  switch (shape) {  // wave-uniform
+    case CHAIN_SSC: chain_candidate<PRIM_SPHERE, PRIM_SPHERE, PRIM_CYLINDER>(ch, ray, best_t, best_prim); break;
+    case CHAIN_SSQ: chain_candidate<PRIM_SPHERE, PRIM_SPHERE, PRIM_CUBE>(ch, ray, best_t, best_prim); break;
+    case CHAIN_CSS: chain_candidate<PRIM_CYLINDER, PRIM_SPHERE, PRIM_SPHERE>(ch, ray, best_t, best_prim); break;
+    case CHAIN_QSS: chain_candidate<PRIM_CUBE, PRIM_SPHERE, PRIM_SPHERE>(ch, ray, best_t, best_prim); break;
+    case CHAIN_QQQ: chain_candidate<PRIM_CUBE, PRIM_CUBE, PRIM_CUBE>(ch, ray, best_t, best_prim); break;
+    case CHAIN_SC: chain_candidate<PRIM_SPHERE, PRIM_CYLINDER, -1>(ch, ray, best_t, best_prim); break;
+    case CHAIN_SQ: chain_candidate<PRIM_SPHERE, PRIM_CUBE, -1>(ch, ray, best_t, best_prim); break;
+    case CHAIN_CS: chain_candidate<PRIM_CYLINDER, PRIM_SPHERE, -1>(ch, ray, best_t, best_prim); break;
+    case CHAIN_QS: chain_candidate<PRIM_CUBE, PRIM_SPHERE, -1>(ch, ray, best_t, best_prim); break;
+    case CHAIN_CB: chain_candidate<PRIM_CYLINDER, PRIM_PARABOLOID, -1>(ch, ray, best_t, best_prim); break;
+    case CHAIN_QB: chain_candidate<PRIM_CUBE, PRIM_PARABOLOID, -1>(ch, ray, best_t, best_prim); break;
+    case CHAIN_PC: chain_candidate<PRIM_PLANE, PRIM_CYLINDER, -1>(ch, ray, best_t, best_prim); break;
+    case CHAIN_PQ: chain_candidate<PRIM_PLANE, PRIM_CUBE, -1>(ch, ray, best_t, best_prim); break;
+    default: chain_candidate<PRIM_PARABOLOID, PRIM_CYLINDER, -1>(ch, ray, best_t, best_prim); break;
+  }
 }
 
 // One program step for one ray (state: the two register pairs and the running nearest hit).
@@ -860,6 +990,14 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
     rb[k] = Pair{PRT_INF, PRT_INF, -1};
   }
   for (int pc = 0; pc < n_instr; ++pc) {
+    if (!RENDER && R == 1) {  // trace programs: a whole component may be one chain record
+      const int kind = code[pc].kind, shape = code[pc].a0;
+      if (kind == I_CHAIN) {
+        chain_step(reinterpret_cast<const DevChain*>(code + pc), shape, ray[0], best_t[0], best_prim[0]);
+        pc += CHAIN_SLOTS - 1;
+        continue;
+      }
+    }
     const DevInstr step = code[pc];  // the whole record, one batch of scalar loads
     if (CULL && !RENDER && step.kind == I_BOX) {
       bool wanted = false;

@@ -211,7 +211,7 @@ __device__ __forceinline__ Shaded interact_compute(const SceneDev& scene, const 
   s.ok = true;
   // tilt columns: pre-hit direction over its 3-norm (_pyrayt.py:176-177)
   const double tilt = norm3(r.dx, r.dy, r.dz);
-  s.tx = r.dx / tilt; s.ty = r.dy / tilt; s.tz = r.dz / tilt;
+  div3(r.dx, r.dy, r.dz, tilt, s.tx, s.ty, s.tz);
   // material dispatch: the primitive table is wave-uniform data, so lanes that hit the same
   // surface shade together and the loop runs once per distinct surface hit in the wave
   unsigned long long todo = __ballot(true);
@@ -433,7 +433,78 @@ __device__ long long g_stamps[16384 * 4 * 8];
 #define STAMP(k) do {} while (0)
 #endif
 
-#define PARK(k) lds_dyn[(k) * PRT_BLOCK + threadIdx.x]
+// parking rows sit behind the hit lists (f64 rows, then int32 rows = half an f64 row each)
+#define PARK(k) lds_dyn[(park_base + (k)) * PRT_BLOCK + threadIdx.x]
+#define PRT_PARK_ROWS 8
+
+// ---- row-major HBM access through buffer descriptors ----------------------------------------------
+// Every access of the generation kernel is "element (uniform column + lane offset) of row k".  A
+// flat global_load/store needs the 64-bit address per lane (one VALU add per row plus the scalar
+// 64-bit row multiply); a buffer access takes the row's base from four SGPRs and one 32-bit lane
+// offset shared by all rows, so a row costs two scalar adds and the memory instruction itself.
+typedef unsigned int prt_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const double* base) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffff8, 0x00020000);
+}
+__device__ __forceinline__ double row_load(const double* base, unsigned lane_bytes) {
+  const prt_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(row_rsrc(base), lane_bytes, 0, 0);
+  return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ __forceinline__ void row_store(double* base, unsigned lane_bytes, double value) {
+  prt_u32x2 v;
+  v.x = (unsigned)__double2loint(value);
+  v.y = (unsigned)__double2hiint(value);
+  __builtin_amdgcn_raw_buffer_store_b64(v, row_rsrc(base), lane_bytes, 0, 0);
+}
+// a value every lane holds identically, moved to SGPRs so that addresses built on it are scalar
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(v & 0xffffffffll));
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+  return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+
+// interact_store through buffer descriptors: `rec` / `nxt` already point at this workgroup's first
+// column of row 0, lane offsets are rank * 8 bytes
+__device__ __forceinline__ void interact_store_rows(const Shaded& s, const Ray8& r, bool carry, unsigned row_bytes,
+                                                    unsigned next_bytes, double* __restrict__ nxt, int64_t ld_next,
+                                                    double* __restrict__ rec, int64_t ld_rows,
+                                                    double next_generation, int relaunch, double ray_offset) {
+  row_store(rec + PRT_COL_GENERATION * ld_rows, row_bytes, s.generation);
+  row_store(rec + PRT_COL_INTENSITY * ld_rows, row_bytes, s.intensity);
+  row_store(rec + PRT_COL_WAVELENGTH * ld_rows, row_bytes, s.wavelength);
+  row_store(rec + PRT_COL_INDEX * ld_rows, row_bytes, s.index_in);
+  row_store(rec + PRT_COL_ID * ld_rows, row_bytes, s.id);
+  row_store(rec + PRT_COL_SURFACE * ld_rows, row_bytes, s.surface_id);
+  row_store(rec + PRT_COL_X0 * ld_rows, row_bytes, r.ox);
+  row_store(rec + PRT_COL_Y0 * ld_rows, row_bytes, r.oy);
+  row_store(rec + PRT_COL_Z0 * ld_rows, row_bytes, r.oz);
+  row_store(rec + PRT_COL_X1 * ld_rows, row_bytes, s.px);
+  row_store(rec + PRT_COL_Y1 * ld_rows, row_bytes, s.py);
+  row_store(rec + PRT_COL_Z1 * ld_rows, row_bytes, s.pz);
+  row_store(rec + PRT_COL_XTILT * ld_rows, row_bytes, s.tx);
+  row_store(rec + PRT_COL_YTILT * ld_rows, row_bytes, s.ty);
+  row_store(rec + PRT_COL_ZTILT * ld_rows, row_bytes, s.tz);
+  if (carry) {
+    double qx = s.px, qy = s.py, qz = s.pz, qw = s.pw;
+    if (relaunch) {
+      qx = s.px + ray_offset * s.dx; qy = s.py + ray_offset * s.dy; qz = s.pz + ray_offset * s.dz;
+      qw = s.pw + ray_offset * s.dw;
+    }
+    row_store(nxt + 0 * ld_next, next_bytes, qx);
+    row_store(nxt + 1 * ld_next, next_bytes, qy);
+    row_store(nxt + 2 * ld_next, next_bytes, qz);
+    row_store(nxt + 3 * ld_next, next_bytes, qw);
+    row_store(nxt + 4 * ld_next, next_bytes, s.dx);
+    row_store(nxt + 5 * ld_next, next_bytes, s.dy);
+    row_store(nxt + 6 * ld_next, next_bytes, s.dz);
+    row_store(nxt + 7 * ld_next, next_bytes, s.dw);
+    row_store(nxt + 8 * ld_next, next_bytes, next_generation);
+    row_store(nxt + 9 * ld_next, next_bytes, s.intensity);
+    row_store(nxt + 10 * ld_next, next_bytes, s.wavelength);
+    row_store(nxt + 11 * ld_next, next_bytes, s.index);
+    row_store(nxt + 12 * ld_next, next_bytes, s.id);
+  }
+}
 
 // Register-allocated for 5 waves per SIMD (96 VGPRs, no spills -- possible because the record
 // columns known before the shading wait in LDS, see PARK).  Measured on MI355X, same box,
@@ -474,14 +545,24 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
 
   const int64_t i = (int64_t)tile * PRT_BLOCK + threadIdx.x;
   const LaneLists lists = lane_lists(scene.lds_slots);
+  const int park_base = (3 * scene.lds_slots + 1) / 2;
   Ray8 r = {0, 0, 0, 1, 0, 0, 0, 0};
   double t = PRT_INF;
   int prim = -1;
   bool live = false, carry = false;
-  Meta5 meta = {0, 0, 0, 0, 0};
   STAMP(0);
   if (i < n && !failed) {
-    r = load_ray8(rays, ld, i);
+    // all 13 rows in one burst; the five metadata rows go straight to the lane's parking slots in
+    // LDS (nothing needs them before the shading), so no second trip to HBM after the hit phase
+    const double* tile_rays = rays + (int64_t)tile * PRT_BLOCK;
+    const unsigned lane_bytes = threadIdx.x * 8u;
+    r.ox = row_load(tile_rays + 0 * ld, lane_bytes); r.oy = row_load(tile_rays + 1 * ld, lane_bytes);
+    r.oz = row_load(tile_rays + 2 * ld, lane_bytes); r.ow = row_load(tile_rays + 3 * ld, lane_bytes);
+    r.dx = row_load(tile_rays + 4 * ld, lane_bytes); r.dy = row_load(tile_rays + 5 * ld, lane_bytes);
+    r.dz = row_load(tile_rays + 6 * ld, lane_bytes); r.dw = row_load(tile_rays + 7 * ld, lane_bytes);
+    PARK(0) = row_load(tile_rays + 8 * ld, lane_bytes); PARK(1) = row_load(tile_rays + 9 * ld, lane_bytes);
+    PARK(2) = row_load(tile_rays + 10 * ld, lane_bytes); PARK(3) = row_load(tile_rays + 11 * ld, lane_bytes);
+    PARK(4) = row_load(tile_rays + 12 * ld, lane_bytes);
 #ifdef PRT_TIMING
     if (r.ox + r.oy + r.oz + r.ow + r.dx + r.dy + r.dz + r.dw == 1.2345e300) t = 0;  // force the wait here
     STAMP(1);
@@ -517,14 +598,11 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   // registers across the fp64-heavy shading.
   Shaded sh;
   sh.ok = true;
-  if (live) meta = load_meta(rays, ld, i);  // (loading these up front measured no faster)
-#ifdef PRT_TIMING
-  if (meta.generation + meta.intensity + meta.wavelength + meta.index + meta.id == 1.2345e300) t = 0;
   STAMP(4);
-#endif
   if (live) {
-    PARK(0) = meta.generation; PARK(1) = meta.intensity; PARK(2) = meta.wavelength;
-    PARK(3) = meta.index; PARK(4) = meta.id;
+    Meta5 meta = {0, 0, 0, 0, 0};  // the shading reads wavelength and index only; the rest stays parked
+    meta.wavelength = PARK(2);
+    meta.index = PARK(3);
     PARK(5) = r.ox; PARK(6) = r.oy; PARK(7) = r.oz;
     sh = interact_compute(scene, meta, r, t, prim);
   }
@@ -577,8 +655,9 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   interact_store(sh, r, carry, threadIdx.x, threadIdx.x, next, ld_next, rows, ld_rows,
                  next_generation, relaunch, ray_offset);
 #else
-  interact_store(sh, r, carry, row_base + excl_live + live_rank, excl_carry + carry_rank, next,
-                 ld_next, rows, ld_rows, next_generation, relaunch, ray_offset);
+  interact_store_rows(sh, r, carry, (unsigned)live_rank * 8u, (unsigned)carry_rank * 8u,
+                      next + uniform64(excl_carry), ld_next, rows + uniform64(row_base + excl_live), ld_rows,
+                      next_generation, relaunch, ray_offset);
 #endif
   if (!sh.ok) atomicExch(&ctrl->error, PRT_ERR_UNTRACABLE);
   STAMP(7);
@@ -802,9 +881,9 @@ extern "C" int prt_device_count(void) {
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + PRT_BLOCK - 1) / PRT_BLOCK); }
 static inline size_t lds_bytes(int slots) { return (size_t)slots * PRT_BLOCK * 12; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-// the fused kernel re-uses the hit-list area as a parking lot for 8 float64 per lane
+// the fused kernel parks 8 float64 per lane behind the hit lists
 static inline size_t lds_bytes_fused(int slots) {
-  return std::max(lds_bytes(slots), (size_t)8 * PRT_BLOCK * sizeof(double));
+  return (size_t)((3 * slots + 1) / 2 + 8) * PRT_BLOCK * sizeof(double);
 }
 
 static SceneDev trace_scene_dev(const prt_scene* s, const DeviceCopy* c) {
@@ -1129,8 +1208,7 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
   const bool two_per_lane = rpl_env && rpl_env[0] == '2' && 2 * lds <= kMaxLdsBytes;
 #endif
   GenCtrl* host_gen = c->host_gen + 1;  // slot -1 receives the control header
-  bool culls = false;
-  for (const DevInstr& in : s->trace_program.code) culls = culls || in.kind == I_BOX;
+  const bool culls = count_steps(s->trace_program.code, I_BOX) > 0;
   int64_t bound = n, total_rows = 0;
   int g = 0, error = 0;
   bool done = false;

@@ -168,6 +168,7 @@ struct Compiler {
 static void shift_slots(std::vector<DevInstr>& code, size_t from, int shift) {
   for (size_t k = from; k < code.size(); ++k) {
     DevInstr& in = code[k];
+    if (in.kind == I_CHAIN) { k += CHAIN_SLOTS - 1; continue; }  // no lists; the next slots are raw data
     if (in.kind == I_LEAF && in.a1 == OPER_LDS) in.a2 += shift;
     if (in.kind == I_LEAF && in.pad[0] == 1 && in.a3 == OPER_LDS) in.a4 += shift;
     if (in.kind == I_CSG) {
@@ -256,13 +257,80 @@ static bool solid_bounds(const prt_scene* s, int node, double* box) {
 }
 
 enum { ROOT_NONE = 0, ROOT_TRACE = 1, ROOT_RENDER = 2 };
+
+// count the steps of one kind in a program (a chain record spans CHAIN_SLOTS raw slots)
+static int count_steps(const std::vector<DevInstr>& code, int kind) {
+  int n = 0;
+  for (size_t k = 0; k < code.size(); ++k) {
+    n += code[k].kind == kind ? 1 : 0;
+    if (code[k].kind == I_CHAIN) k += CHAIN_SLOTS - 1;
+  }
+  return n;
+}
+
+// Is component `root_node` a left-deep chain of two or three leaves whose primitive types have a
+// compiled chain body?  Fills the record if so.
+static bool chain_record(const prt_scene* s, int root_node, const Compiler& c, DevChain* out) {
+  static const bool chain_off = std::getenv("PRT_NO_CHAIN") != nullptr;  // experiment knob
+  if (chain_off) return false;
+  const prt_node& top = s->nodes[root_node];
+  if (top.op == PRT_NODE_LEAF || s->nodes[top.right].op != PRT_NODE_LEAF) return false;
+  int leaves[3], n_leaves, nodes[2];
+  const prt_node& l = s->nodes[top.left];
+  if (l.op == PRT_NODE_LEAF) {
+    n_leaves = 2;
+    leaves[0] = top.left; leaves[1] = top.right;
+    nodes[0] = root_node; nodes[1] = -1;
+  } else {
+    if (s->nodes[l.left].op != PRT_NODE_LEAF || s->nodes[l.right].op != PRT_NODE_LEAF) return false;
+    n_leaves = 3;
+    leaves[0] = l.left; leaves[1] = l.right; leaves[2] = top.right;
+    nodes[0] = top.left; nodes[1] = root_node;
+  }
+  int types[3] = {-1, -1, -1};
+  for (int k = 0; k < n_leaves; ++k) types[k] = s->prims[s->nodes[leaves[k]].prim].type;
+  static const struct { int shape, t0, t1, t2; } table[] = {
+      {CHAIN_SSC, PRIM_SPHERE, PRIM_SPHERE, PRIM_CYLINDER}, {CHAIN_SSQ, PRIM_SPHERE, PRIM_SPHERE, PRIM_CUBE},
+      {CHAIN_CSS, PRIM_CYLINDER, PRIM_SPHERE, PRIM_SPHERE}, {CHAIN_QSS, PRIM_CUBE, PRIM_SPHERE, PRIM_SPHERE},
+      {CHAIN_QQQ, PRIM_CUBE, PRIM_CUBE, PRIM_CUBE},
+      {CHAIN_SC, PRIM_SPHERE, PRIM_CYLINDER, -1}, {CHAIN_SQ, PRIM_SPHERE, PRIM_CUBE, -1},
+      {CHAIN_CS, PRIM_CYLINDER, PRIM_SPHERE, -1}, {CHAIN_QS, PRIM_CUBE, PRIM_SPHERE, -1},
+      {CHAIN_CB, PRIM_CYLINDER, PRIM_PARABOLOID, -1}, {CHAIN_QB, PRIM_CUBE, PRIM_PARABOLOID, -1},
+      {CHAIN_PC, PRIM_PLANE, PRIM_CYLINDER, -1}, {CHAIN_PQ, PRIM_PLANE, PRIM_CUBE, -1},
+      {CHAIN_BC, PRIM_PARABOLOID, PRIM_CYLINDER, -1}};
+  int shape = -1;
+  for (const auto& row : table)
+    if (row.t0 == types[0] && row.t1 == types[1] && row.t2 == types[2]) shape = row.shape;
+  if (shape < 0) return false;
+  std::memset(out, 0, sizeof(*out));
+  out->kind = I_CHAIN;
+  out->shape = shape;
+  out->n_leaves = n_leaves;
+  out->op1 = s->nodes[nodes[0]].op;
+  out->implied1 = c.box_contains_solid(nodes[0]) ? 1 : 0;
+  for (int k = 0; k < 6; ++k) out->box1[k] = s->nodes[nodes[0]].aabb[k];
+  if (n_leaves == 3) {
+    out->op2 = s->nodes[nodes[1]].op;
+    out->implied2 = c.box_contains_solid(nodes[1]) ? 1 : 0;
+    for (int k = 0; k < 6; ++k) out->box2[k] = s->nodes[nodes[1]].aabb[k];
+  }
+  for (int k = 0; k < n_leaves; ++k) {
+    const int prim = s->nodes[leaves[k]].prim;
+    const prt_prim& pr = s->prims[prim];
+    out->prim[k] = prim;
+    for (int j = 0; j < 6; ++j) out->leaf[k][j] = pr.params[j];
+    for (int j = 0; j < 12; ++j) out->leaf[k][6 + j] = pr.minv[j];  // rows 0..2 of M^-1
+  }
+  return true;
+}
 static Operand compile_component(const prt_scene* s, int root_node, std::vector<DevInstr>& code,
                                  int root_rule, int* slots) {
   // a scene of several components gets a cull step in front of each: most rays can reach only one
   // or two of them (see may_reach); with one or two components the test would cost more than it saves
   size_t box_at = (size_t)-1;
-  static const bool cull_off = std::getenv("PRT_NO_CULL") != nullptr;  // experiment knob
-  if (root_rule == ROOT_TRACE && s->roots.size() >= 3 && !cull_off) {
+  static const bool cull_off = std::getenv("PRT_NO_CULL") != nullptr;  // experiment knobs
+  static const int cull_min = std::getenv("PRT_CULL_MIN") ? std::atoi(std::getenv("PRT_CULL_MIN")) : 3;
+  if (root_rule == ROOT_TRACE && (int)s->roots.size() >= cull_min && !cull_off) {
     DevInstr in = Compiler::blank(I_BOX);
     double* box = in.data;
     if (solid_bounds(s, root_node, box)) {
@@ -282,6 +350,15 @@ static Operand compile_component(const prt_scene* s, int root_node, std::vector<
   Compiler c{s, code};
   c.positive_only = root_rule == ROOT_TRACE;
   Operand res;
+  DevChain chain;
+  if (root_rule == ROOT_TRACE && chain_record(s, root_node, c, &chain)) {
+    // the whole component is one register-only step: no lists, no LDS slots
+    DevInstr raw[CHAIN_SLOTS];
+    std::memcpy(raw, &chain, sizeof(chain));
+    for (const DevInstr& slot : raw) code.push_back(slot);
+    if (box_at != (size_t)-1) code[box_at].a0 = CHAIN_SLOTS;
+    return Operand{OPER_REGA, 0, 0};
+  }
   if (s->nodes[root_node].op == PRT_NODE_LEAF)
     res = c.leaf(root_node, OPER_REGA, 0);
   else
@@ -401,8 +478,7 @@ extern "C" void prt_scene_destroy(prt_scene* s) {
 
 extern "C" int prt_scene_info(const prt_scene* s, int64_t* out8) {
   if (!s || !out8) return fail(PRT_ERR_ARG, "null argument");
-  int64_t culls = 0;
-  for (const DevInstr& in : s->trace_program.code) culls += in.kind == I_BOX ? 1 : 0;
+  const int64_t culls = count_steps(s->trace_program.code, I_BOX);
   out8[0] = (int64_t)s->prims.size();
   out8[1] = (int64_t)s->roots.size();
   out8[2] = (int64_t)s->trace_program.code.size();
@@ -410,7 +486,7 @@ extern "C" int prt_scene_info(const prt_scene* s, int64_t* out8) {
   out8[4] = culls;
   out8[5] = (int64_t)s->render_program.code.size();
   out8[6] = s->render_program.lds_slots;
-  out8[7] = 0;
+  out8[7] = count_steps(s->trace_program.code, I_CHAIN);
   return PRT_OK;
 }
 
