@@ -37,6 +37,12 @@ struct DevPrim {
   int32_t type, mat_kind, normal_scale, pad;
 };
 
+// the same table seen through the constant address space (scalar loads when the index is uniform)
+typedef const __attribute__((address_space(4))) DevPrim* ConstPrimPtr;
+__device__ __forceinline__ ConstPrimPtr const_prim(const DevPrim* prims, int index) {
+  return (ConstPrimPtr)(unsigned long long)(prims + index);
+}
+
 enum { I_LEAF = 0, I_CSG = 1, I_ROOT = 2, I_BOX = 3, I_CHAIN = 4 };
 enum { OPER_REGA = 0, OPER_REGB = 1, OPER_LDS = 2 };
 enum { CSG_UNION = 1, CSG_INTERSECT = 2, CSG_DIFFERENCE = 3 };
@@ -109,8 +115,10 @@ __device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : 
 __device__ __forceinline__ double nan_to_inf(double x) { return x == x ? x : PRT_INF; }
 
 // row r of (M . v) with the accumulation order of a dgemm micro-kernel: fma chain from 0
-__device__ __forceinline__ double row_dot(const double* __restrict__ m, int r, double x, double y,
-                                          double z, double w) {
+// (M: pointer to 16 doubles in any address space -- the shading reads the table through the
+// constant address space so that a wave-uniform record is fetched with scalar loads)
+template <class M>
+__device__ __forceinline__ double row_dot(M m, int r, double x, double y, double z, double w) {
   double acc = m[4 * r + 0] * x;
   acc = fma(m[4 * r + 1], y, acc);
   acc = fma(m[4 * r + 2], z, acc);
@@ -118,8 +126,8 @@ __device__ __forceinline__ double row_dot(const double* __restrict__ m, int r, d
   return acc;
 }
 // row r of (M^T . v)
-__device__ __forceinline__ double col_dot(const double* __restrict__ m, int r, double x, double y,
-                                          double z, double w) {
+template <class M>
+__device__ __forceinline__ double col_dot(M m, int r, double x, double y, double z, double w) {
   double acc = m[0 + r] * x;
   acc = fma(m[4 + r], y, acc);
   acc = fma(m[8 + r], z, acc);
@@ -355,14 +363,14 @@ __device__ __forceinline__ void object_normal(int type, const double* __restrict
 
 // ---- TracerSurface.get_world_normals (world_objects.py:401-418) -------------------------------
 // p = world-space point (4 comps).  Returns the world-space unit normal times normal_scale.
-__device__ __forceinline__ void world_normal(const DevPrim* __restrict__ p, double px, double py,
-                                             double pz, double pw, double& nx, double& ny,
-                                             double& nz) {
-  const double* m = p->minv;
+template <class PrimPtr>
+__device__ __forceinline__ void world_normal(PrimPtr p, double px, double py, double pz, double pw,
+                                             double& nx, double& ny, double& nz) {
+  const auto m = p->minv;
   const double lx = row_dot(m, 0, px, py, pz, pw);
   const double ly = row_dot(m, 1, px, py, pz, pw);
   const double lz = row_dot(m, 2, px, py, pz, pw);
-  const double* q = p->params;
+  const auto q = p->params;
   double ax, ay, az;  // object-space normal (w = 0)
   bool normalise = true;
   switch (p->type) {
@@ -408,9 +416,10 @@ __device__ __forceinline__ void world_normal(const DevPrim* __restrict__ p, doub
 }
 
 // ---- materials --------------------------------------------------------------------------------
-__device__ __forceinline__ double glass_index(const DevPrim* __restrict__ p, double wavelength) {
+template <class PrimPtr>
+__device__ __forceinline__ double glass_index(PrimPtr p, double wavelength) {
   if (p->mat_kind == MAT_CONST) return p->coef[0];  // materials.py:112-118
-  const double* k = p->coef;                          // materials.py:136-145
+  const auto k = p->coef;                             // materials.py:136-145
   const double w2 = wavelength * wavelength;
   return sqrt(((1 + (k[0] * w2) / (w2 - k[3])) + (k[1] * w2) / (w2 - k[4])) +
               (k[2] * w2) / (w2 - k[5]));
@@ -465,10 +474,10 @@ __device__ __forceinline__ void refract4(double vx, double vy, double vz, double
 // tilt columns.  When dw == 0, norm4(d) is bit-identical to norm3(d) (adding +0 is exact), so
 // the refraction's own normalisation d / |d| (operations.py:125) IS that vector and its
 // square root and divisions are not repeated.
-__device__ __forceinline__ bool shade(const DevPrim* __restrict__ p, double px, double py,
-                                      double pz, double pw, double& dx, double& dy, double& dz,
-                                      double& dw, double wavelength, double& index, double tx,
-                                      double ty, double tz) {
+template <class PrimPtr>
+__device__ __forceinline__ bool shade(PrimPtr p, double px, double py, double pz, double pw, double& dx,
+                                      double& dy, double& dz, double& dw, double wavelength,
+                                      double& index, double tx, double ty, double tz) {
   const int kind = p->mat_kind;
   if (kind == MAT_NONE) return false;
   if (kind == MAT_ABSORBER) {  // materials.py:47-50

@@ -58,8 +58,11 @@ struct TraceCtrl {
 
 // dead-ray rule of _pyrayt.py:415-420: absorbed (|d| ~ 0 before the interaction) or no hit;
 // the intensity threshold is a no-op upstream (Q2).
+// |d| <= 1e-8 is decided on |d|^2: sqrt is monotonic and correctly rounded, and 0x1.cd2b297d889bdp-54
+// is the largest double whose square root does not exceed the double 1e-8 (NaN compares false both ways)
 __device__ __forceinline__ bool is_live(const Ray8& r, int prim) {
-  return !(near0(norm4(r.dx, r.dy, r.dz, r.dw)) || prim < 0);
+  const double len2 = ((r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz) + r.dw * r.dw;
+  return !(len2 <= 0x1.cd2b297d889bdp-54 || prim < 0);
 }
 
 // prt_interact receives surface ids from the caller: map one back to its primitive (-1 = none)
@@ -214,6 +217,13 @@ __device__ __forceinline__ Shaded interact_compute(const SceneDev& scene, const 
   div3(r.dx, r.dy, r.dz, tilt, s.tx, s.ty, s.tz);
   // material dispatch: the primitive table is wave-uniform data, so lanes that hit the same
   // surface shade together and the loop runs once per distinct surface hit in the wave
+  // (v_readfirstlane of the lanes still pending: the index is in an SGPR, so the compiler knows the
+  // table entry is uniform and fetches it with scalar loads -- one batch for the whole record --
+  // instead of per-lane vector loads that all hit the same address)
+#ifndef PRT_SCALAR_WATERFALL
+  // (the table reads below are per-lane vector loads of one address -- a single L1 line per field
+  // group, fetched in one batch.  The scalar-load form of this loop, kept under PRT_SCALAR_WATERFALL,
+  // measured 7 % slower for the whole kernel: its reads are dependent round trips to the scalar cache.)
   unsigned long long todo = __ballot(true);
   while (todo) {
     const int leader = __ffsll((long long)todo) - 1;
@@ -225,6 +235,24 @@ __device__ __forceinline__ Shaded interact_compute(const SceneDev& scene, const 
       s.surface_id = p->surface_id;
     }
     todo &= ~__ballot(prim == cur);
+  }
+  return s;
+#endif
+  for (bool pending = true; __ballot(pending) != 0ull;) {
+    if (pending) {
+      const int cur = __builtin_amdgcn_readfirstlane(prim);
+      // compare against an opaque copy: inside `if (prim == cur)` the optimiser would otherwise
+      // substitute the per-lane `prim` for `cur` and turn the table reads back into vector loads
+      int same = cur;
+      asm volatile("" : "+s"(same));
+      if (prim == same) {
+        const ConstPrimPtr p = const_prim(scene.prims, cur);
+        s.ok = shade(p, s.px, s.py, s.pz, s.pw, s.dx, s.dy, s.dz, s.dw, s.wavelength, s.index,
+                     s.tx, s.ty, s.tz);
+        s.surface_id = p->surface_id;
+        pending = false;
+      }
+    }
   }
   return s;
 }
@@ -569,7 +597,11 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
 #endif
     nearest_hit<false, CULL>(scene.prims, scene.code, scene.n_instr, r, lists, t, prim);
     live = is_live(r, prim);
-    carry = live && (keep_absorbed || scene.prims[prim].mat_kind != MAT_ABSORBER);
+    // absorbed rays are recorded and dropped; which primitives absorb is a bit mask for the first 64
+    // (one scalar test instead of a per-lane table lookup in HBM)
+    bool absorbs = false;
+    if (live) absorbs = prim < 64 ? ((scene.absorber_mask >> prim) & 1ull) != 0 : scene.prims[prim].mat_kind == MAT_ABSORBER;
+    carry = live && (keep_absorbed || !absorbs);
   }
   // workgroup aggregate and ranks: wave ballots + popcounts, four waves combined through LDS
   STAMP(2);
@@ -887,7 +919,10 @@ static inline size_t lds_bytes_fused(int slots) {
 }
 
 static SceneDev trace_scene_dev(const prt_scene* s, const DeviceCopy* c) {
-  return SceneDev{c->prims, c->trace_code, (int)s->trace_program.code.size(), s->trace_program.lds_slots};
+  SceneDev sd{c->prims, c->trace_code, (int)s->trace_program.code.size(), s->trace_program.lds_slots};
+  for (size_t p = 0; p < s->dev_prims.size() && p < 64; ++p)
+    if (s->dev_prims[p].mat_kind == MAT_ABSORBER) sd.absorber_mask |= 1ull << p;
+  return sd;
 }
 
 extern "C" int prt_intersect(prt_scene* s, int device, int root, const double* rays, int64_t n,

@@ -29,6 +29,7 @@ struct SceneDev {
   const DevInstr* code;
   int n_instr;
   int lds_slots;
+  unsigned long long absorber_mask = 0;  // bit p: primitive p (< 64) has the absorbing material
 };
 
 struct Program {
