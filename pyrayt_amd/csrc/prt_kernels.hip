@@ -381,6 +381,31 @@ struct FusedCtrl {
   int64_t rows_cap;
 };
 
+// What the host needs from a batch of generations, in host-mapped (fine-grained) memory: the device
+// writes it at the end of the batch and the host spins on `epoch` -- no copy engine, no interrupt.
+struct HostMirror {
+  unsigned long long epoch;  // written last, system scope
+  int32_t error;
+  int32_t pad[13];
+  GenCtrl gen[kMaxBatch + 4];
+};
+static_assert(offsetof(HostMirror, gen) == 64, "mirror header");
+
+__global__ void k_publish(const FusedCtrl* __restrict__ ctrl, const GenCtrl* __restrict__ gen, int count,
+                          HostMirror* host, unsigned long long epoch) {
+  const int k = threadIdx.x;
+  if (k < count) {
+    host->gen[k].n_in = gen[k].n_in;
+    host->gen[k].row_base = gen[k].row_base;
+    host->gen[k].n_live = gen[k].n_live;
+    host->gen[k].n_carry = gen[k].n_carry;
+  }
+  if (k == 0) host->error = ctrl->error;
+  __threadfence_system();
+  __syncthreads();
+  if (k == 0) __hip_atomic_store(&host->epoch, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 #define PRT_ERR_STALL (-100) /* internal: look-back gave up -> host falls back to the unfused path */
 
 // tile status word for the decoupled look-back: [63:62] status, [61:31] live, [30:0] carried.
@@ -550,7 +575,8 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
              int64_t ld_next, double* __restrict__ rows, int64_t ld_rows, FusedCtrl* __restrict__ ctrl,
              GenCtrl* __restrict__ gen, int g, unsigned long long* __restrict__ tiles_cur,
              unsigned long long* __restrict__ tiles_next, double next_generation, int relaunch,
-             double ray_offset, int keep_absorbed) {
+             double ray_offset, int keep_absorbed, HostMirror* mirror, unsigned long long epoch,
+             int mirror_slot, int batch_last) {
   __shared__ int s_wave_live[4], s_wave_carry[4];
   __shared__ unsigned s_excl[2];
   // A ticket from one atomic word would also give start-ordered tile numbers, but a single
@@ -659,12 +685,31 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   const int64_t last_tile = (n - 1) / PRT_BLOCK;
   if (tile == last_tile && threadIdx.x == 0) {  // totals are known here: hand over to g + 1
     const int64_t total_live = excl_live + agg_live, total_carry = excl_carry + agg_carry;
+    const int64_t next_in = (total_live == 0) ? 0 : total_carry;
     gen[g].n_live = total_live;
     gen[g].n_carry = total_carry;
-    gen[g + 1].n_in = (total_live == 0) ? 0 : total_carry;
+    gen[g + 1].n_in = next_in;
     gen[g + 1].row_base = row_base + total_live;
+    if (mirror) {
+      // The host is told from here, not by a copy after the launch: the counts of this generation go to
+      // host-mapped memory, and the generation that ends the trace (or the batch) raises the epoch word
+      // the host spins on.  Errors that can still be raised after this point are ruled out by the
+      // caller (scenes with untracable materials take the k_publish path).
+      mirror->gen[mirror_slot].n_in = n;
+      mirror->gen[mirror_slot].row_base = row_base;
+      mirror->gen[mirror_slot].n_live = total_live;
+      mirror->gen[mirror_slot].n_carry = total_carry;
+      if (next_in == 0 || batch_last) {
+        mirror->gen[mirror_slot + 1].n_in = next_in;
+        int err = __hip_atomic_load(&ctrl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (err == 0 && row_base + total_live > ld_rows) err = PRT_ERR_ROWS_CAP;
+        mirror->error = err;
+        __threadfence_system();
+        __hip_atomic_store(&mirror->epoch, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
-  if (row_base + excl_live + agg_live > ctrl->rows_cap) {  // uniform per workgroup
+  if (row_base + excl_live + agg_live > ld_rows) {  // uniform per workgroup (ld_rows == rows_cap)
     if (threadIdx.x == 0) atomicExch(&ctrl->error, PRT_ERR_ROWS_CAP);
     return;
   }
@@ -787,7 +832,7 @@ k_generation2(SceneDev scene, const double* __restrict__ rays, int64_t ld, doubl
     gen[g + 1].n_in = (total_live == 0) ? 0 : total_carry;
     gen[g + 1].row_base = row_base + total_live;
   }
-  if (row_base + excl_live + agg_live > ctrl->rows_cap) {  // uniform per workgroup
+  if (row_base + excl_live + agg_live > ld_rows) {  // uniform per workgroup (ld_rows == rows_cap)
     if (threadIdx.x == 0) atomicExch(&ctrl->error, PRT_ERR_ROWS_CAP);
     return;
   }
@@ -804,8 +849,7 @@ k_generation2(SceneDev scene, const double* __restrict__ rays, int64_t ld, doubl
 
 // start of a fused trace: clear the control slots and tile buffer 0
 __global__ void k_fused_init(FusedCtrl* ctrl, GenCtrl* gen, int n_gen_slots,
-                             unsigned long long* tiles0, int64_t n_tiles, int64_t n, int64_t rows_cap,
-                             int test_stall) {
+                             unsigned long long* tiles0, int64_t n_tiles, int64_t n, int test_stall) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t k = i; k < n_tiles; k += stride) tiles0[k] = TILE_INVALID;
@@ -815,7 +859,28 @@ __global__ void k_fused_init(FusedCtrl* ctrl, GenCtrl* gen, int n_gen_slots,
     if (k == 0) z.n_in = n;
     gen[k] = z;
   }
-  if (i == 0) { ctrl->error = 0; ctrl->pad = test_stall; ctrl->rows_cap = rows_cap; }
+  if (i == 0) { ctrl->error = 0; ctrl->pad = test_stall; ctrl->rows_cap = 0; }
+}
+
+// end of a fused trace, enqueued blind behind a batch: if the trace is over (the slot behind the batch
+// holds no rays, or the generation limit is reached) clear the control words for the next trace of the
+// same shape -- off the host's critical path; otherwise leave everything for the next batch.
+__global__ void k_fused_reinit(FusedCtrl* ctrl, GenCtrl* gen, int n_gen_slots, int end_slot, int limit,
+                               unsigned long long* tiles0, int64_t n_tiles, int64_t n, int test_stall) {
+  const bool over = end_slot >= limit || gen[end_slot].n_in == 0 || ctrl->error != 0;
+  if (!over) return;
+  // every block must see the same `over`: the slot is rewritten below, so sync through a second launch
+  // is avoided by letting block 0 alone touch the slots and only after all blocks have read them --
+  // simplest: one block does everything
+  for (int64_t k = threadIdx.x; k < n_tiles; k += blockDim.x) tiles0[k] = TILE_INVALID;
+  __syncthreads();
+  for (int k = threadIdx.x; k < n_gen_slots; k += blockDim.x) {
+    GenCtrl z;
+    memset(&z, 0, sizeof(z));
+    if (k == 0) z.n_in = n;
+    gen[k] = z;
+  }
+  if (threadIdx.x == 0) { ctrl->error = 0; ctrl->pad = test_stall; ctrl->rows_cap = 0; }
 }
 
 // component.intersect(): run one component's program and spill its list
@@ -1215,6 +1280,33 @@ static int64_t trace_unfused(prt_scene* s, DeviceCopy* c, const double* rays, in
 // between (a generation whose predecessor left no rays exits in its prologue)
 static const int kGenerationBatch = 4;
 
+// add the HIP-event time of the last batch to the kernel-time statistic (waits for ev1 if need be:
+// by the time anybody asks, the batch has long finished)
+static int settle_timing(prt_scene* s, DeviceCopy* c) {
+  if (!c->timing_pending) return PRT_OK;
+  c->timing_pending = false;
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  s->stats[2] += ms;
+  return PRT_OK;
+}
+
+// spin on the epoch word of the host mirror; gives up after ~2 s of polling and lets the stream
+// synchronisation report whatever went wrong
+static int await_epoch(DeviceCopy* c, unsigned long long epoch, hipStream_t st) {
+  volatile unsigned long long* word = &c->mirror->epoch;
+  for (long spins = 0; __atomic_load_n(word, __ATOMIC_ACQUIRE) != epoch; ++spins) {
+    __builtin_ia32_pause();
+    if (spins > (1l << 28)) {
+      HIP_TRY(hipStreamSynchronize(st));
+      if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != epoch) return fail(PRT_ERR_HIP, "trace batch never published its counts");
+      break;
+    }
+  }
+  return PRT_OK;
+}
+
 static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int64_t n, int64_t ld,
                            int generation_limit, double ray_offset, double* rows_out,
                            int64_t rows_cap, int64_t* rows_per_generation, char* w, int flags,
@@ -1233,8 +1325,14 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
   // the fallback to the three-kernel path.
   const char* stall_env = getenv("PRT_TEST_STALL");
   const int test_stall = (stall_env && stall_env[0] == '1') ? 1 : 0;
-  hipLaunchKernelGGL(k_fused_init, dim3(64), dim3(256), 0, st, ctrl, gen, n_slots, tiles[0],
-                     (int64_t)blocks_for(n), n, rows_cap, test_stall);
+  int rc;
+  // The control words of a trace (generation slots, tile words, error word) are cleared on the stream
+  // right after the previous trace of the same shape finished, off the critical path; only a first
+  // trace, or one with another workspace / ray count, clears them here.
+  if (!(c->ready_workspace == w && c->ready_n == n && c->ready_slots == n_slots && c->ready_stall == test_stall))
+    hipLaunchKernelGGL(k_fused_init, dim3(64), dim3(256), 0, st, ctrl, gen, n_slots, tiles[0],
+                       (int64_t)blocks_for(n), n, test_stall);
+  c->ready_workspace = nullptr;
 
   size_t lds_pad = 0;  // experiment: PRT_LDS_PAD=<bytes> lowers occupancy without touching the code
   if (const char* pad_env = getenv("PRT_LDS_PAD")) lds_pad = (size_t)atol(pad_env);
@@ -1242,8 +1340,14 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
   const char* rpl_env = getenv("PRT_RAYS_PER_LANE");
   const bool two_per_lane = rpl_env && rpl_env[0] == '2' && 2 * lds <= kMaxLdsBytes;
 #endif
-  GenCtrl* host_gen = c->host_gen + 1;  // slot -1 receives the control header
   const bool culls = count_steps(s->trace_program.code, I_BOX) > 0;
+  // the generation kernels tell the host themselves unless an error can still be raised after the
+  // last tile has its totals (only PRT_ERR_UNTRACABLE, at store time) or an experiment kernel runs
+  // (the stall test hook raises its fake error from a tile that no successor waits for: same path)
+  bool in_kernel_publish = !s->has_untracable && !test_stall && getenv("PRT_PUBLISH_KERNEL") == nullptr;
+#ifdef PRT_EXPERIMENTS
+  if (two_per_lane) in_kernel_publish = false;
+#endif
   int64_t bound = n, total_rows = 0;
   int g = 0, error = 0;
   bool done = false;
@@ -1254,6 +1358,9 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
     int want = kGenerationBatch;
     if (g == 0 && s->last_generations > 0) want = std::min(s->last_generations, kMaxBatch);
     const int batch = std::min(want, generation_limit - g);
+    rc = settle_timing(s, c);
+    if (rc) return rc;
+    const unsigned long long epoch = ++c->epoch;
     HIP_TRY(hipEventRecord(c->ev0, st));
     for (int b = 0; b < batch; ++b) {
       const int gg = g + b;
@@ -1272,21 +1379,24 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
       auto kernel = culls ? k_generation<true> : k_generation<false>;
       hipLaunchKernelGGL(kernel, dim3(blocks_for(bound)), dim3(PRT_BLOCK), lds + lds_pad, st, sd, src,
                          src_ld, buf[gg & 1], n, rows_out, rows_cap, ctrl, gen, gg, tiles[gg & 1],
-                         tiles[(gg + 1) & 1], (double)(gg + 1), relaunch, ray_offset, keep_absorbed);
+                         tiles[(gg + 1) & 1], (double)(gg + 1), relaunch, ray_offset, keep_absorbed,
+                         in_kernel_publish ? c->mirror_dev : (HostMirror*)nullptr, epoch, b,
+                         b + 1 == batch ? 1 : 0);
     }
     HIP_TRY(hipEventRecord(c->ev1, st));
-    if (g == 0) {  // header + slots 0..batch are contiguous: one copy
-      HIP_TRY(hipMemcpyAsync(host_gen - 1, ctrl, (batch + 2) * sizeof(GenCtrl), hipMemcpyDeviceToHost, st));
-    } else {
-      HIP_TRY(hipMemcpyAsync(host_gen, gen + g, (batch + 1) * sizeof(GenCtrl), hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(host_gen - 1, ctrl, sizeof(FusedCtrl), hipMemcpyDeviceToHost, st));
-    }
-    HIP_TRY(hipStreamSynchronize(st));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    s->stats[2] += ms;
+    c->timing_pending = true;
+    if (!in_kernel_publish)
+      hipLaunchKernelGGL(k_publish, dim3(1), dim3(kMaxBatch + 4), 0, st, (const FusedCtrl*)ctrl,
+                         (const GenCtrl*)(gen + g), batch + 1, c->mirror_dev, epoch);
+    // clears the control words for the next trace if this batch turns out to end the trace
+    hipLaunchKernelGGL(k_fused_reinit, dim3(1), dim3(1024), 0, st, ctrl, gen, n_slots, g + batch,
+                       generation_limit, tiles[0], (int64_t)blocks_for(n), n, test_stall);
+    HIP_TRY(hipGetLastError());
+    rc = await_epoch(c, epoch, st);
+    if (rc) return rc;
+    const GenCtrl* host_gen = c->mirror->gen;
     s->stats[3] += batch;
-    error = ((const FusedCtrl*)(host_gen - 1))->error;
+    error = c->mirror->error;
     if (error) break;
     for (int b = 0; b < batch; ++b) {
       if (host_gen[b].n_in == 0) { done = true; break; }
@@ -1297,7 +1407,7 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
       rows_per_generation[g + b] = host_gen[b].n_live;
       total_rows += host_gen[b].n_live;
     }
-    bound = host_gen[batch].n_in;
+    if (!done) bound = host_gen[batch].n_in;
     if (bound == 0) done = true;
     g += batch;
   }
@@ -1311,6 +1421,11 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
 #endif
   if (error) return trace_error(error);
   s->last_generations = (int)s->stats[0];
+  // k_fused_reinit behind the last batch has cleared the control words for a next trace of this shape
+  c->ready_workspace = w;
+  c->ready_n = n;
+  c->ready_slots = n_slots;
+  c->ready_stall = test_stall;
   return total_rows;
 }
 
@@ -1326,16 +1441,27 @@ extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64
     return fail(PRT_ERR_ARG, "bad buffers (generation_limit must be <= 1024)");
   if (n >= (1ll << 31)) return fail(PRT_ERR_ARG, "at most 2^31-1 rays per call");
   for (int g = 0; g < generation_limit; ++g) rows_per_generation[g] = 0;
+  rc = settle_timing(s, c);  // events of the previous trace, before its statistics are dropped
+  if (rc) return rc;
   for (double& v : s->stats) v = 0;
   if (n == 0 || generation_limit == 0) return 0;
-  if (flags & PRT_TRACE_UNFUSED)
+  s->stats[6] = (double)s->lookback_fallbacks;
+  if (flags & PRT_TRACE_UNFUSED) {
+    s->stats[7] = PRT_VARIANT_UNFUSED;
     return trace_unfused(s, c, rays, n, ld, generation_limit, ray_offset, rows_out, rows_cap,
                          rows_per_generation, (char*)workspace, flags, (hipStream_t)stream);
+  }
+  s->stats[7] = PRT_VARIANT_FUSED;
   int64_t rc64 = trace_fused(s, c, rays, n, ld, generation_limit, ray_offset, rows_out, rows_cap,
                              rows_per_generation, (char*)workspace, flags, (hipStream_t)stream);
-  if (rc64 == PRT_ERR_STALL) {  // never observed; see lookback()
+  if (rc64 == PRT_ERR_STALL) {  // never observed outside the test hook; see lookback()
     for (int g = 0; g < generation_limit; ++g) rows_per_generation[g] = 0;
+    rc = settle_timing(s, c);
+    if (rc) return rc;
     for (double& v : s->stats) v = 0;
+    s->lookback_fallbacks += 1;  // telemetry: a box that falls back silently would just look 2x slow
+    s->stats[6] = (double)s->lookback_fallbacks;
+    s->stats[7] = PRT_VARIANT_UNFUSED;
     rc64 = trace_unfused(s, c, rays, n, ld, generation_limit, ray_offset, rows_out, rows_cap,
                          rows_per_generation, (char*)workspace, flags, (hipStream_t)stream);
   }
@@ -1344,6 +1470,11 @@ extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64
 
 extern "C" int prt_trace_stats(const prt_scene* s, double* out8) {
   if (!s || !out8) return fail(PRT_ERR_ARG, "null argument");
+  prt_scene* scene = const_cast<prt_scene*>(s);
+  for (DeviceCopy& c : scene->per_device) {  // the last batch's event time is collected on demand
+    int rc = settle_timing(scene, &c);
+    if (rc) return rc;
+  }
   for (int k = 0; k < 8; ++k) out8[k] = s->stats[k];
   return PRT_OK;
 }

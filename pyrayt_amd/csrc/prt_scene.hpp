@@ -43,8 +43,15 @@ struct DeviceCopy {
   DevInstr* render_code = nullptr;              // same with the renderers' selection rule
   std::vector<DevInstr*> component_code;        // one program per component, no I_ROOT
   int64_t* host_pinned = nullptr;               // 8 x int64 pinned staging
-  struct GenCtrl* host_gen = nullptr;           // pinned read-back of one batch of slots
+  struct HostMirror* mirror = nullptr;          // host-mapped: the device publishes a batch's counts here
+  struct HostMirror* mirror_dev = nullptr;      // the same memory as the device addresses it
+  unsigned long long epoch = 0;                 // number of batches published so far
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timing_pending = false;                  // ev0..ev1 of the last batch not yet added to stats[2]
+  // control words already initialised on the stream for a next trace of this shape (see trace_fused)
+  const void* ready_workspace = nullptr;
+  int64_t ready_n = -1;
+  int ready_slots = 0, ready_stall = 0;
 };
 
 struct prt_scene {
@@ -61,6 +68,7 @@ struct prt_scene {
   bool has_untracable = false;
   double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int last_generations = 0;  // working generations of the previous trace: sizes the first batch
+  long lookback_fallbacks = 0;  // traces of this scene that fell back to the three-kernel path
 };
 
 static int leaves_under(const prt_scene* s, int node) {
@@ -470,7 +478,7 @@ extern "C" void prt_scene_destroy(prt_scene* s) {
     (void)hipFree(c.render_code);
     for (DevInstr* p : c.component_code) (void)hipFree(p);
     if (c.host_pinned) (void)hipHostFree(c.host_pinned);
-    if (c.host_gen) (void)hipHostFree(c.host_gen);
+    if (c.mirror) (void)hipHostFree(c.mirror);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
     if (c.ev1) (void)hipEventDestroy(c.ev1);
   }
@@ -530,7 +538,9 @@ static int on_device(prt_scene* s, int device, DeviceCopy** out) {
       c.component_code.push_back(code);
     }
     HIP_TRY(hipHostMalloc((void**)&c.host_pinned, 8 * sizeof(int64_t), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void**)&c.host_gen, (kMaxBatch + 4) * 64, hipHostMallocDefault));  // GenCtrl is 64 B
+    HIP_TRY(hipHostMalloc((void**)&c.mirror, 64 + (kMaxBatch + 4) * 64, hipHostMallocMapped | hipHostMallocCoherent));  // header + GenCtrl slots of 64 B
+    std::memset((void*)c.mirror, 0, 64 + (kMaxBatch + 4) * 64);
+    HIP_TRY(hipHostGetDevicePointer((void**)&c.mirror_dev, (void*)c.mirror, 0));
     int rc_lds = raise_lds_limits();
     if (rc_lds) return rc_lds;
     HIP_TRY(hipEventCreate(&c.ev0));

@@ -185,7 +185,7 @@ class DeviceScene:
         out = (ctypes.c_int64 * 8)()
         _check(library().prt_scene_info(self.handle, out))
         keys = ("primitives", "components", "trace_steps", "trace_slots", "cull_steps", "render_steps",
-                "render_slots")
+                "render_slots", "chain_steps")
         return dict(zip(keys, (int(v) for v in out)))
 
     def close(self):
@@ -200,11 +200,13 @@ class DeviceScene:
             pass
 
     # --- the hot loop -------------------------------------------------------------------------
-    def trace(self, rays, generation_limit, ray_offset=DEFAULT_RAY_OFFSET, flags=0, rows_cap=None):
+    def trace(self, rays, generation_limit, ray_offset=DEFAULT_RAY_OFFSET, flags=0, rows_cap=None, out=None):
         """Run all generations on the device.
 
         rays: CUDA float64 tensor (13, n), row-major.  Returns (rows, counts): rows is a CUDA
-        (15, total) tensor view, generation-major; counts the rows recorded per generation."""
+        (15, total) tensor view, generation-major; counts the rows recorded per generation.
+        out: optional (15, cap) CUDA float64 block to record into (a design loop that is done with
+        the previous frame passes it back instead of having a new block allocated per call)."""
         torch = _torch()
         lib = library()
         assert rays.is_cuda and rays.dtype == torch.float64 and rays.dim() == 2
@@ -214,17 +216,22 @@ class DeviceScene:
         limit = int(generation_limit)
         if n == 0 or limit <= 0:
             return torch.empty((RECORD_COLS, 0), dtype=torch.float64, device=dev), []
-        cap = int(rows_cap) if rows_cap is not None else self._rows_cap(torch, n, limit, dev)
+        if out is not None:
+            assert out.is_cuda and out.dtype == torch.float64 and out.dim() == 2 and out.device == dev
+            assert out.shape[0] == RECORD_COLS and out.is_contiguous()
+            cap = out.shape[1]
+        else:
+            cap = int(rows_cap) if rows_cap is not None else self._rows_cap(torch, n, limit, dev)
         work = self._workspace(torch, n, dev)
         counts = (ctypes.c_int64 * limit)()
         while True:
-            rows = torch.empty((RECORD_COLS, cap), dtype=torch.float64, device=dev)
+            rows = out if out is not None else torch.empty((RECORD_COLS, cap), dtype=torch.float64, device=dev)
             total = lib.prt_trace(
                 self.handle, dev.index or 0, rays.data_ptr(), n, rays.stride(0), limit,
                 float(ray_offset), rows.data_ptr(), cap, counts, work.data_ptr(), int(flags),
                 _stream_ptr(torch, dev),
             )
-            if total == ERR_ROWS_CAP and cap < n * limit:
+            if total == ERR_ROWS_CAP and cap < n * limit and out is None:
                 cap = min(n * limit, cap * 4)  # only when HBM was too tight for the full block
                 continue
             _check(total)
@@ -265,7 +272,8 @@ class DeviceScene:
         _check(library().prt_trace_stats(self.handle, out))
         return {"generations": int(out[0]), "ray_generations": int(out[1]),
                 "kernel_ms": float(out[2]), "kernel_launches": int(out[3]),
-                "rows": int(out[4]), "rays_carried": int(out[5])}
+                "rows": int(out[4]), "rays_carried": int(out[5]),
+                "lookback_fallbacks": int(out[6]), "variant": int(out[7])}
 
     # --- per-state entry points -----------------------------------------------------------------
     def propagate(self, rays):

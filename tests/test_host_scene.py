@@ -194,10 +194,13 @@ def test_compiled_programs_carry_cull_steps_only_for_three_or_more_components():
         info = ds.info()
         ds.close()
         assert (info["components"], info["primitives"], info["cull_steps"]) == (components, prims, culls), name
-        # one step per leaf and per CSG node (+ culls); render programs add a root step per CSG
-        # component, bare surfaces reduce inside their own leaf step
-        assert info["trace_steps"] == info["render_steps"] - sum(
-            1 for p in parts if hasattr(p, "children")) + culls
+        # trace programs: every part factory builds a left-deep chain of two or three leaves, which
+        # compiles to one chain record (three step slots); a bare surface is one leaf step (+ culls)
+        csg_parts = sum(1 for p in parts if hasattr(p, "children"))
+        assert info["chain_steps"] == csg_parts, name
+        assert info["trace_steps"] == 3 * csg_parts + (components - csg_parts) + culls, name
+        # render programs: one step per leaf and per CSG node plus a root step per CSG component
+        assert info["render_steps"] == (2 * prims - components) + csg_parts, name
 
 
 def test_coordinate_helpers_like_upstream():
