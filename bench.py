@@ -5,15 +5,17 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One *step* = one pass of the hot path (every generation: intersect + nearest hit + shade +
-compaction + record rows) over one batch of 1,000,000 rays per GPU that is already resident
-in HBM.  The metric counts result rows (one row = one ray segment resolved to its nearest
-surface and shaded), aggregated over all ranks, divided by the max-over-ranks wall time of
-the K timed steps (barrier + synchronize on both sides).
+compaction + record rows) over the job's rays, already resident in HBM.  The metric counts
+result rows (one row = one ray segment resolved to its nearest surface and shaded), aggregated
+over all ranks, divided by the max-over-ranks wall time of the K timed steps (barrier +
+synchronize on both sides).
 
-Scaling is weak: every rank traces its own 1M-ray contiguous id range of an N x 1M-ray job
-(rays are independent, the trace needs no collective).  The re-assembly of the result frame
-(one RCCL all-gather, pyrayt_amd.distributed) is exercised and timed separately after the
-timed region and reported under "gather" -- it is not part of `value`.
+Scaling is strong (BASELINE.json: "1M-ray biconvex lens, 1/2/4/8 GPU"): ONE seeded 1M-ray job;
+rank r traces the contiguous id range [r n/G, (r+1) n/G) of the same ray set (rays are
+independent, the trace needs no collective).  `--scaling weak` gives every rank its own 1M rays
+instead (secondary figure).  The re-assembly of the result frame (RCCL all-gathers + a placement
+kernel inside the library, pyrayt_amd/csrc/prt_gather.hpp) is timed separately after the timed
+region and reported under "gather" and "value_with_gather" -- it is not part of `value`.
 
 rank 0 prints ONE JSON line.  `roofline` is for the generation kernel(s): algorithmic bytes
 (328 B per ray alive at generation entry) over the HIP-event time of
@@ -30,6 +32,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+WORKLOADS = {
+    "config2": "BASELINE config 2: biconvex_lens(2,2,0.25,aperture=1) + detector baffle, seeded 6 degree cone at -f",
+    "config3": "[informational] BASELINE config 3: Cooke-style triplet (3 thick lenses) + aperture stop + detector, "
+               "seeded 4 degree cone",
+    "config4": "[informational] BASELINE config 4: equilateral BK7 prism + detector, 8 wavelengths of LineOfRays",
+    "config5": "[informational] BASELINE config 5: paraboloid & cylinder CSG condenser + baffle",
+}
 RAYS_PER_GPU = 1_000_000
 GENERATION_LIMIT = 10
 BYTES_PER_RAY_GENERATION = 328  # 104 B state read + 104 B state write + 120 B record row
@@ -41,7 +50,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rays", type=int, default=RAYS_PER_GPU, help="rays per GPU")
+    ap.add_argument("--rays", type=int, default=RAYS_PER_GPU,
+                    help="rays of the job (strong scaling) / per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--flags", type=int, default=0, help="PRT_TRACE_* flags")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5"],
@@ -90,17 +101,24 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    # the workload: config 2, this rank's contiguous id range of a (world x rays) job
-    n = args.rays
+    # the workload: this rank's contiguous id range of the job
+    n_job = args.rays
+    strong = args.scaling == "strong"
     CountedObject.reset_ids()
+    seed_shift = 0 if strong else rank
     if args.workload == "config2":
-        parts, rays = scenes.config2(scenes.product_api(), n, seed=1234 + rank)
+        parts, rays = scenes.config2(scenes.product_api(), n_job, seed=1234 + seed_shift)
     elif args.workload == "config4":
-        parts, rays = scenes.config4(scenes.product_api(), n // 8)
+        parts, rays = scenes.config4(scenes.product_api(), n_job // 8)
     else:
-        parts, rays = scenes.SCENES[args.workload](scenes.product_api(), n)
+        parts, rays = scenes.SCENES[args.workload](scenes.product_api(), n_job)
+    n_job = rays.shape[1]
+    if strong:  # one job, sharded by contiguous id range (ids are already global)
+        lo, hi = pdist.shard_bounds(n_job, rank=rank, world=world)
+        rays = np.ascontiguousarray(rays[:, lo:hi])
+    else:
+        rays[12] += rank * n_job
     n = rays.shape[1]
-    rays[12] += rank * n
     snap = SceneSnapshot(parts)
     scene = engine.DeviceScene(snap)
     rays_dev = torch.from_numpy(rays).to(device)
@@ -108,7 +126,7 @@ def main():
     limit = args.generation_limit
     # one record block, handed back to every step (what a design loop does once it has consumed the
     # previous frame); n * limit columns always suffice
-    block = torch.empty((engine.RECORD_COLS, n * limit), dtype=torch.float64, device=device)
+    block = torch.empty((engine.RECORD_COLS, max(n, 1) * limit), dtype=torch.float64, device=device)
 
     def step():
         return scene.trace(rays_dev, limit, flags=args.flags, out=block)
@@ -146,21 +164,31 @@ def main():
     else:
         total_rows_per_step = float(rows_per_step)
 
-    # frame re-assembly (not in the timed region): one all-gather, checked for row count
+    # frame re-assembly (not in the timed region): the library's RCCL all-gathers + placement kernel
+    # when the group is RCCL-backed, torch.distributed + the placement kernel otherwise
     gather = None
     if distributed:
         try:  # an extra: its failure must not cost the benchmark line
-            torch.cuda.synchronize(device)
-            dist.barrier()
-            g0 = time.perf_counter()
-            full, full_counts = pdist.assemble_rows(rows.to(comm_device), counts, limit, dist.group.WORLD, "all")
-            torch.cuda.synchronize(device)
-            dist.barrier()
-            gather_s = time.perf_counter() - g0
-            assert full.shape[1] == int(total_rows_per_step)
-            gather = {"ms": gather_s * 1e3, "rows": int(full.shape[1]),
-                      "GB_into_each_gpu": full.shape[1] * 120 * (world - 1) / world / 1e9}
-            del full
+            comm = pdist.LibraryComm.from_group(dist.group.WORLD, device) if backend == "nccl" else None
+            times = []
+            for _ in range(3):  # the first pass also builds RCCL's channels
+                torch.cuda.synchronize(device)
+                dist.barrier()
+                g0 = time.perf_counter()
+                full, full_counts = pdist.assemble_rows(rows, counts, limit, dist.group.WORLD, "all", comm=comm)
+                torch.cuda.synchronize(device)
+                dist.barrier()
+                times.append(time.perf_counter() - g0)
+                assert full.shape[1] == int(total_rows_per_step), (full.shape, total_rows_per_step)
+                del full
+            agg = torch.tensor([min(times[1:])], dtype=torch.float64, device=comm_device)
+            dist.all_reduce(agg, op=dist.ReduceOp.MAX)
+            gather = {"ms": float(agg[0]) * 1e3, "first_call_ms": times[0] * 1e3, "rows": int(total_rows_per_step),
+                      "GB_into_each_gpu": total_rows_per_step * 120 * (world - 1) / world / 1e9,
+                      "transport": "RCCL inside libprt_hip (prt_allgather_rows)" if comm is not None
+                                   else f"torch.distributed {backend} + prt_place_rows"}
+            if comm is not None:
+                comm.close()
         except Exception as exc:  # noqa: BLE001
             gather = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
@@ -198,7 +226,7 @@ def main():
     algorithmic_bytes = 104.0 * ray_generations + 120.0 * rows_recorded + 104.0 * rays_carried
     achieved = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     traffic = None
-    traffic_file = os.path.join(ROOT, "profiles", "r1", "traffic.json")
+    traffic_file = os.path.join(ROOT, "profiles", "r2", "traffic.json")
     if os.path.exists(traffic_file) and args.flags == 0 and n == RAYS_PER_GPU and args.workload == "config2":
         with open(traffic_file) as fh:
             measured = json.load(fh)
@@ -215,22 +243,23 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": ("" if args.workload == "config2" else f"[{args.workload} scene, informational] ") +
-                        "BASELINE config 2: biconvex_lens(2,2,0.25,aperture=1) + detector baffle, "
-                        f"{n} rays per GPU from a seeded 6 degree cone at -f, generation_limit "
-                        f"{limit}, rays resident in HBM",
+            "workload": WORKLOADS[args.workload] +
+                        (f": one {n_job}-ray job, contiguous id shards over {world} GPU(s)" if strong
+                         else f": {n_job} rays per GPU (weak scaling)") +
+                        f", generation_limit {limit}, rays resident in HBM",
+            "rays_job": n_job * (1 if strong else world),
             "rays_per_gpu": n,
             "rows_per_step_per_gpu": rows_per_step,
             "rows_per_generation": counts,
             # secondary metric of SURVEY.md section 8d: rays alive at generation entry x primitives
             "primitive_tests_per_s": ray_generations * len(snap.prims) * world / elapsed,
             "trace_flags": args.flags,
-            "parallelism": f"ray data-parallel x{world}, no collective in the timed region",
+            "parallelism": f"ray data-parallel x{world} (contiguous id shards), no collective in the timed region",
         },
         "roofline": {
             "bound": "hbm",
@@ -239,7 +268,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "traffic_source": "profiles/r1/traffic.json (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, "
+            "traffic_source": "profiles/r2/traffic.json (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, "
                               "calibrated; same command, separate passes)" if traffic else None,
             "kernel": "k_generation" if not (args.flags & 2) else "k_hit + k_scan + k_shade + k_advance",
             "algorithmic_bytes_per_launch": algorithmic_bytes / launches if launches else 0,
@@ -252,6 +281,8 @@ def main():
     }
     if gather:
         line["gather"] = gather
+        if "ms" in gather:
+            line["value_with_gather"] = total_rows_per_step / (elapsed / args.steps + gather["ms"] * 1e-3)
 
     if not args.no_cpu_baseline and world == 1:
         from oracle import prt_oracle

@@ -217,6 +217,35 @@ int64_t prt_trace(prt_scene* scene, int device, const double* rays, int64_t n, i
                   int generation_limit, double ray_offset, double* rows_out, int64_t rows_cap,
                   int64_t* rows_per_generation, void* workspace, int flags, void* stream);
 
+/* ---- frame re-assembly across the GPUs of a node ----------------------------
+ * No counterpart upstream (pyrayt/_pyrayt.py:329-339 is one Python thread).  Rank r traces the
+ * contiguous id range [r n/G, (r+1) n/G) with no communication; these entry points put the per-rank
+ * record blocks back into the row order of pyrayt/_pyrayt.py:168-186 (generation-major, ascending
+ * ray id = rank-major inside a generation).  One process per GPU; the communicator is RCCL's
+ * (resolved with dlopen at first use), bootstrapped like any NCCL communicator: rank 0 draws a
+ * 128-byte id, the caller broadcasts it (torch.distributed, MPI, a file ...), every rank creates.
+ *   prt_allgather_counts   (limit) rows-per-generation of every rank -> counts_all[r * limit + g];
+ *                          synchronises the stream (the host sizes the assembled frame from it)
+ *   prt_allgather_rows     15 grouped ncclAllGather (one per record column, straight out of the
+ *                          (15, ld_rows) block) + the placement kernel; stream-ordered, no host sync;
+ *                          ld_rows must be >= the largest per-rank row total
+ *   prt_place_rows         the placement kernel alone, for a staging area filled by another
+ *                          transport: element (column k, rank r, position p) at
+ *                          staging[k * stride_col + r * stride_rank + p]                              */
+typedef struct prt_comm prt_comm;
+int prt_comm_unique_id(char* id128);
+int prt_comm_create(int device, int world, int rank, const char* id128, prt_comm** out);
+void prt_comm_destroy(prt_comm* comm);
+int prt_allgather_counts(prt_comm* comm, const int64_t* counts_local, int limit, int64_t* counts_all,
+                         void* stream);
+int64_t prt_allgather_workspace_bytes(int world, int limit, int64_t pad_rows);
+int prt_allgather_rows(prt_comm* comm, const double* rows, int64_t ld_rows, const int64_t* counts_all,
+                       int limit, double* out, int64_t ld_out, void* workspace, void* stream);
+int64_t prt_place_workspace_bytes(int world, int limit);
+int prt_place_rows(int device, const double* staging, int64_t stride_rank, int64_t stride_col, int world,
+                   const int64_t* counts_all, int limit, double* out, int64_t ld_out, void* workspace,
+                   void* stream);
+
 /* statistics of the last prt_trace on this scene (for bench.py's roofline):
  * out[0] = generations that found rays, out[1] = sum over generations of rays alive at entry,
  * out[2] = GPU milliseconds spent in generation kernels (hipEvent, on the trace stream),

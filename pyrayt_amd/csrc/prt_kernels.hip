@@ -1731,3 +1731,8 @@ extern "C" int prt_primitive_normal(int device, int type, const double* params, 
   HIP_TRY(hipGetLastError());
   return PRT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// frame re-assembly across ranks (RCCL all-gather + placement kernel)
+// ------------------------------------------------------------------------------------------------
+#include "prt_gather.hpp"

@@ -68,6 +68,14 @@ def _declare(lib):
         "prt_primitive_intersect": (c_int, [c_int, c_int, c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
         "prt_primitive_normal": (c_int, [c_int, c_int, c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
         "prt_array_csg": (c_int, [c_int, c_p, c_int, c_p, c_int, c_i64, c_i64, c_int, c_int, c_p, c_i64, c_p]),
+        "prt_comm_unique_id": (c_int, [c_p]),
+        "prt_comm_create": (c_int, [c_int, c_int, c_int, c_p, ctypes.POINTER(c_p)]),
+        "prt_comm_destroy": (None, [c_p]),
+        "prt_allgather_counts": (c_int, [c_p, c_p, c_int, c_p, c_p]),
+        "prt_allgather_workspace_bytes": (c_i64, [c_int, c_int, c_i64]),
+        "prt_allgather_rows": (c_int, [c_p, c_p, c_i64, c_p, c_int, c_p, c_i64, c_p, c_p]),
+        "prt_place_workspace_bytes": (c_i64, [c_int, c_int]),
+        "prt_place_rows": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_int, c_p, c_i64, c_p, c_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = the library does not match prt.h
@@ -84,7 +92,9 @@ EXPORTED_SYMBOLS = (
     "prt_camera_rays", "prt_render_hits", "prt_gooch_shade", "prt_gooch_mix", "prt_render",
     "prt_edge_workspace_bytes", "prt_edge_canvas", "prt_reflect", "prt_refract", "prt_binomial_root",
     "prt_smallest_positive_root", "prt_dot", "prt_array_csg", "prt_primitive_intersect",
-    "prt_primitive_normal",
+    "prt_primitive_normal", "prt_comm_unique_id", "prt_comm_create", "prt_comm_destroy",
+    "prt_allgather_counts", "prt_allgather_workspace_bytes", "prt_allgather_rows",
+    "prt_place_workspace_bytes", "prt_place_rows",
 )
 
 

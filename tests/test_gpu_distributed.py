@@ -1,0 +1,116 @@
+"""Multi-rank path on the GPU: real HIP traces per shard, frames re-assembled by the library.
+
+A gpurun box has one GPU, and RCCL refuses two ranks on one device, so the two-rank tests let the
+blocks travel through a gloo group and order them with the library's placement kernel
+(``prt_place_rows`` -- the same kernel ``prt_allgather_rows`` runs behind its RCCL all-gathers);
+the RCCL leg itself (communicator bootstrap, count all-gather, fifteen grouped all-gathers) runs
+with a one-rank communicator.  The assembled frame must equal the single-rank frame bit for bit,
+row order included (pyrayt/_pyrayt.py:168-186)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+LIMIT = 10
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _scene_and_rays(name, n):
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    CountedObject.reset_ids()
+    parts, rays = scenes.SCENES[name](scenes.product_api(), n)
+    return SceneSnapshot(parts), rays
+
+
+def _worker(rank, world, port, name, n, mode, result_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyrayt_amd import distributed as pdist
+        from pyrayt_amd import engine
+
+        torch.cuda.set_device(0)
+        snap, rays = _scene_and_rays(name, n)
+        group = pdist.resolve_group(None)
+        lo, hi = pdist.shard_bounds(rays.shape[1], group)
+        scene = engine.DeviceScene(snap)
+        shard = torch.from_numpy(np.ascontiguousarray(rays[:, lo:hi])).to("cuda:0")
+        rows, counts = scene.trace(shard, LIMIT)
+        assert scene.trace_stats()["variant"] == 1
+        full, full_counts = pdist.assemble_rows(rows, counts, LIMIT, group, mode)
+        assert full.is_cuda
+        np.save(os.path.join(result_dir, f"rows_{rank}.npy"), full.cpu().numpy())
+        np.save(os.path.join(result_dir, f"counts_{rank}.npy"), np.array(full_counts))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,n,world,mode", [("config2", 20011, 2, "all"), ("stopped_lens", 6007, 3, "all"),
+                                               ("config3", 9001, 2, "root")])
+def test_sharded_hip_trace_assembles_to_the_single_rank_frame(tmp_path, name, n, world, mode):
+    import torch.multiprocessing as mp
+
+    from pyrayt_amd import engine
+
+    mp.start_processes(_worker, args=(world, _free_port(), name, n, mode, str(tmp_path)), nprocs=world,
+                       join=True, start_method="spawn")
+    snap, rays = _scene_and_rays(name, n)
+    rows, counts = engine.DeviceScene(snap).trace(torch.from_numpy(rays).to("cuda:0"), LIMIT)
+    want = rows.cpu().numpy()
+    for rank in range(world):
+        got = np.load(tmp_path / f"rows_{rank}.npy")
+        assert np.load(tmp_path / f"counts_{rank}.npy").tolist() == counts
+        if mode == "all" or rank == 0:
+            assert got.shape == want.shape
+            assert np.array_equal(got, want, equal_nan=True)  # sharded == unsharded, same row order
+        else:
+            assert got.shape[1] == 0
+
+
+def test_rccl_leg_with_a_one_rank_communicator():
+    """prt_comm_create / prt_allgather_counts / prt_allgather_rows over RCCL itself."""
+    from pyrayt_amd import distributed as pdist
+    from pyrayt_amd import engine
+
+    snap, rays = _scene_and_rays("config2", 5000)
+    rows, counts = engine.DeviceScene(snap).trace(torch.from_numpy(rays).to("cuda:0"), LIMIT)
+    comm = pdist.LibraryComm(0, 1, 0, pdist.LibraryComm.unique_id())
+    try:
+        matrix = comm.gather_counts(counts, LIMIT)
+        assert matrix.shape == (1, LIMIT) and matrix[0, : len(counts)].tolist() == counts
+        out, merged = pdist.assemble_rows(rows, counts, LIMIT, None, "all", comm=comm)
+        assert merged == counts
+        assert torch.equal(out, rows)
+    finally:
+        comm.close()
+
+
+def test_placement_kernel_against_the_indexed_copy():
+    """prt_place_rows == the torch placement on a ragged count matrix with empty segments."""
+    from pyrayt_amd import distributed as pdist
+
+    matrix = torch.tensor([[5, 0, 3, 0], [0, 0, 4, 1], [2, 7, 0, 0]])
+    world, limit = matrix.shape
+    widest = int(matrix.sum(dim=1).max())
+    gen = torch.Generator().manual_seed(3)
+    blocks = torch.rand((world, 15, widest), generator=gen, dtype=torch.float64)
+    _, _, total = pdist.placement(matrix)
+    want = pdist._place_with_torch(list(blocks.unbind(0)), matrix, total)
+    got = pdist._place_on_device(blocks.to("cuda:0"), matrix, limit, total)
+    assert torch.equal(got.cpu(), want)
