@@ -640,6 +640,13 @@ __device__ __forceinline__ void first_positive_else_first(const Operand& o, cons
 // no survivor gets the all-inf list either way.  Only rays whose survivors are (nearly)
 // coincident -- tangent rays, a Plane's double hit (t,t) -- take the exact six-division test.
 // UNION nodes always take it (their upstream box can be smaller than the solid).
+#ifdef PRT_COUNT_SLOW  // experiment build: how often the shortcuts fall through to their exact paths
+__device__ unsigned long long g_slow[4];  // [0] implied nodes with survivors, [1] ... that took the exact box test, [2] cull tests, [3] ... that skipped
+#define PRT_COUNT(k, flag) do { const unsigned long long m_ = __ballot(flag); if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(true)) - 1) && m_) atomicAdd(&g_slow[k], (unsigned long long)__popcll(m_)); } while (0)
+#else
+#define PRT_COUNT(k, flag) do {} while (0)
+#endif
+
 // keep flags of one node (the part of csg_node below that needs no list storage): c(i,j), the
 // parities, the keep rule per operation and the (lazily evaluated) cull box.  Neither list has to
 // be sorted or compacted for this: every quantity is a count of entries of the *other* list that
@@ -695,7 +702,21 @@ __device__ __forceinline__ void csg_keep(int op, const double (&lv)[ML], const d
     }
     const bool any = hi >= lo;  // false when nothing survived (lo = +inf, hi = -inf)
     const bool robust = any && lo > -PRT_INF && (hi - lo) > 1e-6 * ((1.0 + fabs(lo)) + fabs(hi));
+    PRT_COUNT(0, any);
+    PRT_COUNT(1, any && !robust);
     if (any && !robust) touched = box_touched(aabb, ray);
+    // The chord argument covers the axes the ray actually moves along (a slab crossing is off by
+    // ~1e-16 |b| / |d| <= 1e-8, far below the robust margin).  An axis with |d| <= 1e-8 has no
+    // crossing: there upstream's test is the bare comparison lo <= o <= hi (primitives.py:531-565),
+    // which a ray running along a face one ulp outside the box fails however long its chord through
+    // the (object-space) solid is -- found by the adversarial fixtures (tests/scenes.py adv_lens).
+    const bool px = near0(ray.dx), py = near0(ray.dy), pz = near0(ray.dz);
+    if (__ballot(px || py || pz) != 0ull) {
+      const bool outside = (px && !(ray.ox >= aabb[0] && ray.ox <= aabb[1])) ||
+                           (py && !(ray.oy >= aabb[2] && ray.oy <= aabb[3])) ||
+                           (pz && !(ray.oz >= aabb[4] && ray.oz <= aabb[5]));
+      touched = touched && !outside;
+    }
   }
 #pragma unroll
   for (int i = 0; i < ML; ++i) keep_l[i] = keep_l[i] && touched;
@@ -1012,6 +1033,8 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
       bool wanted = false;
 #pragma unroll
       for (int k = 0; k < R; ++k) wanted = wanted || may_reach(step.data, ray[k], best_t[k]);
+      PRT_COUNT(2, true);
+      PRT_COUNT(3, !wanted);
       if (__ballot(wanted) == 0ull) pc += step.a0;  // no lane of the wave needs this component
       continue;
     }

@@ -1468,6 +1468,17 @@ extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64
   return rc64;
 }
 
+#ifdef PRT_COUNT_SLOW
+extern "C" int prt_debug_slow_counters(unsigned long long* out4, int reset) {
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_slow), 4 * sizeof(unsigned long long)) != hipSuccess) return PRT_ERR_HIP;
+  if (reset) {
+    const unsigned long long zero[4] = {0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_slow), zero, sizeof(zero)) != hipSuccess) return PRT_ERR_HIP;
+  }
+  return PRT_OK;
+}
+#endif
+
 extern "C" int prt_trace_stats(const prt_scene* s, double* out8) {
   if (!s || !out8) return fail(PRT_ERR_ARG, "null argument");
   prt_scene* scene = const_cast<prt_scene*>(s);

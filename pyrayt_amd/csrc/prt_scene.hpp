@@ -280,8 +280,7 @@ static int count_steps(const std::vector<DevInstr>& code, int kind) {
 // Is component `root_node` a left-deep chain of two or three leaves whose primitive types have a
 // compiled chain body?  Fills the record if so.
 static bool chain_record(const prt_scene* s, int root_node, const Compiler& c, DevChain* out) {
-  static const bool chain_off = std::getenv("PRT_NO_CHAIN") != nullptr;  // experiment knob
-  if (chain_off) return false;
+  if (std::getenv("PRT_NO_CHAIN") != nullptr) return false;  // A/B and test knob: the step interpreter instead
   const prt_node& top = s->nodes[root_node];
   if (top.op == PRT_NODE_LEAF || s->nodes[top.right].op != PRT_NODE_LEAF) return false;
   int leaves[3], n_leaves, nodes[2];
@@ -337,8 +336,8 @@ static Operand compile_component(const prt_scene* s, int root_node, std::vector<
   // a scene of several components gets a cull step in front of each: most rays can reach only one
   // or two of them (see may_reach); with one or two components the test would cost more than it saves
   size_t box_at = (size_t)-1;
-  static const bool cull_off = std::getenv("PRT_NO_CULL") != nullptr;  // experiment knobs
-  static const int cull_min = std::getenv("PRT_CULL_MIN") ? std::atoi(std::getenv("PRT_CULL_MIN")) : 3;
+  const bool cull_off = std::getenv("PRT_NO_CULL") != nullptr;  // A/B and test knobs, read per scene
+  const int cull_min = std::getenv("PRT_CULL_MIN") ? std::atoi(std::getenv("PRT_CULL_MIN")) : 3;
   if (root_rule == ROOT_TRACE && (int)s->roots.size() >= cull_min && !cull_off) {
     DevInstr in = Compiler::blank(I_BOX);
     double* box = in.data;

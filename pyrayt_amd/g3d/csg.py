@@ -53,11 +53,17 @@ class CSGSurface(Intersectable):
         if not isinstance(operation, Operation):
             raise ValueError(f"operation {operation} is invalid")
         self._operation = operation
+        # the cull box is cached and refreshed through the watch lists, in upstream's order
+        # (csg.py:76-91): watch first, attach the children, flip normals, compute
+        self.var_watchlist.append(self._update_bounding_box)
         self._l_child = l_child
+        self._l_child.attach_to(self)
         self._r_child = r_child
+        self._r_child.attach_to(self)
         if operation is Operation.DIFFERENCE:
             # the subtracted solid shows its inside: flip its normals (csg.py:87-89)
             r_child.invert_normals()
+        self._update_bounding_box()
 
     @property
     def operation(self):
@@ -67,16 +73,23 @@ class CSGSurface(Intersectable):
     def children(self):
         return self._l_child, self._r_child
 
-    @property
-    def bounding_box(self):
-        """World-space cull box, recomputed from the children's current transforms
-        (the reference caches it and refreshes through watch-lists, ``csg.py:93-116``)."""
+    def _update_bounding_box(self):
+        """World-space cull box from the children's *current* boxes (``csg.py:93-116``): the left
+        child's for a DIFFERENCE, the span algebra of both otherwise.  It runs whenever this node or
+        one of the parts attached to it changes its transform -- and only then, which reproduces
+        upstream's stale box of a right-nested tree moved after construction
+        (``world_objects.py:315-317``; tests/golden/scene_stale_box.npz)."""
         if self._operation is Operation.DIFFERENCE:
-            return self._l_child.bounding_box
+            self._aobb = self._l_child.bounding_box
+            return
         l_spans = self._l_child.bounding_box.axis_spans
         r_spans = self._r_child.bounding_box.axis_spans
         lo, hi = zip(*(_span_algebra(l_spans[a], r_spans[a], self._operation) for a in range(3)))
-        return AxisBox(lo, hi)
+        self._aobb = AxisBox(lo, hi)
+
+    @property
+    def bounding_box(self):
+        return self._aobb
 
     def invert_normals(self):
         self._l_child.invert_normals()

@@ -52,6 +52,9 @@ class WorldObject(CountedObject):
         super().__init__(*args, **kwargs)
         self._world = np.identity(4, dtype=float)
         self._object = np.identity(4, dtype=float)
+        # functions called (without arguments) after every change of the world transform
+        # (world_objects.py:98-100, 122-124); CSG nodes hang their bounding-box refresh in here
+        self.var_watchlist = []
 
     # --- matrix access -------------------------------------------------------------------
     def get_world_transform(self):
@@ -90,6 +93,8 @@ class WorldObject(CountedObject):
             # world_objects.py:113-117
             raise ValueError("transform collapses the object's z axis")
         self._object = np.linalg.inv(self._world)
+        for notify in self.var_watchlist:
+            notify()
 
     def transform(self, matrix):
         self._append_world_transform(np.asarray(matrix, dtype=float))
@@ -189,10 +194,14 @@ class Intersectable(WorldObject):
     _normal_scale = 1
 
     def attach_to(self, parent_object):
-        """Remember the object this one is a part of (``world_objects.py:315-317``).  Upstream also
-        chains its change-watch lists through here; nothing is cached on this side -- bounding
-        boxes are derived when asked for -- so the link itself is all there is to keep."""
+        """Become a part of `parent_object` (``world_objects.py:315-317``): from now on a change of
+        this object's transform also runs the functions the parent is watching *at this moment* --
+        which is how a CSG node's cached bounding box follows its children.  Like upstream, what the
+        parent starts watching later (being attached to a node of its own) is not passed down to
+        parts attached earlier: the outer node of a right-nested tree that is moved after construction
+        keeps the box it computed before its inner node's children had moved (see ``csg.CSGSurface``)."""
         self._parent = parent_object
+        self.var_watchlist += parent_object.var_watchlist
 
     def invert_normals(self):
         self._normal_scale = -1

@@ -617,7 +617,8 @@ def render_vectors():
 
 
 def main():
-    which = set(sys.argv[1:]) or {"scenes", "primitives", "csg", "shading", "sources", "summary", "render", "operations", "raw"}
+    which = set(sys.argv[1:]) or {"scenes", "primitives", "csg", "shading", "sources", "summary", "render", "operations", "raw",
+                                  "adversarial", "stale"}
     print(f"numpy {np.__version__} pandas {pd.__version__} (reference locks numpy 1.20.2 / pandas 1.2.4)")
     if "scenes" in which:
         scene_fixture("config1", 100, 1000)
@@ -629,6 +630,11 @@ def main():
         scene_fixture("tutorial", 10, 10)
         scene_fixture("mirrors_and_stops", 6, 4096)
         scene_fixture("stopped_lens", 10, 2048, allow_sensitive=True)
+    if "adversarial" in which:  # rays on the thresholds of the engine's shortcuts (tests/scenes.py adv_*)
+        for name in ("adv_lens", "adv_stop", "adv_prism", "adv_condenser"):
+            scene_fixture(name, 6, allow_sensitive=True)
+    if "stale" in which:  # upstream's cached cull box of a right-nested tree moved after construction
+        scene_fixture("stale_box", 6, 3000, allow_sensitive=True)
     if "primitives" in which:
         primitive_vectors()
     if "csg" in which:

@@ -218,6 +218,234 @@ def stopped_lens(api, n, seed=21):
 
 
 # ---------------------------------------------------------------------------------------------
+# adversarial ray families: rays constructed to sit on the thresholds of the engine's shortcuts
+# (lazily implied cull box: survivors a "robust" distance apart; component cull boxes: padded by
+# 1e-3 of the diagonal; right-leaf skip: no positive entry on the left) and of numpy's own
+# isclose branches (|x| <= 1e-8).  Offsets sweep many decades through every threshold, so the
+# 0.5x / 1x / 2x neighbourhoods are all sampled.
+# ---------------------------------------------------------------------------------------------
+def _sweep(lo=-16, hi=-3, per_decade=4):
+    mags = 10.0 ** np.arange(lo, hi + 1e-9, 1.0 / per_decade)
+    return np.concatenate([[0.0], mags, -mags])
+
+
+def _unit(v):
+    v = np.asarray(v, dtype=float)
+    return v / np.linalg.norm(v)
+
+
+def _rays_from(origins, directions, wavelength=0.633):
+    origins, directions = np.atleast_2d(origins), np.atleast_2d(directions)
+    rays = blank_rays(len(origins), wavelength)
+    rays[0:3] = origins.T
+    rays[4:7] = directions.T
+    return rays
+
+
+def _grazing(centre, radius, normal, tangent, depths, standoff):
+    """Rays tangent to a sphere at centre + radius * normal, pushed in by `depths` (negative: miss)."""
+    n, u = _unit(normal), _unit(tangent)
+    point = np.asarray(centre, dtype=float) + radius * n
+    origins = [point - d * n - standoff * u for d in depths]
+    return origins, [u] * len(depths)
+
+
+def _aimed(origin, targets):
+    origin = np.asarray(origin, dtype=float)
+    return [origin] * len(targets), [_unit(np.asarray(t, dtype=float) - origin) for t in targets]
+
+
+def _tiny_components(base_direction, axis, scale=1e-8):
+    """base direction with one component replaced by scale * {0, 0.5, 1, 2, -1} (not renormalised:
+    the thresholds are on the components themselves)."""
+    out = []
+    for f in (0.0, 0.5, 0.999, 1.0, 1.001, 2.0, -1.0, -0.5):
+        d = np.array(base_direction, dtype=float)
+        d[axis] = f * scale
+        out.append(d)
+    return out
+
+
+def stale_box(api, n, seed=31):
+    """A right-nested CSG tree moved after construction, whose outer cull box upstream leaves stale
+    (world_objects.py:315-317, csg.py:76-91), next to a left-nested twin and a detector."""
+    cg, matl = api.cg, api.materials
+    glass = matl.glass["ideal"]
+    inner = cg.csg.intersect(cg.Cylinder(0.7, -1, 1, material=glass).rotate_x(90),
+                             cg.Sphere(1.0, material=glass).move_x(0.4))
+    right_nested = cg.csg.union(cg.Sphere(0.9, material=glass).move_x(-0.8), inner)
+    right_nested.move(1.5, 0.5, -0.25).rotate_z(30)
+    twin_inner = cg.csg.intersect(cg.Cylinder(0.7, -1, 1, material=matl.mirror).rotate_x(90),
+                                  cg.Sphere(1.0, material=matl.mirror).move_x(0.4))
+    left_nested = cg.csg.union(twin_inner, cg.Sphere(0.9, material=matl.mirror).move_x(-0.8))
+    left_nested.move(-2.0, -1.0, 0.5).rotate_y(-20)
+    det = api.components.baffle((8, 8)).move_x(5)
+    return [right_nested, left_nested, det], random_rays(n, seed, box=4.0, wavelength=0.5)
+
+
+def adv_lens(api):
+    """Biconvex lens + detector (the north-star scene; an INTERSECT chain root, two components)."""
+    lens = api.components.biconvex_lens(2, 2, 0.25, aperture=1)
+    det = api.components.baffle((1, 1)).move_x(1)
+    o, d = [], []
+    depths = _sweep(-16, -3)
+    front, back = np.array([1.875, 0, 0]), np.array([-1.875, 0, 0])
+    for rho, phi in ((0.0, 0.0), (0.2, 0.3), (0.45, 2.0), (0.4999, 4.0), (0.5, 1.0), (0.6, 5.0)):
+        for centre, sign in ((front, -1.0), (back, 1.0)):
+            # point of the lens face at radius rho, outward normal, a tangent direction
+            surf = np.array([sign * np.sqrt(4 - rho ** 2), rho * np.cos(phi), rho * np.sin(phi)])
+            normal = surf / 2.0
+            tangent = np.cross(normal, [0.3, -0.5, 0.8])
+            oo, dd = _grazing(centre, 2.0, normal, tangent, depths, 1.7)
+            o += oo; d += dd
+    # the rim where the aperture cylinder meets the front face, and the cylinder wall itself
+    x_rim = 1.875 - np.sqrt(4 - 0.25)
+    for phi in (0.0, 1.1, 3.9):
+        radial = np.array([0.0, np.cos(phi), np.sin(phi)])
+        for src in ((-2.0, 0.0, 0.0), (-1.5, 0.9, -0.4), (0.05, 1.5, 0.2)):
+            oo, dd = _aimed(src, [np.array([x_rim, 0, 0]) + (0.5 + e) * radial for e in depths])
+            o += oo; d += dd
+        # rays running along the wall (tangent to the cylinder) inside the lens thickness
+        along = np.cross(radial, [1.0, 0.0, 0.0])
+        for x in (-0.05, 0.0, 0.06):
+            o += [np.array([x, 0, 0]) + (0.5 + e) * radial - 1.3 * along for e in depths]
+            d += [along] * len(depths)
+    # axis-parallel rays (exact zeros) at and around the aperture radius, and the tiny-component family
+    for e in depths:
+        o.append([-2.0, 0.5 + e, 0.0]); d.append([1.0, 0.0, 0.0])
+        o.append([-2.0, 0.0, 0.25 + e]); d.append([1.0, 0.0, 0.0])
+    for axis in range(3):
+        for base in ([1.0, 0.02, -0.01], [0.6, 0.8, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, -1.0]):
+            for vec in _tiny_components(base, axis):
+                o.append([-1.0, 0.1, -0.07] if base[0] else [0.0, -1.5 * base[1], 1.5 * (-base[2])]); d.append(vec)
+    # nearly axial rays: the cylinder's a = dy^2 + dz^2 crosses 1e-8 at |d_perp| = 1e-4 (SURVEY Q5)
+    for f in (0.25, 0.5, 0.9, 0.99, 1.0, 1.01, 1.1, 2.0, 4.0, 16.0):
+        for y0 in (0.0, 0.05, 0.3, 0.49):
+            o.append([-2.0, y0, 0.01]); d.append([1.0, f * 1e-4, 0.0])
+            o.append([-2.0, y0, -0.02]); d.append([1.0, f * 0.6e-4, -f * 0.8e-4])
+    o.append([-2.0, 0.0, 0.0]); d.append([0.0, 0.0, 0.0])  # an absorbed (zero-direction) ray
+    return [lens, det], _rays_from(o, d)
+
+
+def adv_stop(api):
+    """Aperture stop (Plane - Cylinder: the Plane's double hit inside a DIFFERENCE), a thick lens with
+    concave faces (DIFFERENCE chain) and a detector: three components, so cull steps are active."""
+    c = api.components
+    stop = c.aperture((3.0, 3.0), 0.5).move_x(-0.5)
+    lens = c.thick_lens(-3.0, 3.0, 0.2, aperture=1.2, material=api.materials.glass["BK7"]).move_x(0.5)
+    det = c.baffle((4, 4)).move_x(2.5)
+    o, d = [], []
+    depths = _sweep(-16, -3)
+    # the edge of the hole (radius 0.25) and of the plate (half side 1.5), several incidences
+    for phi in (0.0, 0.7, 2.4, 4.1):
+        radial = np.array([0.0, np.cos(phi), np.sin(phi)])
+        for src in ((-3.0, 0.0, 0.0), (-2.0, 0.8, 0.3), (-0.6, 0.2, -0.1), (1.0, 0.1, 0.1)):
+            oo, dd = _aimed(src, [np.array([-0.5, 0, 0]) + (0.25 + e) * radial for e in depths])
+            o += oo; d += dd
+        for e in depths:  # normal incidence, exact zeros in the direction
+            o.append(np.array([-3.0, 0, 0]) + (0.25 + e) * radial); d.append([1.0, 0.0, 0.0])
+    for e in depths:
+        o.append([-3.0, 1.5 + e, 0.3]); d.append([1.0, 0.0, 0.0])
+        o.append([-3.0, -0.2, -1.5 + e]); d.append(_unit([1.0, 0.01, 0.0]))
+        # rays skimming the plate: parallel to it at distance e, and starting on it
+        o.append([-0.5 + e, -2.0, 0.1]); d.append([0.0, 1.0, 0.0])
+        o.append([-0.5 + e, 0.9, 0.1]); d.append(_unit([0.3, -0.2, 0.9]))
+    # concave faces of the lens: centres at x = 0.5 -+ (3 + 0.1); grazing the inside of the cut
+    for centre, sign in ((np.array([0.5 - 3.1, 0, 0]), 1.0), (np.array([0.5 + 3.1, 0, 0]), -1.0)):
+        for rho, phi in ((0.0, 0.0), (0.3, 1.0), (0.59, 3.0), (0.6, 5.0)):
+            surf = np.array([sign * np.sqrt(9 - rho ** 2), rho * np.cos(phi), rho * np.sin(phi)])
+            tangent = np.cross(surf, [0.2, 0.9, -0.4])
+            oo, dd = _grazing(centre, 3.0, surf / 3.0, tangent, depths, 1.1)
+            o += oo; d += dd
+    # origins on, just inside and just outside the padded component boxes (pad = 1e-3 * diagonal):
+    # the lens solid spans x in [0.4 - sag, 0.6 + sag], |y|,|z| <= 0.6; the plate is 3 x 3 at x = -0.5
+    for (lo, hi) in (((0.3394, -0.6, -0.6), (0.6606, 0.6, 0.6)), ((-0.55, -1.5, -1.5), (-0.45, 1.5, 1.5))):
+        lo, hi = np.array(lo), np.array(hi)
+        pad = 1e-3 * np.linalg.norm(hi - lo)
+        for axis in range(3):
+            for face, outward in ((lo, -1.0), (hi, 1.0)):
+                for e in np.concatenate([depths[::3], pad + depths[::2], pad * (1 + depths[::3])]):
+                    p = 0.5 * (lo + hi) + 0.0
+                    p[axis] = face[axis] + outward * e
+                    inward = np.zeros(3); inward[axis] = -outward
+                    o.append(p.copy()); d.append(inward)                        # straight in
+                    side = np.zeros(3); side[(axis + 1) % 3] = 1.0
+                    o.append(p.copy()); d.append(side)                          # along the face
+                    o.append(p.copy()); d.append(_unit(-inward + 0.3 * side))   # away from the box
+    o.append([0.0, 0.0, 0.0]); d.append([0.0, 0.0, 0.0])
+    return [stop, lens, det], _rays_from(o, d, wavelength=0.55)
+
+
+def adv_prism(api):
+    """Equilateral prism (a DIFFERENCE chain of cuboids: faces of the body and of the wedges meet in
+    edges, i.e. equal parameters from different surfaces), a mirror slab and a detector."""
+    c = api.components
+    prism = c.equilateral_prism(1, 1).move_x(0.25)
+    slab = c.plane_mirror(0.2, aperture=(1.0, 1.0)).move_x(2.0)
+    det = c.baffle((3, 3)).rotate_y(90).move(1, 0, -1.5)
+    o, d = [], []
+    depths = _sweep(-16, -3)
+    s60 = np.sin(np.radians(60))
+    z0 = 0.5 * (1 - s60)
+    # vertices of the triangular cross section (y is the extrusion axis): base corners and the apex
+    base_l, base_r, apex = np.array([-0.25, 0, z0 - 0.5]), np.array([0.75, 0, z0 - 0.5]), np.array([0.25, 0, z0 - 0.5 + s60])
+    for corner in (base_l, base_r, apex):
+        for src in ((-1.0, 0.1, 0.0), (0.25, -0.2, -2.0), (2.0, 0.3, 0.4), (0.25, 0.0, 2.0)):
+            for wiggle in ([1.0, 0, 0], [0, 0, 1.0], _unit([1, 0, 1])):
+                oo, dd = _aimed(src, [corner + np.array([0, 0.1, 0]) + e * np.array(wiggle) for e in depths[::2]])
+                o += oo; d += dd
+    # the end faces y = +-0.5 and their edges; axis-parallel rays with exact zeros
+    for e in depths:
+        o.append([-1.0, 0.5 + e, z0 - 0.2]); d.append([1.0, 0.0, 0.0])
+        o.append([0.25, -2.0, z0 - 0.5 + e]); d.append([0.0, 1.0, 0.0])
+        o.append([0.25 + e, 0.2, -2.0]); d.append([0.0, 0.0, 1.0])
+        o.append([-1.0, 0.1, z0 - 0.5 + e]); d.append([1.0, 0.0, 0.0])       # skimming the base
+        o.append([1.5, 0.5 + e, 0.0]); d.append([1.0, 0.0, 0.0])             # edge of the mirror slab
+    for axis in range(3):
+        for base in ([1.0, 0.0, 0.1], [0.5, 0.1, 0.85]):
+            for vec in _tiny_components(base, axis):
+                o.append([-1.0, 0.05, -0.1]); d.append(vec)
+    o.append([0.0, 0.0, 0.0]); d.append([0.0, 0.0, 0.0])
+    return [prism, slab, det], _rays_from(o, d, wavelength=0.5)
+
+
+def adv_condenser(api):
+    """Paraboloid & Cylinder (config 5's INTERSECT pair) with a spherical mirror behind it and a detector."""
+    cg, c, glass = api.cg, api.components, api.materials.glass["BK7"]
+    body = cg.csg.intersect(
+        cg.Paraboloid(2.0, 1.0, material=glass),
+        cg.Cylinder(1.5, -0.25, 0.75, material=glass),
+    ).rotate_y(90)
+    mirror = c.spherical_mirror(6.0, 0.5, aperture=2.0).rotate_y(180).move_x(5)
+    det = c.baffle((6, 6)).move_x(-3)
+    o, d = [], []
+    depths = _sweep(-16, -3)
+    # rim of the cap (x = 0.75, radius sqrt(4*2*0.75) = 2.449 > 1.5: the cylinder clips first at 1.5,
+    # where the paraboloid is at x = 1.5^2 / 8 = 0.28125) and the cap plane itself
+    for phi in (0.0, 2.2, 4.4):
+        radial = np.array([0.0, np.cos(phi), np.sin(phi)])
+        for src in ((-2.0, 0.0, 0.0), (3.0, 0.4, -0.2), (0.5, 3.0, 0.1)):
+            oo, dd = _aimed(src, [np.array([0.28125, 0, 0]) + (1.5 + e) * radial for e in depths])
+            o += oo; d += dd
+            oo, dd = _aimed(src, [np.array([0.75 + e, 0, 0]) + 1.2 * radial for e in depths[::2]])
+            o += oo; d += dd
+    # rays parallel to the axis: a = dy^2 + dz^2 crosses 1e-8 at |d_perp| = 1e-4 (both primitives'
+    # linear branches), and exactly axial rays
+    for f in (0.0, 0.25, 0.5, 0.9, 0.99, 1.0, 1.01, 1.1, 2.0, 4.0, 16.0):
+        for y0 in (0.0, 0.4, 1.2, 1.4999, 1.5, 1.6):
+            for sx in (1.0, -1.0):
+                o.append([-2.0 * sx, y0, 0.03]); d.append([sx, f * 1e-4, 0.0])
+                o.append([-2.0 * sx, 0.1, y0]); d.append([sx, f * 0.6e-4, f * 0.8e-4])
+    # the vertex region and rays in the cap plane
+    for e in depths:
+        o.append([e, -3.0, 0.0]); d.append([0.0, 1.0, 0.0])
+        o.append([0.75 + e, -3.0, 0.2]); d.append([0.0, 1.0, 0.0])
+        o.append([-0.25 + e, -3.0, 0.2]); d.append([0.0, 1.0, 0.0])
+    o.append([0.0, 0.0, 0.0]); d.append([0.0, 0.0, 0.0])
+    return [body, mirror, det], _rays_from(o, d, wavelength=0.59)
+
+
+# ---------------------------------------------------------------------------------------------
 # renderer views (tinygfx/g3d/renderers.py): (surfaces, camera, light position)
 # ---------------------------------------------------------------------------------------------
 def draw_camera(api, surfaces, view, resolution):
@@ -314,4 +542,9 @@ SCENES = {
     "two_mirrors": two_mirrors,
     "tutorial": tutorial,
     "mirrors_and_stops": mirrors_and_stops,
+    "stale_box": stale_box,
+    "adv_lens": adv_lens,
+    "adv_stop": adv_stop,
+    "adv_prism": adv_prism,
+    "adv_condenser": adv_condenser,
 }

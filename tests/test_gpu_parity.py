@@ -18,7 +18,9 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 SCENE_FIXTURES = ["config1", "config2", "config3", "config4", "config5", "two_mirrors",
-                  "tutorial", "mirrors_and_stops", "stopped_lens"]
+                  "tutorial", "mirrors_and_stops", "stopped_lens",
+                  # adversarial families (tests/scenes.py adv_*) and upstream's stale cull box
+                  "adv_lens", "adv_stop", "adv_prism", "adv_condenser", "stale_box"]
 KINDS = ("sphere", "cylinder", "plane", "cube", "paraboloid")
 VARIANTS = ("identity", "moved", "rotated", "scaled")
 
@@ -72,6 +74,26 @@ def test_trace_matches_reference(name, flags):
     rows, counts = ds.trace(dev(fx["rays0"]), int(fx["generation_limit"]), flags=flags)
     helpers.assert_frames_match(rows.cpu().numpy().T, fx["frame"], what=f"{name} flags={flags}")
     assert sum(counts) == fx["frame"].shape[0]
+    ds.close()
+
+
+@pytest.mark.parametrize("name", SCENE_FIXTURES)
+@pytest.mark.parametrize("knob", ["PRT_NO_CHAIN", "PRT_NO_CULL", "PRT_CULL_MIN"])
+def test_trace_matches_reference_on_every_program_form(name, knob, monkeypatch):
+    """The same goldens with the scene compiled to the other program forms: the step interpreter
+    instead of chain steps, no component cull steps, cull steps from two components on."""
+    monkeypatch.setenv(knob, "2" if knob == "PRT_CULL_MIN" else "1")
+    fx = helpers.load(f"scene_{name}.npz")
+    ds = device_scene(helpers.scene_of(fx))
+    info = ds.info()
+    if knob == "PRT_NO_CHAIN":
+        assert info["chain_steps"] == 0
+    if knob == "PRT_NO_CULL":
+        assert info["cull_steps"] == 0
+    rows, counts = ds.trace(dev(fx["rays0"]), int(fx["generation_limit"]))
+    helpers.assert_frames_match(rows.cpu().numpy().T, fx["frame"], what=f"{name} {knob}")
+    t, surf = ds.propagate(dev(fx["rays0"]))
+    assert np.array_equal(surf.cpu().numpy(), fx["surf_0"]), f"{name} {knob}: surfaces"
     ds.close()
 
 
