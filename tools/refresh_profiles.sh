@@ -1,17 +1,23 @@
 #!/bin/bash
 # One GPU-box pass that regenerates everything under profiles/<round>/ from the current build:
 #   bench line, rocprofv3 kernel-trace stats of the same command, HBM traffic (PMC, calibrated),
-#   SQ issue/stall counters of k_generation and k_hit, renderer kernel stats.
-# usage (through gpurun): bash tools/refresh_profiles.sh ; then copy gpurun_out/refresh/* into profiles/
+#   SQ issue/stall counters of k_generation and k_hit, renderer kernel stats, and the other
+#   BASELINE configs at their per-GPU sizes (bench line + kernel stats each).
+# usage (through gpurun): bash tools/refresh_profiles.sh ; then copy gpurun_out/refresh/* into profiles/<round>/
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/refresh
 rm -rf $out $R/gpurun_out/traffic $R/gpurun_out/sq; mkdir -p $out
 cd $R
+(cd tools/ubench && make -s copy_f64 >/dev/null 2>&1)
 python3 bench.py > $out/bench.json 2> $out/bench.err
-python3 bench.py --workload config3 --no-cpu-baseline > $out/bench_config3.json 2>> $out/bench.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $out/trace.log 2>&1
+for cfg in "config3 4000000" "config4 8000000" "config5 2000000"; do
+  set -- $cfg
+  python3 $R/bench.py --workload $1 --rays $2 --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_$1.json 2>> $out/bench.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace_$1 -- python3 $R/bench.py --workload $1 --rays $2 --steps 5 --warmup 2 --no-cpu-baseline > $out/trace_$1.log 2>&1
+done
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o render -- python3 $R/tools/render_bench.py --width 640 8192 --cpu-pixels 20000 > $out/render.log 2>&1
 cd $R
 bash tools/traffic.sh > $out/traffic.log 2>&1
@@ -24,5 +30,7 @@ cp gpurun_out/traffic/bench_FETCH_SIZE_counter_collection.csv $out/k_generation_
 cp gpurun_out/traffic/bench_WRITE_SIZE_counter_collection.csv $out/k_generation_pmc_WRITE_SIZE.csv
 cp gpurun_out/traffic/cal_FETCH_SIZE_counter_collection.csv $out/calibration_pmc_FETCH_SIZE.csv
 cp gpurun_out/traffic/cal_WRITE_SIZE_counter_collection.csv $out/calibration_pmc_WRITE_SIZE.csv
-ls -la $out | head -40
-tail -1 $out/bench.json | cut -c1-400
+# keep the summaries, drop the bulky per-dispatch traces
+rm -f $out/*_kernel_trace.csv $out/*_agent_info.csv $out/*domain_stats.csv
+ls -la $out | head -60
+tail -1 $out/bench.json | cut -c1-600
