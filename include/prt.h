@@ -256,6 +256,8 @@ int prt_place_rows(int device, const double* staging, int64_t stride_rank, int64
  * out[7] = PRT_VARIANT_* the last trace ran on. */
 #define PRT_VARIANT_FUSED 1       /* one ray per lane, one fused kernel per generation */
 #define PRT_VARIANT_UNFUSED 2     /* propagate / scan / interact kernels per generation */
+#define PRT_VARIANT_KLANES 3      /* ... with the surface-parallel nearest-hit kernel (K lanes per ray,
+                                     shuffle min-reduce; environment PRT_HIT_VARIANT=lanes4|lanes8|lanes16) */
 int prt_trace_stats(const prt_scene* scene, double* out8);
 
 /* ---- renderers (second consumer of the intersect path) ----------

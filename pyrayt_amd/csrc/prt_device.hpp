@@ -1046,6 +1046,30 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
   }
 }
 
+// One component's candidate with a *per-lane* program counter: steps [first, last) of `code`, which may
+// differ from lane to lane (the k-lanes-per-ray kernels give every lane of a ray's group its own
+// components).  Step records are then per-lane data: they arrive through vector loads, or from an LDS
+// copy of the program, not through the scalar cache.  The wave-level shortcuts inside the steps
+// (ballots over the active lanes) stay valid: each only ever skips work when *no* active lane needs it.
+__device__ __forceinline__ void component_candidate(const DevInstr* code, int first, int last, const Ray8& ray,
+                                                    const LaneLists& lists, double& t, int& prim) {
+  Pair ra = {PRT_INF, PRT_INF, -1}, rb = {PRT_INF, PRT_INF, -1};
+  t = PRT_INF;
+  prim = -1;
+  for (int pc = first; pc < last; ++pc) {
+    const DevInstr* in = code + pc;
+    const int kind = in->kind;
+    if (kind == I_CHAIN) {
+      chain_step(reinterpret_cast<const DevChain*>(in), in->a0, ray, t, prim);
+      pc += CHAIN_SLOTS - 1;
+    } else if (kind == I_BOX) {
+      if (!may_reach(in->data, ray, PRT_INF)) return;  // the cull step leads its component
+    } else {
+      run_step<false>(in, ray, lists, ra, rb, t, prim);
+    }
+  }
+}
+
 template <bool RENDER = false, bool CULL = true>
 __device__ __forceinline__ void nearest_hit(const DevPrim* __restrict__ prims,
                                             const DevInstr* __restrict__ code, int n_instr,

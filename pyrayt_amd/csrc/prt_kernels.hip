@@ -76,6 +76,9 @@ __device__ __forceinline__ int prim_of_surface(const DevPrim* __restrict__ prims
 
 // [_st_propagate] nearest hit + per-workgroup counts of live / carried rays.
 // prt_propagate uses the same kernel with counts == nullptr and surf_out != nullptr.
+// STAGED (experiment, A/B partner of the scalar-load step fetch): the workgroup first copies the
+// program into LDS and the interpreter reads its steps from there.
+template <bool STAGED>
 __global__ void __launch_bounds__(PRT_BLOCK)
 k_hit(SceneDev scene, const double* __restrict__ rays, int64_t ld, const TraceCtrl* __restrict__ ctrl,
       int64_t n_fixed, double* __restrict__ hit_t, int32_t* __restrict__ hit_prim,
@@ -83,12 +86,21 @@ k_hit(SceneDev scene, const double* __restrict__ rays, int64_t ld, const TraceCt
   const int64_t n = ctrl ? ctrl->n_cur : n_fixed;
   const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
   const LaneLists lists = lane_lists(scene.lds_slots);
+  const DevInstr* code = scene.code;
+  if (STAGED) {
+    double* stage = lds_dyn + ((3 * scene.lds_slots + 1) / 2) * PRT_BLOCK;
+    const double* src = reinterpret_cast<const double*>(scene.code);
+    const int words = scene.n_instr * (int)(sizeof(DevInstr) / sizeof(double));
+    for (int k = threadIdx.x; k < words; k += PRT_BLOCK) stage[k] = src[k];
+    __syncthreads();
+    code = reinterpret_cast<const DevInstr*>(stage);
+  }
   bool live = false, carry = false;
   if (i < n) {
     const Ray8 r = load_ray8(rays, ld, i);
     double t;
     int prim;
-    nearest_hit(scene.prims, scene.code, scene.n_instr, r, lists, t, prim);
+    nearest_hit(scene.prims, code, scene.n_instr, r, lists, t, prim);
     hit_t[i] = t;
     if (hit_prim) hit_prim[i] = prim;
     if (surf_out) surf_out[i] = prim >= 0 ? (int64_t)scene.prims[prim].surface_id : -1;
@@ -109,6 +121,72 @@ k_hit(SceneDev scene, const double* __restrict__ rays, int64_t ld, const TraceCt
     if (threadIdx.x == 0) {
       block_counts[2 * blockIdx.x + 0] = s_live;
       block_counts[2 * blockIdx.x + 1] = s_carry;
+    }
+  }
+}
+
+// [_st_propagate, surface-parallel form] K lanes per ray.  Lane j of a ray's group evaluates components
+// j, j + K, ... (each with its own program counter), then the group reduces its candidates with
+// wavefront shuffles to the lexicographic minimum of (t, component order) -- exactly the running
+// strict '<' minimum of _pyrayt.py:380-386: the earliest component among those with the smallest t.
+// Lane 0 of the group owns the ray's outputs.  STAGED: the program is first copied to LDS by the
+// workgroup and the per-lane step records are read from there (ds_read) instead of through vector
+// loads -- the north-star sketch's "LDS-staged surface transform matrices".
+template <int K, bool STAGED>
+__global__ void __launch_bounds__(PRT_BLOCK)
+k_hit_lanes(SceneDev scene, const int32_t* __restrict__ comp_first, int n_comp,
+            const double* __restrict__ rays, int64_t ld, const TraceCtrl* __restrict__ ctrl, int64_t n_fixed,
+            double* __restrict__ hit_t, int32_t* __restrict__ hit_prim, int64_t* __restrict__ surf_out,
+            int32_t* __restrict__ tile_counts, int keep_absorbed) {
+  constexpr int RAYS = PRT_BLOCK / K;
+  const int64_t n = ctrl ? ctrl->n_cur : n_fixed;
+  const int sub = threadIdx.x % K;
+  const int64_t i = (int64_t)blockIdx.x * RAYS + threadIdx.x / K;
+  const LaneLists lists = lane_lists(scene.lds_slots);
+  const DevInstr* code = scene.code;
+  if (STAGED) {
+    // the program behind the hit lists, 16-byte aligned; every thread copies a strided share
+    double* stage = lds_dyn + ((3 * scene.lds_slots + 1) / 2) * PRT_BLOCK;
+    const double* src = reinterpret_cast<const double*>(scene.code);
+    const int words = scene.n_instr * (int)(sizeof(DevInstr) / sizeof(double));
+    for (int k = threadIdx.x; k < words; k += PRT_BLOCK) stage[k] = src[k];
+    __syncthreads();
+    code = reinterpret_cast<const DevInstr*>(stage);
+  }
+  bool live = false, carry = false;
+  if (i < n) {
+    const Ray8 r = load_ray8(rays, ld, i);
+    double best_t = PRT_INF;
+    int best_prim = -1, best_comp = 0x7fffffff;
+    for (int c = sub; c < n_comp; c += K) {
+      double t;
+      int prim;
+      component_candidate(code, comp_first[c], comp_first[c + 1], r, lists, t, prim);
+      if (t < best_t) { best_t = t; best_prim = prim; best_comp = c; }
+    }
+#pragma unroll
+    for (int off = K / 2; off > 0; off >>= 1) {  // group of K adjacent lanes, K a power of two <= 64
+      const double t2 = __shfl_xor(best_t, off);
+      const int p2 = __shfl_xor(best_prim, off), c2 = __shfl_xor(best_comp, off);
+      const bool take = t2 < best_t || (t2 == best_t && c2 < best_comp);
+      best_t = take ? t2 : best_t;
+      best_prim = take ? p2 : best_prim;
+      best_comp = take ? c2 : best_comp;
+    }
+    if (sub == 0) {
+      hit_t[i] = best_t;
+      if (hit_prim) hit_prim[i] = best_prim;
+      if (surf_out) surf_out[i] = best_prim >= 0 ? (int64_t)scene.prims[best_prim].surface_id : -1;
+      live = is_live(r, best_prim);
+      carry = live && (keep_absorbed || scene.prims[best_prim].mat_kind != MAT_ABSORBER);
+    }
+  }
+  if (tile_counts) {  // counts per PRT_BLOCK-ray tile, the unit k_scan / k_shade work in (zeroed by the caller)
+    const int w_live = __popcll(__ballot(live)), w_carry = __popcll(__ballot(carry));
+    if ((threadIdx.x & 63) == 0 && (w_live | w_carry)) {
+      const int64_t first_ray = (int64_t)blockIdx.x * RAYS + (threadIdx.x / K);
+      atomicAdd(&tile_counts[2 * (first_ray / PRT_BLOCK)], w_live);
+      atomicAdd(&tile_counts[2 * (first_ray / PRT_BLOCK) + 1], w_carry);
     }
   }
 }
@@ -954,7 +1032,14 @@ k_material_trace(const DevPrim* __restrict__ prim, double* __restrict__ rays, in
 static int raise_lds_limits() {
   HIP_TRY(hipFuncSetAttribute((const void*)k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_render_hits, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
-  HIP_TRY(hipFuncSetAttribute((const void*)k_hit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_hit<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_hit<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_hit_lanes<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_hit_lanes<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_hit_lanes<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_hit_lanes<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_hit_lanes<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_hit_lanes<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_generation<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_generation<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
 #ifdef PRT_EXPERIMENTS
@@ -990,6 +1075,58 @@ static SceneDev trace_scene_dev(const prt_scene* s, const DeviceCopy* c) {
   return sd;
 }
 
+// ---- nearest-hit kernel selection -----------------------------------------------------------------
+// PRT_HIT_VARIANT = "lanes4" | "lanes8" | "lanes16" (surface-parallel: K lanes per ray, shuffle
+// min-reduce) and/or "lds" (program staged in LDS), e.g. "lanes8,lds".  Read per call; applies to
+// prt_propagate and to the three-kernel trace (PRT_TRACE_UNFUSED).  Default: one ray per lane, steps
+// through the scalar cache -- the measured winner.
+struct HitVariant {
+  int lanes = 1;
+  bool staged = false;
+};
+static HitVariant hit_variant() {
+  HitVariant v;
+  if (const char* env = getenv("PRT_HIT_VARIANT")) {
+    const std::string text(env);
+    if (text.find("lanes16") != std::string::npos) v.lanes = 16;
+    else if (text.find("lanes8") != std::string::npos) v.lanes = 8;
+    else if (text.find("lanes4") != std::string::npos) v.lanes = 4;
+    v.staged = text.find("lds") != std::string::npos;
+  }
+  return v;
+}
+
+// n_bound: rays the grid must cover (the kernels read the exact count from ctrl when given);
+// tile_counts: (live, carried) per PRT_BLOCK-ray tile, or null
+static int launch_hit(const prt_scene* s, const DeviceCopy* c, const SceneDev& sd, hipStream_t st,
+                      const double* rays, int64_t ld, const TraceCtrl* ctrl, int64_t n_fixed, int64_t n_bound,
+                      double* hit_t, int32_t* hit_prim, int64_t* surf_out, int32_t* tile_counts,
+                      int keep_absorbed) {
+  const HitVariant v = hit_variant();
+  size_t lds = lds_bytes(sd.lds_slots);
+  if (v.staged) lds = align_up(lds, 16) + (size_t)sd.n_instr * sizeof(DevInstr) + 8 * PRT_BLOCK;
+  if (lds > kMaxLdsBytes) return fail(PRT_ERR_SCENE, "program too large to stage in LDS");
+  if (v.lanes == 1) {
+    auto kernel = v.staged ? k_hit<true> : k_hit<false>;
+    hipLaunchKernelGGL(kernel, dim3(blocks_for(n_bound)), dim3(PRT_BLOCK), lds, st, sd, rays, ld, ctrl, n_fixed,
+                       hit_t, hit_prim, surf_out, tile_counts, keep_absorbed);
+  } else {
+    if (tile_counts) HIP_TRY(hipMemsetAsync(tile_counts, 0, (size_t)blocks_for(n_bound) * 2 * sizeof(int32_t), st));
+    const int n_comp = (int)s->roots.size();
+    const unsigned grid = (unsigned)((n_bound + PRT_BLOCK / v.lanes - 1) / (PRT_BLOCK / v.lanes));
+#define PRT_LAUNCH_LANES(K, STAGED)                                                                          \
+    hipLaunchKernelGGL((k_hit_lanes<K, STAGED>), dim3(grid), dim3(PRT_BLOCK), lds, st, sd,                    \
+                       (const int32_t*)c->trace_component_first, n_comp, rays, ld, ctrl, n_fixed, hit_t,     \
+                       hit_prim, surf_out, tile_counts, keep_absorbed)
+    if (v.lanes == 4) { if (v.staged) PRT_LAUNCH_LANES(4, true); else PRT_LAUNCH_LANES(4, false); }
+    else if (v.lanes == 8) { if (v.staged) PRT_LAUNCH_LANES(8, true); else PRT_LAUNCH_LANES(8, false); }
+    else { if (v.staged) PRT_LAUNCH_LANES(16, true); else PRT_LAUNCH_LANES(16, false); }
+#undef PRT_LAUNCH_LANES
+  }
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}
+
 extern "C" int prt_intersect(prt_scene* s, int device, int root, const double* rays, int64_t n,
                              int64_t ld, double* hits_out, int64_t* ids_out, int64_t ld_out,
                              void* stream) {
@@ -1018,11 +1155,8 @@ extern "C" int prt_propagate(prt_scene* s, int device, const double* rays, int64
     return fail(PRT_ERR_ARG, "bad ray / output buffers");
   if (n == 0) return PRT_OK;
   SceneDev sd = trace_scene_dev(s, c);
-  hipLaunchKernelGGL(k_hit, dim3(blocks_for(n)), dim3(PRT_BLOCK), lds_bytes(sd.lds_slots),
-                     (hipStream_t)stream, sd, rays, ld, (const TraceCtrl*)nullptr, n, t_out,
-                     (int32_t*)nullptr, surf_out, (int32_t*)nullptr, 1);
-  HIP_TRY(hipGetLastError());
-  return PRT_OK;
+  return launch_hit(s, c, sd, (hipStream_t)stream, rays, ld, (const TraceCtrl*)nullptr, n, n, t_out,
+                    (int32_t*)nullptr, surf_out, (int32_t*)nullptr, 1);
 }
 
 extern "C" int prt_generate_rays(int device, const prt_source* source, int64_t n_total,
@@ -1228,7 +1362,6 @@ static int64_t trace_unfused(prt_scene* s, DeviceCopy* c, const double* rays, in
   const int keep_absorbed = (flags & PRT_TRACE_KEEP_ABSORBED) ? 1 : 0;
 
   SceneDev sd = trace_scene_dev(s, c);
-  const size_t lds = lds_bytes(sd.lds_slots);
   hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, st, ctrl, n, rows_cap);
 
   const double* src = rays;
@@ -1240,9 +1373,11 @@ static int64_t trace_unfused(prt_scene* s, DeviceCopy* c, const double* rays, in
     const unsigned nb = blocks_for(n_cur);
     const int relaunch = (g + 1 != generation_limit) ? 1 : 0;
     HIP_TRY(hipEventRecord(c->ev0, st));
-    hipLaunchKernelGGL(k_hit, dim3(nb), dim3(PRT_BLOCK), lds, st, sd, src, src_ld,
-                       (const TraceCtrl*)ctrl, (int64_t)0, hit_t, hit_prim, (int64_t*)nullptr,
-                       counts, keep_absorbed);
+    {
+      int rc_hit = launch_hit(s, c, sd, st, src, src_ld, (const TraceCtrl*)ctrl, (int64_t)0, n_cur, hit_t, hit_prim,
+                              (int64_t*)nullptr, counts, keep_absorbed);
+      if (rc_hit) return rc_hit;
+    }
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, (const int32_t*)counts, offsets, ctrl);
     hipLaunchKernelGGL(k_shade, dim3(nb), dim3(PRT_BLOCK), 0, st, sd, src, src_ld,
                        (const TraceCtrl*)ctrl, (int64_t)0, (const double*)hit_t,
@@ -1447,7 +1582,7 @@ extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64
   if (n == 0 || generation_limit == 0) return 0;
   s->stats[6] = (double)s->lookback_fallbacks;
   if (flags & PRT_TRACE_UNFUSED) {
-    s->stats[7] = PRT_VARIANT_UNFUSED;
+    s->stats[7] = hit_variant().lanes > 1 ? PRT_VARIANT_KLANES : PRT_VARIANT_UNFUSED;
     return trace_unfused(s, c, rays, n, ld, generation_limit, ray_offset, rows_out, rows_cap,
                          rows_per_generation, (char*)workspace, flags, (hipStream_t)stream);
   }

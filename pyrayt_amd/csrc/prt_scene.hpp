@@ -35,11 +35,13 @@ struct SceneDev {
 struct Program {
   std::vector<DevInstr> code;
   int lds_slots = 0;
+  std::vector<int32_t> component_first;  // step slot where each component starts (its cull step included), + end
 };
 
 struct DeviceCopy {
   DevPrim* prims = nullptr;
   DevInstr* trace_code = nullptr;               // all components, each reduced to its candidate hit
+  int32_t* trace_component_first = nullptr;     // [components + 1] step ranges of trace_code (k-lanes kernels)
   DevInstr* render_code = nullptr;              // same with the renderers' selection rule
   std::vector<DevInstr*> component_code;        // one program per component, no I_ROOT
   int64_t* host_pinned = nullptr;               // 8 x int64 pinned staging
@@ -450,6 +452,7 @@ extern "C" int prt_scene_create(const prt_prim* prims, int n_prims, const prt_no
     s->dev_prims.push_back(d);
   }
   for (int r : s->roots) {
+    s->trace_program.component_first.push_back((int32_t)s->trace_program.code.size());
     compile_component(s, r, s->trace_program.code, ROOT_TRACE, &s->trace_program.lds_slots);
     compile_component(s, r, s->render_program.code, ROOT_RENDER, &s->render_program.lds_slots);
     Program p;
@@ -457,6 +460,7 @@ extern "C" int prt_scene_create(const prt_prim* prims, int n_prims, const prt_no
     s->component_programs.push_back(p);
     s->component_result.push_back(res);
   }
+  s->trace_program.component_first.push_back((int32_t)s->trace_program.code.size());
   const size_t lds = (size_t)std::max(s->trace_program.lds_slots, s->render_program.lds_slots) * PRT_BLOCK * 12;
   if (lds > kMaxLdsBytes) {
     delete s;
@@ -474,6 +478,7 @@ extern "C" void prt_scene_destroy(prt_scene* s) {
     (void)hipSetDevice((int)d);
     (void)hipFree(c.prims);
     (void)hipFree(c.trace_code);
+    (void)hipFree(c.trace_component_first);
     (void)hipFree(c.render_code);
     for (DevInstr* p : c.component_code) (void)hipFree(p);
     if (c.host_pinned) (void)hipHostFree(c.host_pinned);
@@ -527,6 +532,8 @@ static int on_device(prt_scene* s, int device, DeviceCopy** out) {
     int rc = upload(&c.prims, s->dev_prims);
     if (rc) return rc;
     rc = upload(&c.trace_code, s->trace_program.code);
+    if (rc) return rc;
+    rc = upload(&c.trace_component_first, s->trace_program.component_first);
     if (rc) return rc;
     rc = upload(&c.render_code, s->render_program.code);
     if (rc) return rc;

@@ -98,6 +98,24 @@ def test_trace_matches_reference_on_every_program_form(name, knob, monkeypatch):
 
 
 @pytest.mark.parametrize("name", SCENE_FIXTURES)
+@pytest.mark.parametrize("variant", ["lanes4", "lanes8,lds", "lanes16", "lds"])
+def test_surface_parallel_variants_match_reference(name, variant, monkeypatch):
+    """The k-lanes-per-ray nearest-hit kernels (K lanes of a wave share a ray, each takes components
+    j, j+K, ..., shuffle min-reduce over (t, component order)) and the LDS-staged program fetch give
+    the reference's surfaces and frames exactly like the lane-per-ray kernel."""
+    monkeypatch.setenv("PRT_HIT_VARIANT", variant)
+    fx = helpers.load(f"scene_{name}.npz")
+    ds = device_scene(helpers.scene_of(fx))
+    t, surf = ds.propagate(dev(fx["rays0"]))
+    assert np.array_equal(surf.cpu().numpy(), fx["surf_0"]), f"{name} {variant}: surfaces"
+    assert np.allclose(t.cpu().numpy(), fx["t_0"], rtol=0, atol=helpers.ATOL), f"{name} {variant}: t"
+    rows, counts = ds.trace(dev(fx["rays0"]), int(fx["generation_limit"]), flags=2)
+    helpers.assert_frames_match(rows.cpu().numpy().T, fx["frame"], what=f"{name} {variant}")
+    assert ds.trace_stats()["variant"] == (3 if "lanes" in variant else 2)
+    ds.close()
+
+
+@pytest.mark.parametrize("name", SCENE_FIXTURES)
 def test_stepwise_matches_reference(name):
     """prt_propagate + prt_interact generation by generation against the reference's
     intermediates: t, surface ids (exact) and the ray set after each interaction."""
