@@ -246,6 +246,19 @@ int prt_place_rows(int device, const double* staging, int64_t stride_rank, int64
                    const int64_t* counts_all, int limit, double* out, int64_t ld_out, void* workspace,
                    void* stream);
 
+/* ---- result sink: reductions over the record block on the device ---------------------------------
+ * The (15, R) record block is the frame of pyrayt/_pyrayt.py:147-186 in columns.  What upstream's
+ * examples compute from that frame (examples/lens_design.ipynb cells 11-16, 19-20, 38) is: keep
+ * the rows of one surface and / or generation, group them by source (id // rays_per_source,
+ * _pyrayt.py:349-354), and reduce spot positions (y1, z1) and axis intercepts
+ * x0 - x_tilt * y0 / y_tilt per group.  One pass over the block; out is (n_groups, 8) float64 on
+ * the device: count, sum(y1 - py), sum(z1 - pz), sum((y1 - py)^2 + (z1 - pz)^2), sum(focus - pf),
+ * sum((focus - pf)^2), sum(wavelength), sum(intensity), with pivots = (py, pz, pf) or NULL for 0.
+ * surface / generation: NaN selects every row; rays_per_source <= 0: a single group. */
+int prt_frame_reduce(int device, const double* rows, int64_t ld, int64_t n_rows, double surface,
+                     double generation, double rays_per_source, int n_groups, const double* pivots,
+                     double* out, void* stream);
+
 /* statistics of the last prt_trace on this scene (for bench.py's roofline):
  * out[0] = generations that found rays, out[1] = sum over generations of rays alive at entry,
  * out[2] = GPU milliseconds spent in generation kernels (hipEvent, on the trace stream),

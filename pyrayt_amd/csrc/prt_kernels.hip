@@ -1882,3 +1882,8 @@ extern "C" int prt_primitive_normal(int device, int type, const double* params, 
 // frame re-assembly across ranks (RCCL all-gather + placement kernel)
 // ------------------------------------------------------------------------------------------------
 #include "prt_gather.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// reductions over the result frame
+// ------------------------------------------------------------------------------------------------
+#include "prt_frame.hpp"

@@ -6,9 +6,13 @@ costs two orders of magnitude more than the trace itself.  ``RayTracer.trace_dev
 this view instead: the engine's (15, R) record block, one contiguous row per column, with the
 handful of selections the reference's examples make on the frame (``results.loc[results[
 "surface"] == id]``, per-generation slices, spot statistics: ``examples/lens_design.ipynb``)
-done on the device, so that only what is looked at crosses PCIe.  Selection / reduction use
-torch tensor ops: they are conveniences around the result, not part of the traced path.
+done on the device, so that only what is looked at crosses PCIe.  The grouped reductions
+(``group_stats``: per-source / per-wavelength spot and focus statistics, the notebook's cells
+11-16) are one HIP kernel over the column block (``prt_frame_reduce``, ``csrc/prt_frame.hpp``);
+row selections that return a new frame are torch indexing -- plumbing around the result.
 """
+import ctypes
+
 import numpy as np
 import pandas as pd
 
@@ -61,8 +65,65 @@ class DeviceFrame:
         return DeviceFrame(self.rows[:, mask])
 
     # --- reductions the notebook does on the frame -------------------------------------------------
+    def _reduce(self, surface, generation, rays_per_source, n_groups, pivots):
+        """One pass of ``prt_frame_reduce``: (n_groups, 8) float64 on the host."""
+        import torch
+
+        from . import engine
+
+        rows = self.rows
+        if rows.stride(1) != 1:
+            rows = rows.contiguous()
+        dev = rows.device
+        out = torch.empty((n_groups, 8), dtype=torch.float64, device=dev)
+        nan = float("nan")
+        piv = (ctypes.c_double * 3)(*pivots) if pivots is not None else None
+        engine._check(engine.library().prt_frame_reduce(
+            dev.index or 0, rows.data_ptr(), rows.stride(0), rows.shape[1],
+            nan if surface is None else float(surface), nan if generation is None else float(generation),
+            float(rays_per_source or 0), n_groups, piv, out.data_ptr(), engine._stream_ptr(torch, dev)))
+        return out.cpu().numpy()
+
+    def group_stats(self, surface=None, generation=None, rays_per_source=None, n_groups=None):
+        """Per-source statistics of the rows that hit ``surface`` and / or belong to ``generation``
+        (``examples/lens_design.ipynb`` cells 11-16: ``results.loc[results['surface'] == id]``
+        grouped by ``source_id = id // rays_per_source``, ``_pyrayt.py:349-354``).
+
+        Returns a DataFrame indexed by source id with columns ``count``, ``y`` / ``z`` (spot centroid
+        of the end points), ``rms_radius`` (about that centroid), ``focus`` / ``focus_std`` (mean and
+        spread of the x-axis intercepts ``x0 - x_tilt * y0 / y_tilt``, the notebook's paraxial-focus
+        estimate), ``wavelength`` and ``intensity`` (means).  One HIP reduction kernel, run twice: the
+        second pass accumulates about the first pass's means so the second moments are well
+        conditioned.  Without ``rays_per_source`` everything is one group."""
+        if rays_per_source:
+            if n_groups is None:
+                n_groups = int(float(self["id"].max()) // rays_per_source) + 1 if len(self) else 1
+        else:
+            n_groups = 1
+        first = self._reduce(surface, generation, rays_per_source, n_groups, None)
+        count = first[:, 0]
+        safe = np.where(count > 0, count, 1.0)
+        # one pivot for the whole pass (the kernel takes three scalars): the overall means
+        total = max(count.sum(), 1.0)
+        pivots = (first[:, 1].sum() / total, first[:, 2].sum() / total, first[:, 4].sum() / total)
+        second = self._reduce(surface, generation, rays_per_source, n_groups, pivots)
+        dy, dz, df = second[:, 1] / safe, second[:, 2] / safe, second[:, 4] / safe
+        var_r = np.maximum(second[:, 3] / safe - dy ** 2 - dz ** 2, 0.0)
+        var_f = np.maximum(second[:, 5] / safe - df ** 2, 0.0)
+        frame = pd.DataFrame({
+            "count": count.astype(np.int64), "y": pivots[0] + dy, "z": pivots[1] + dz,
+            "rms_radius": np.sqrt(var_r), "focus": pivots[2] + df, "focus_std": np.sqrt(var_f),
+            "wavelength": second[:, 6] / safe, "intensity": second[:, 7] / safe,
+        })
+        frame.index.name = "source_id"
+        frame.loc[count == 0, ["y", "z", "rms_radius", "focus", "focus_std", "wavelength", "intensity"]] = np.nan
+        return frame
+
     def spot(self, plane=("y1", "z1")):
         """(centroid, rms radius) of the end points in a transverse plane."""
+        if tuple(plane) == ("y1", "z1") and getattr(self.rows, "is_cuda", False) and len(self):
+            stats = self.group_stats().iloc[0]
+            return (float(stats["y"]), float(stats["z"])), float(stats["rms_radius"])
         a, b = self[plane[0]], self[plane[1]]
         ca, cb = a.mean(), b.mean()
         rms = (((a - ca) ** 2 + (b - cb) ** 2).mean()) ** 0.5
@@ -78,8 +139,7 @@ class DeviceFrame:
         """(R, 15) float64 view of a host copy (one D2H transfer)."""
         from . import engine
 
-        rows = self.rows.contiguous() if hasattr(self.rows, "contiguous") else self.rows
-        return engine.to_host(rows).T
+        return engine.to_host(self.rows).T  # a strided view crosses PCIe as it is: no device-side repack
 
     def to_pandas(self):
         values = self.to_numpy()

@@ -1,0 +1,101 @@
+"""Result sink on the device: the grouped reductions of
+``prt_frame_reduce`` against pandas on the *reference's own* frames (the golden fixtures), i.e.
+what examples/lens_design.ipynb computes from ``tracer.trace()``'s DataFrame (cells 11-16):
+rows of one surface / generation, grouped by source id, spot centroid / rms radius and the
+x-axis intercept ``x0 - x_tilt * y0 / y_tilt``."""
+import numpy as np
+import pandas as pd
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+COLUMNS = ("generation", "intensity", "wavelength", "index", "id", "surface",
+           "x0", "y0", "z0", "x1", "y1", "z1", "x_tilt", "y_tilt", "z_tilt")
+
+
+def _frames(name):
+    from pyrayt_amd.frame import DeviceFrame
+
+    fx = helpers.load(f"scene_{name}.npz")
+    golden = fx["frame"]                                    # (R, 15) float64, the reference's rows
+    device = DeviceFrame(torch.from_numpy(np.ascontiguousarray(golden.T)).to("cuda:0"))
+    return pd.DataFrame(golden, columns=COLUMNS), device, fx
+
+
+def _pandas_stats(frame, rays_per_source):
+    with np.errstate(all="ignore"):
+        focus = frame["x0"] - frame["x_tilt"] * frame["y0"] / frame["y_tilt"]
+    work = frame.assign(focus=focus.where(np.isfinite(focus)),
+                        source_id=(frame["id"] // rays_per_source).astype(int) if rays_per_source else 0)
+    out = {}
+    for sid, rows in work.groupby("source_id"):
+        cy, cz = rows["y1"].mean(), rows["z1"].mean()
+        f = rows["focus"].fillna(0.0)  # the kernel counts a ray without an intercept as focus 0 about the pivot
+        out[sid] = dict(count=len(rows), y=cy, z=cz,
+                        rms_radius=np.sqrt(((rows["y1"] - cy) ** 2 + (rows["z1"] - cz) ** 2).mean()),
+                        wavelength=rows["wavelength"].mean(), intensity=rows["intensity"].mean(),
+                        focus=rows["focus"].mean(), n_focus=int(rows["focus"].notna().sum()))
+    return out
+
+
+@pytest.mark.parametrize("name,rays_per_source", [("config4", 256), ("config3", None), ("mirrors_and_stops", 512),
+                                                  ("config2", 100)])
+def test_group_stats_match_pandas_on_the_reference_frame(name, rays_per_source):
+    frame, device, fx = _frames(name)
+    detector = float(frame["surface"].iloc[-1])             # the surface the last recorded row ended on
+    for surface, generation in ((detector, None), (None, float(frame["generation"].max())), (None, None),
+                                (detector, float(frame["generation"].max()))):
+        sel = frame
+        if surface is not None:
+            sel = sel.loc[sel["surface"] == surface]
+        if generation is not None:
+            sel = sel.loc[sel["generation"] == generation]
+        want = _pandas_stats(sel, rays_per_source)
+        n_groups = int(frame["id"].max() // rays_per_source) + 1 if rays_per_source else None
+        got = device.group_stats(surface=surface, generation=generation, rays_per_source=rays_per_source,
+                                 n_groups=n_groups)
+        assert int(got["count"].sum()) == len(sel)
+        for sid, w in want.items():
+            g = got.loc[sid]
+            assert int(g["count"]) == w["count"]
+            for key in ("y", "z", "wavelength", "intensity"):
+                assert np.isclose(g[key], w[key], rtol=1e-12, atol=1e-12), (name, sid, key)
+            assert np.isclose(g["rms_radius"], w["rms_radius"], rtol=1e-9, atol=1e-12), (name, sid)
+            if w["n_focus"] == w["count"] and np.isfinite(w["focus"]) and abs(w["focus"]) < 1e6:
+                assert np.isclose(g["focus"], w["focus"], rtol=1e-9, atol=1e-9), (name, sid, "focus")
+        empty = got.loc[got["count"] == 0]
+        assert empty[["y", "z", "rms_radius"]].isna().all().all()
+
+
+def test_trace_keeps_the_device_frame_and_converts_lazily():
+    """RayTracer.trace() is trace_device() + to_pandas(): the block stays in HBM for the reductions."""
+    import pyrayt_amd as pyrayt
+    import scenes
+
+    lens = pyrayt.components.biconvex_lens(2, 2, 0.25, aperture=1)
+    focus = scenes.lensmakers_equation(2, -2, 1.5, 0.25)
+    sources = [pyrayt.components.ConeOfRays(cone_angle=a).move_x(-focus) for a in (2, 4, 6)]
+    baffle = pyrayt.components.baffle((1, 1)).move_x(1)
+    tracer = pyrayt.RayTracer(sources, [lens, baffle], rays_per_source=400, generation_limit=10)
+    frame = tracer.trace()
+    assert tracer.device_frame is not None and tracer.device_frame.rows.is_cuda
+    assert np.array_equal(tracer.device_frame.to_numpy(), frame.to_numpy())
+    stats = tracer.device_frame.group_stats(surface=baffle.get_id(), rays_per_source=400)
+    tracer.calculate_source_ids()
+    on_det = frame.loc[frame["surface"] == baffle.get_id()]
+    for sid, rows in on_det.groupby("source_id"):
+        assert int(stats.loc[sid, "count"]) == len(rows)
+        assert np.isclose(stats.loc[sid, "y"], rows["y1"].mean(), atol=1e-12)
+        rms = np.sqrt(((rows["y1"] - rows["y1"].mean()) ** 2 + (rows["z1"] - rows["z1"].mean()) ** 2).mean())
+        assert np.isclose(stats.loc[sid, "rms_radius"], rms, rtol=1e-9)
+    # a second trace of the unchanged system re-uses the compiled scene
+    first_scene = tracer._scene_cache[1]
+    tracer.trace()
+    assert tracer._scene_cache[1] is first_scene
+    lens.move_x(0.01)
+    tracer.trace()
+    assert tracer._scene_cache[1] is not first_scene
