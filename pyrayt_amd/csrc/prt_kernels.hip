@@ -161,7 +161,7 @@ k_hit_lanes(SceneDev scene, const int32_t* __restrict__ comp_first, int n_comp,
     for (int c = sub; c < n_comp; c += K) {
       double t;
       int prim;
-      component_candidate(code, comp_first[c], comp_first[c + 1], r, lists, t, prim);
+      component_candidate(code, comp_first[2 * c], comp_first[2 * c + 1], r, lists, t, prim);
       if (t < best_t) { best_t = t; best_prim = prim; best_comp = c; }
     }
 #pragma unroll

@@ -35,13 +35,13 @@ struct SceneDev {
 struct Program {
   std::vector<DevInstr> code;
   int lds_slots = 0;
-  std::vector<int32_t> component_first;  // step slot where each component starts (its cull step included), + end
+  std::vector<int32_t> component_first;  // per component: first and one-past-last step slot (its own cull step included)
 };
 
 struct DeviceCopy {
   DevPrim* prims = nullptr;
   DevInstr* trace_code = nullptr;               // all components, each reduced to its candidate hit
-  int32_t* trace_component_first = nullptr;     // [components + 1] step ranges of trace_code (k-lanes kernels)
+  int32_t* trace_component_first = nullptr;     // [2 * components] step ranges of trace_code (k-lanes kernels)
   DevInstr* render_code = nullptr;              // same with the renderers' selection rule
   std::vector<DevInstr*> component_code;        // one program per component, no I_ROOT
   int64_t* host_pinned = nullptr;               // 8 x int64 pinned staging
@@ -269,6 +269,18 @@ static bool solid_bounds(const prt_scene* s, int node, double* box) {
 
 enum { ROOT_NONE = 0, ROOT_TRACE = 1, ROOT_RENDER = 2 };
 
+// widen a cull box by 1e-3 of its diagonal (plus a floor relative to its distance from the origin)
+static void pad_box(double* box) {
+  double diag = 0, reach = 0;
+  for (int k = 0; k < 3; ++k) {
+    const double side = std::max(0.0, box[2 * k + 1] - box[2 * k]);  // an empty overlap has no extent
+    diag += side * side;
+    reach = std::max(reach, std::max(std::fabs(box[2 * k]), std::fabs(box[2 * k + 1])));
+  }
+  const double pad = 1e-3 * std::sqrt(diag) + 1e-9 * reach + 1e-12;
+  for (int k = 0; k < 3; ++k) { box[2 * k] -= pad; box[2 * k + 1] += pad; }
+}
+
 // count the steps of one kind in a program (a chain record spans CHAIN_SLOTS raw slots)
 static int count_steps(const std::vector<DevInstr>& code, int kind) {
   int n = 0;
@@ -344,14 +356,7 @@ static Operand compile_component(const prt_scene* s, int root_node, std::vector<
     DevInstr in = Compiler::blank(I_BOX);
     double* box = in.data;
     if (solid_bounds(s, root_node, box)) {
-      double diag = 0, reach = 0;
-      for (int k = 0; k < 3; ++k) {
-        const double side = std::max(0.0, box[2 * k + 1] - box[2 * k]);  // an empty overlap has no extent
-        diag += side * side;
-        reach = std::max(reach, std::max(std::fabs(box[2 * k]), std::fabs(box[2 * k + 1])));
-      }
-      const double pad = 1e-3 * std::sqrt(diag) + 1e-9 * reach + 1e-12;
-      for (int k = 0; k < 3; ++k) { box[2 * k] -= pad; box[2 * k + 1] += pad; }
+      pad_box(box);
       box_at = code.size();
       code.push_back(in);
     }
@@ -390,6 +395,53 @@ static Operand compile_component(const prt_scene* s, int root_node, std::vector<
   if (res.mode == OPER_LDS) res.base += shift;
   *slots = std::max(*slots, shift);
   return res;
+}
+
+// The trace program of components [lo, hi) of the scene, in list order.  Scenes of many components
+// get a hierarchy of cull steps over *runs of consecutive components*: a run of more than
+// kGroupFanout components is split into kGroupFanout sub-runs, each led by an I_BOX step holding
+// the union of its members' solid boxes whose jump spans the whole sub-run (the interpreter's I_BOX
+// semantic nests as it is).  A coherent wave then tests O(fanout * log n) boxes instead of n: the
+// runs behind it, or beyond its nearest hit so far, go with one test each.  Order of evaluation
+// -- and with it the strict '<' tie rule of _pyrayt.py:384 -- stays the component list's.
+static const int kGroupFanout = 4;
+static const int kGroupMinComponents = 8;
+static void compile_trace_run(prt_scene* s, int lo, int hi, bool grouped) {
+  Program& prog = s->trace_program;
+  const int n = hi - lo;
+  if (n == 1) {
+    prog.component_first.push_back((int32_t)prog.code.size());
+    compile_component(s, s->roots[lo], prog.code, ROOT_TRACE, &prog.lds_slots);
+    prog.component_first.push_back((int32_t)prog.code.size());
+    return;
+  }
+  const int step = grouped && n > kGroupFanout ? (n + kGroupFanout - 1) / kGroupFanout : 1;
+  for (int at = lo; at < hi; at += step) {
+    const int end = std::min(hi, at + step);
+    size_t box_at = (size_t)-1;
+    if (end - at > 1) {  // a sub-run of several components: its own cull step in front
+      DevInstr in = Compiler::blank(I_BOX);
+      double* box = in.data;
+      bool ok = true;
+      for (int k = 0; k < 3; ++k) { box[2 * k] = HUGE_VAL; box[2 * k + 1] = -HUGE_VAL; }
+      for (int c = at; c < end && ok; ++c) {
+        double member[6];
+        ok = solid_bounds(s, s->roots[c], member);
+        for (int k = 0; k < 3 && ok; ++k) {
+          box[2 * k] = std::min(box[2 * k], member[2 * k]);
+          box[2 * k + 1] = std::max(box[2 * k + 1], member[2 * k + 1]);
+        }
+      }
+      if (ok) {
+        pad_box(box);
+        box_at = prog.code.size();
+        prog.code.push_back(in);
+      }
+    }
+    const size_t from = prog.code.size();
+    compile_trace_run(s, at, end, grouped);
+    if (box_at != (size_t)-1) prog.code[box_at].a0 = (int)(prog.code.size() - from);
+  }
 }
 
 static int validate_tree(const prt_scene* s, int node, int depth, std::vector<char>& seen) {
@@ -451,16 +503,18 @@ extern "C" int prt_scene_create(const prt_prim* prims, int n_prims, const prt_no
     if (m.kind == PRT_MAT_NONE) s->has_untracable = true;
     s->dev_prims.push_back(d);
   }
+  {
+    const bool cull_off = std::getenv("PRT_NO_CULL") != nullptr || std::getenv("PRT_NO_GROUPS") != nullptr;
+    const bool grouped = (int)s->roots.size() >= kGroupMinComponents && !cull_off;
+    if (!s->roots.empty()) compile_trace_run(s, 0, (int)s->roots.size(), grouped);
+  }
   for (int r : s->roots) {
-    s->trace_program.component_first.push_back((int32_t)s->trace_program.code.size());
-    compile_component(s, r, s->trace_program.code, ROOT_TRACE, &s->trace_program.lds_slots);
     compile_component(s, r, s->render_program.code, ROOT_RENDER, &s->render_program.lds_slots);
     Program p;
     Operand res = compile_component(s, r, p.code, ROOT_NONE, &p.lds_slots);
     s->component_programs.push_back(p);
     s->component_result.push_back(res);
   }
-  s->trace_program.component_first.push_back((int32_t)s->trace_program.code.size());
   const size_t lds = (size_t)std::max(s->trace_program.lds_slots, s->render_program.lds_slots) * PRT_BLOCK * 12;
   if (lds > kMaxLdsBytes) {
     delete s;

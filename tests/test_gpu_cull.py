@@ -3,6 +3,8 @@ cannot reach a component's box before its current nearest hit skips the componen
 The step must never change a result: HIP engine vs the C oracle (which has no such step), surface
 ids exact, on scenes built to stress it -- a lens train traversed in both directions, rays born
 inside boxes, incoherent rays over a grid of parts, empty and unioned solids, touching parts."""
+import os
+
 import numpy as np
 import pytest
 
@@ -23,7 +25,12 @@ def check(parts, rays, limit, expect_culls=True):
     flat = helpers.flat_scene(snap)
     ds = DeviceScene(snap)
     info = ds.info()
-    assert info["cull_steps"] == (len(parts) if expect_culls else 0), info
+    if expect_culls:
+        # one cull step per component, plus the steps over runs of components from eight components on
+        grouped = len(parts) >= 8 and "PRT_NO_GROUPS" not in os.environ
+        assert info["cull_steps"] >= len(parts) and (info["cull_steps"] > len(parts)) == grouped, info
+    else:
+        assert info["cull_steps"] == 0, info
     device_rays = torch.from_numpy(np.ascontiguousarray(rays)).to("cuda:0")
     t, surf = ds.propagate(device_rays)
     want_t, want_surf = c_oracle.propagate(flat, rays)
@@ -56,6 +63,24 @@ def test_lens_train_both_directions(api):
     rays[12] = np.arange(rays.shape[1])
     counts = check(parts, rays, 40)
     assert len(counts) > 20  # forward through six lenses, off the mirror, and back again
+
+
+@pytest.mark.parametrize("groups", [True, False])
+def test_long_lens_train_with_run_cull_steps(api, groups, monkeypatch):
+    """33 components: the hierarchy of cull steps over runs of consecutive components (and the flat
+    form, PRT_NO_GROUPS) against the C oracle, rays entering from both ends and from the side."""
+    if not groups:
+        monkeypatch.setenv("PRT_NO_GROUPS", "1")
+    c = api.components
+    parts = [c.biconvex_lens(4, 4, 0.25, aperture=1).move_x(1.0 * k) for k in range(32)]
+    parts.append(c.baffle((2, 2)).move_x(33.0))
+    rays = np.hstack((scenes.cone_rays(5000, (-3.0, 0.0, 0.0), 3.0, 41),
+                      scenes.cone_rays(3000, (12.5, 0.0, 0.0), 30.0, 42),
+                      scenes.random_rays(4288, 43, box=20.0, degenerate=True)))
+    rays[4, 5000:6500] *= -1.0  # part of the mid-train cone runs backwards
+    rays[12] = np.arange(rays.shape[1])
+    counts = check(parts, rays, 70)
+    assert len(counts) > 60
 
 
 def test_rays_born_inside_boxes_and_nested_parts(api):
