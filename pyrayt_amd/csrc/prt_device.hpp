@@ -705,17 +705,24 @@ __device__ __forceinline__ void csg_keep(int op, const double (&lv)[ML], const d
     PRT_COUNT(0, any);
     PRT_COUNT(1, any && !robust);
     if (any && !robust) touched = box_touched(aabb, ray);
-    // The chord argument covers the axes the ray actually moves along (a slab crossing is off by
-    // ~1e-16 |b| / |d| <= 1e-8, far below the robust margin).  An axis with |d| <= 1e-8 has no
-    // crossing: there upstream's test is the bare comparison lo <= o <= hi (primitives.py:531-565),
-    // which a ray running along a face one ulp outside the box fails however long its chord through
-    // the (object-space) solid is -- found by the adversarial fixtures (tests/scenes.py adv_lens).
-    const bool px = near0(ray.dx), py = near0(ray.dy), pz = near0(ray.dz);
-    if (__ballot(px || py || pz) != 0ull) {
+    // The chord argument covers the axes the ray really moves along: with |d| >= 1e-4 a slab crossing
+    // is off by at most ~1e-12 / |d| <= 1e-8 (rounding, and the 1e-12 by which the compiler lets the
+    // upstream box fall short of the solid's bounds), far below the robust margin.  An axis with
+    // |d| <= 1e-8 has no crossing at all: there upstream's test is the bare comparison lo <= o <= hi
+    // (primitives.py:531-565), which a ray running along a face one ulp outside the box fails however
+    // long its chord through the (object-space) solid is -- found by the adversarial fixtures
+    // (tests/scenes.py adv_lens).  In between (1e-8 < |d| < 1e-4) the exact test decides.
+    const double ax = fabs(ray.dx), ay = fabs(ray.dy), az = fabs(ray.dz);
+    if (__ballot(ax < 1e-4 || ay < 1e-4 || az < 1e-4) != 0ull) {
+      const bool px = ax <= 1e-8, py = ay <= 1e-8, pz = az <= 1e-8;
       const bool outside = (px && !(ray.ox >= aabb[0] && ray.ox <= aabb[1])) ||
                            (py && !(ray.oy >= aabb[2] && ray.oy <= aabb[3])) ||
                            (pz && !(ray.oz >= aabb[4] && ray.oz <= aabb[5]));
       touched = touched && !outside;
+      const bool grazing = (!px && ax < 1e-4) || (!py && ay < 1e-4) || (!pz && az < 1e-4);
+      if (__ballot(grazing && any && robust) != 0ull) {
+        if (grazing && any && robust) touched = touched && box_touched(aabb, ray);
+      }
     }
   }
 #pragma unroll

@@ -88,6 +88,8 @@ static int leaves_under(const prt_scene* s, int node) {
 // b-2+k only after it has consumed k-2 entries of that operand, so it never overwrites an
 // unread entry, and a chain of k leaves needs just 2k slots.  Two LDS operands keep the right
 // one a further len(right) slots down so the same argument holds for the left one.
+static bool solid_bounds(const prt_scene* s, int node, double* box);
+
 struct Compiler {
   const prt_scene* s;
   std::vector<DevInstr>& out;
@@ -119,13 +121,27 @@ struct Compiler {
     return o;
   }
 
-  // does the upstream cull box of `node` provably contain the node's solid?  (see csg_node)
+  // does the upstream cull box of `node` provably contain the node's solid?  (see csg_keep)
+  // Structurally it does for INTERSECT / DIFFERENCE over UNION-free subtrees -- *if* the box is the one
+  // csg.py:93-116 would compute now.  Upstream caches it, and the cache of the outer node of a
+  // right-nested tree moved after construction is stale (world_objects.py:315-317): the snapshot
+  // carries that stale box, so the box is also checked against the solid's real bounds (found by the
+  // 500-seed fuzz tier: a stale, empty box culls every ray upstream).
   bool box_contains_solid(int node) const {
     const prt_node& n = s->nodes[node];
     if (n.op == PRT_NODE_LEAF) return true;
-    if (n.op == PRT_NODE_INTERSECT) return box_contains_solid(n.left) && box_contains_solid(n.right);
-    if (n.op == PRT_NODE_DIFFERENCE) return box_contains_solid(n.left);
-    return false;  // UNION of disjoint operands keeps only the first operand's span (csg.py:98-109)
+    bool structural = false;
+    if (n.op == PRT_NODE_INTERSECT) structural = box_contains_solid(n.left) && box_contains_solid(n.right);
+    if (n.op == PRT_NODE_DIFFERENCE) structural = box_contains_solid(n.left);
+    if (!structural) return false;  // UNION of disjoint operands keeps only the first operand's span (csg.py:98-109)
+    double real[6];
+    if (!solid_bounds(s, node, real)) return false;
+    for (int k = 0; k < 3; ++k) {
+      if (!(real[2 * k] <= real[2 * k + 1])) continue;  // the solid has no extent on this axis: nothing to contain
+      const double tol = 1e-12 * (1.0 + std::fabs(real[2 * k]) + std::fabs(real[2 * k + 1]));
+      if (!(n.aabb[2 * k] <= real[2 * k] + tol && n.aabb[2 * k + 1] >= real[2 * k + 1] - tol)) return false;
+    }
+    return true;
   }
 
   Operand emit(int node, int ceiling) {

@@ -46,7 +46,14 @@ def random_component(rng, cg, matl, depth):
     return node
 
 
-@pytest.mark.parametrize("seed", range(24))
+def _seeds():
+    # the everyday tier, and the 500-seed tier for gpurun sessions: PRT_FUZZ_SEEDS=500 pytest -m gpu ...
+    import os
+
+    return range(int(os.environ.get("PRT_FUZZ_SEEDS", "24")))
+
+
+@pytest.mark.parametrize("seed", _seeds())
 def test_random_scene(seed):
     from pyrayt_amd.engine import DeviceScene
     from pyrayt_amd.g3d.objects import CountedObject
