@@ -276,8 +276,11 @@ __device__ __forceinline__ Meta5 load_meta(const double* __restrict__ rays, int6
   return m;
 }
 
+// the primitive table staged in LDS by the generation kernel (null: read it from HBM)
+typedef const __attribute__((address_space(3))) DevPrim* LdsPrimPtr;
+
 __device__ __forceinline__ Shaded interact_compute(const SceneDev& scene, const Meta5& m, const Ray8& r,
-                                                   double t, int prim) {
+                                                   double t, int prim, LdsPrimPtr lds_prims = nullptr) {
   Shaded s;
   s.generation = m.generation;
   s.intensity = m.intensity;
@@ -298,6 +301,17 @@ __device__ __forceinline__ Shaded interact_compute(const SceneDev& scene, const 
   // (v_readfirstlane of the lanes still pending: the index is in an SGPR, so the compiler knows the
   // table entry is uniform and fetches it with scalar loads -- one batch for the whole record --
   // instead of per-lane vector loads that all hit the same address)
+  if (lds_prims) {
+    // The workgroup holds the table in LDS: every lane reads its own primitive's record with ds_reads
+    // (lanes on the same primitive read the same words: a broadcast) -- per-lane, dynamically indexed
+    // data is what LDS is for, and a read returns in ~100 cycles where the dependent table loads from
+    // HBM / L1 below cost several hundred each.  No waterfall: the branches on type and material are
+    // per lane.
+    const LdsPrimPtr p = lds_prims + prim;
+    s.ok = shade(p, s.px, s.py, s.pz, s.pw, s.dx, s.dy, s.dz, s.dw, s.wavelength, s.index, s.tx, s.ty, s.tz);
+    s.surface_id = p->surface_id;
+    return s;
+  }
 #ifndef PRT_SCALAR_WATERFALL
   // (the table reads below are per-lane vector loads of one address -- a single L1 line per field
   // group, fetched in one batch.  The scalar-load form of this loop, kept under PRT_SCALAR_WATERFALL,
@@ -694,6 +708,19 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   const int64_t i = (int64_t)tile * PRT_BLOCK + threadIdx.x;
   const LaneLists lists = lane_lists(scene.lds_slots);
   const int park_base = (3 * scene.lds_slots + 1) / 2;
+  // the primitive table goes to LDS behind the parking rows (small scenes; see lds_bytes_fused): the
+  // copy is issued here, ahead of the ray loads, and is complete for everybody at the barrier that
+  // follows the hit phase
+  LdsPrimPtr lds_prims = nullptr;
+#ifndef PRT_NO_LDS_PRIMS
+  if (scene.n_prims_staged > 0) {
+    double* table = lds_dyn + (park_base + PRT_PARK_ROWS) * PRT_BLOCK;
+    const double* src = reinterpret_cast<const double*>(scene.prims);
+    const int words = scene.n_prims_staged * (int)(sizeof(DevPrim) / sizeof(double));
+    for (int k = threadIdx.x; k < words; k += PRT_BLOCK) table[k] = src[k];
+    lds_prims = (LdsPrimPtr)table;
+  }
+#endif
   Ray8 r = {0, 0, 0, 1, 0, 0, 0, 0};
   double t = PRT_INF;
   int prim = -1;
@@ -756,7 +783,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     meta.wavelength = PARK(2);
     meta.index = PARK(3);
     PARK(5) = r.ox; PARK(6) = r.oy; PARK(7) = r.oz;
-    sh = interact_compute(scene, meta, r, t, prim);
+    sh = interact_compute(scene, meta, r, t, prim, lds_prims);
   }
   STAMP(5);
   if (wave == 0) {
@@ -1080,8 +1107,9 @@ static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + PRT_BLOCK 
 static inline size_t lds_bytes(int slots) { return (size_t)slots * PRT_BLOCK * 12; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // the fused kernel parks 8 float64 per lane behind the hit lists
-static inline size_t lds_bytes_fused(int slots) {
-  return (size_t)((3 * slots + 1) / 2 + 8) * PRT_BLOCK * sizeof(double);
+static const int kMaxStagedPrims = 48;  // 48 x 264 B = 12.4 KiB next to the 16 KiB of parking rows
+static inline size_t lds_bytes_fused(int slots, int prims_staged) {
+  return (size_t)((3 * slots + 1) / 2 + 8) * PRT_BLOCK * sizeof(double) + (size_t)prims_staged * sizeof(DevPrim);
 }
 
 static SceneDev trace_scene_dev(const prt_scene* s, const DeviceCopy* c) {
@@ -1470,7 +1498,12 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
   double* buf[2] = {(double*)(w + l.rays_a), (double*)(w + l.rays_b)};
   const int keep_absorbed = (flags & PRT_TRACE_KEEP_ABSORBED) ? 1 : 0;
   SceneDev sd = trace_scene_dev(s, c);
-  const size_t lds = lds_bytes_fused(sd.lds_slots);
+  // experiment knob PRT_LDS_PRIMS=1: shade from an LDS copy of the primitive table, per lane, without the
+  // waterfall.  Measured slower on every BASELINE scene (+6 % config 2, +17 % config 3, +10 % config 4):
+  // the waterfall's wave-uniform branches and batched L1 reads beat per-lane ds_reads and divergent code.
+  sd.n_prims_staged = getenv("PRT_LDS_PRIMS") && (int)s->dev_prims.size() <= kMaxStagedPrims ? (int)s->dev_prims.size() : 0;
+  size_t lds = lds_bytes_fused(sd.lds_slots, sd.n_prims_staged);
+  if (lds > kMaxLdsBytes) { sd.n_prims_staged = 0; lds = lds_bytes_fused(sd.lds_slots, 0); }
   const int n_slots = generation_limit + 1;
   // PRT_TEST_STALL=1 makes one tile report an expired look-back so that the tests can exercise
   // the fallback to the three-kernel path.
