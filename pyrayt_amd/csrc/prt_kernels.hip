@@ -276,11 +276,8 @@ __device__ __forceinline__ Meta5 load_meta(const double* __restrict__ rays, int6
   return m;
 }
 
-// the primitive table staged in LDS by the generation kernel (null: read it from HBM)
-typedef const __attribute__((address_space(3))) DevPrim* LdsPrimPtr;
-
 __device__ __forceinline__ Shaded interact_compute(const SceneDev& scene, const Meta5& m, const Ray8& r,
-                                                   double t, int prim, LdsPrimPtr lds_prims = nullptr) {
+                                                   double t, int prim) {
   Shaded s;
   s.generation = m.generation;
   s.intensity = m.intensity;
@@ -301,17 +298,6 @@ __device__ __forceinline__ Shaded interact_compute(const SceneDev& scene, const 
   // (v_readfirstlane of the lanes still pending: the index is in an SGPR, so the compiler knows the
   // table entry is uniform and fetches it with scalar loads -- one batch for the whole record --
   // instead of per-lane vector loads that all hit the same address)
-  if (lds_prims) {
-    // The workgroup holds the table in LDS: every lane reads its own primitive's record with ds_reads
-    // (lanes on the same primitive read the same words: a broadcast) -- per-lane, dynamically indexed
-    // data is what LDS is for, and a read returns in ~100 cycles where the dependent table loads from
-    // HBM / L1 below cost several hundred each.  No waterfall: the branches on type and material are
-    // per lane.
-    const LdsPrimPtr p = lds_prims + prim;
-    s.ok = shade(p, s.px, s.py, s.pz, s.pw, s.dx, s.dy, s.dz, s.dw, s.wavelength, s.index, s.tx, s.ty, s.tz);
-    s.surface_id = p->surface_id;
-    return s;
-  }
 #ifndef PRT_SCALAR_WATERFALL
   // (the table reads below are per-lane vector loads of one address -- a single L1 line per field
   // group, fetched in one batch.  The scalar-load form of this loop, kept under PRT_SCALAR_WATERFALL,
@@ -526,43 +512,79 @@ __device__ __forceinline__ unsigned long long tile_load(unsigned long long* p) {
 // waiting on anything behind it.  That ordering is not an architectural guarantee, so the spin
 // is bounded: on expiry the wave reports failure and the host re-runs the generation loop on
 // the three-kernel path, which has no inter-workgroup dependency.
+#ifndef PRT_LOOKBACK_WINDOWS
+#define PRT_LOOKBACK_WINDOWS 1
+#endif
+#ifndef PRT_LOOKBACK_LANES
+#define PRT_LOOKBACK_LANES 32  // words inspected per poll: polls are fabric traffic; 16-32 measured best (64: +1-2 %, 8: +7 %)
+#endif
+// The first poll of a tile's look-back, issued right after its aggregate is published and consumed
+// only after the shading: a round trip to the fabric hidden behind useful work.  Status words only
+// move forward (invalid -> aggregate -> prefix), so an older snapshot is still a valid one.
+__device__ __forceinline__ unsigned long long lookback_early(unsigned long long* state, int tile) {
+  const int lane = threadIdx.x & 63;
+  const int idx = tile - 1 - lane;
+  unsigned long long w = tile_pack(TILE_PREFIX, 0, 0);
+  if (idx >= 0) w = lane < PRT_LOOKBACK_LANES ? tile_load(state + idx) : TILE_INVALID;
+  return w;
+}
+
 __device__ __forceinline__ bool lookback(unsigned long long* state, int tile, unsigned agg_live,
                                          unsigned agg_carry, unsigned& excl_live,
-                                         unsigned& excl_carry) {
+                                         unsigned& excl_carry, unsigned long long early = ~0ull) {
+  // One poll fetches PRT_LOOKBACK_WINDOWS x 64 predecessor words (lane l: tiles base - l, base - 64 - l,
+  // ...), all loads in flight together: a poll is a round trip to the fabric (~1 us under load, the
+  // words are device-scope), and the nearest inclusive prefix is typically 40-130 tiles back
+  // (tools/lookback_analysis.py), so one window per poll meant two or three dependent round trips.
   const int lane = threadIdx.x & 63;
   unsigned sum_live = 0, sum_carry = 0;
   int base = tile - 1;
   int idle = 0;
   bool ok = true;
   while (base >= 0) {
-    const int idx = base - lane;
-    unsigned long long w = tile_pack(TILE_PREFIX, 0, 0);  // before tile 0: empty prefix
-    if (idx >= 0) w = tile_load(state + idx);
-    const unsigned long long status = w >> 62;
-    const unsigned long long pending = __ballot(status == TILE_INVALID);
-    const unsigned long long prefix = __ballot(status == TILE_PREFIX);
-    // lanes [0, run) have published; stop after the first inclusive prefix among them
-    int run = pending ? (__ffsll((long long)pending) - 1) : 64;
-    bool closed = false;
-    if (prefix) {
-      const int first = __ffsll((long long)prefix) - 1;
-      if (first < run) { run = first + 1; closed = true; }
+    unsigned long long w[PRT_LOOKBACK_WINDOWS];
+#pragma unroll
+    for (int k = 0; k < PRT_LOOKBACK_WINDOWS; ++k) {
+      const int idx = base - 64 * k - lane;
+      w[k] = tile_pack(TILE_PREFIX, 0, 0);  // before tile 0: empty prefix
+      if (idx >= 0) w[k] = lane < PRT_LOOKBACK_LANES ? tile_load(state + idx) : TILE_INVALID;
     }
-    if (run == 0) {
+    if (early != ~0ull) {  // the first window was fetched before the shading (lookback_early)
+      w[0] = early;
+      early = ~0ull;
+    }
+    bool closed = false, stalled = false;
+    int consumed = 0;
+#pragma unroll
+    for (int k = 0; k < PRT_LOOKBACK_WINDOWS; ++k) {
+      if (closed || stalled) break;
+      const unsigned long long status = w[k] >> 62;
+      const unsigned long long pending = __ballot(status == TILE_INVALID);
+      const unsigned long long prefix = __ballot(status == TILE_PREFIX);
+      // lanes [0, run) have published; stop after the first inclusive prefix among them
+      int run = pending ? (__ffsll((long long)pending) - 1) : 64;
+      if (prefix) {
+        const int first = __ffsll((long long)prefix) - 1;
+        if (first < run) { run = first + 1; closed = true; }
+      }
+      unsigned l = (lane < run) ? (unsigned)((w[k] >> 31) & 0x7fffffffull) : 0u;
+      unsigned c = (lane < run) ? (unsigned)(w[k] & 0x7fffffffull) : 0u;
+      for (int off = 32; off > 0; off >>= 1) {
+        l += __shfl_xor(l, off);
+        c += __shfl_xor(c, off);
+      }
+      sum_live += l;
+      sum_carry += c;
+      consumed += run;
+      stalled = run < 64 && !closed;
+    }
+    if (closed) break;
+    if (consumed == 0) {
       if (++idle > (1 << 20)) { ok = false; break; }
       __builtin_amdgcn_s_sleep(8);
       continue;
     }
-    unsigned l = (lane < run) ? (unsigned)((w >> 31) & 0x7fffffffull) : 0u;
-    unsigned c = (lane < run) ? (unsigned)(w & 0x7fffffffull) : 0u;
-    for (int off = 32; off > 0; off >>= 1) {
-      l += __shfl_xor(l, off);
-      c += __shfl_xor(c, off);
-    }
-    sum_live += l;
-    sum_carry += c;
-    if (closed) break;
-    base -= run;
+    base -= consumed;
   }
   excl_live = sum_live;
   excl_carry = sum_carry;
@@ -573,7 +595,7 @@ __device__ __forceinline__ bool lookback(unsigned long long* state, int tile, un
 #ifdef PRT_TIMING
 // experiment build: s_memtime stamps of every wave of generation 0 at 8 points of k_generation
 __device__ long long g_stamps[16384 * 4 * 8];
-#define STAMP(k) do { if (g == 0 && (threadIdx.x & 63) == 0 && blockIdx.x < 16384) g_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define STAMP(k) do { if (g == 0 && (threadIdx.x & 63) == 0 && blockIdx.x < 16384) g_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define STAMP(k) do {} while (0)
 #endif
@@ -708,19 +730,6 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   const int64_t i = (int64_t)tile * PRT_BLOCK + threadIdx.x;
   const LaneLists lists = lane_lists(scene.lds_slots);
   const int park_base = (3 * scene.lds_slots + 1) / 2;
-  // the primitive table goes to LDS behind the parking rows (small scenes; see lds_bytes_fused): the
-  // copy is issued here, ahead of the ray loads, and is complete for everybody at the barrier that
-  // follows the hit phase
-  LdsPrimPtr lds_prims = nullptr;
-#ifndef PRT_NO_LDS_PRIMS
-  if (scene.n_prims_staged > 0) {
-    double* table = lds_dyn + (park_base + PRT_PARK_ROWS) * PRT_BLOCK;
-    const double* src = reinterpret_cast<const double*>(scene.prims);
-    const int words = scene.n_prims_staged * (int)(sizeof(DevPrim) / sizeof(double));
-    for (int k = threadIdx.x; k < words; k += PRT_BLOCK) table[k] = src[k];
-    lds_prims = (LdsPrimPtr)table;
-  }
-#endif
   Ray8 r = {0, 0, 0, 1, 0, 0, 0, 0};
   double t = PRT_INF;
   int prim = -1;
@@ -770,6 +779,10 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   STAMP(3);
   if (threadIdx.x == 0 && tile > 0)
     tile_store(tiles_cur + tile, tile_pack(TILE_AGGREGATE, agg_live, agg_carry));
+  unsigned long long early = ~0ull;
+#ifdef PRT_LOOKBACK_EARLY
+  if (wave == 0) early = lookback_early(tiles_cur, tile);
+#endif
   // Shade BEFORE asking where the results go: the predecessors get this long to publish their
   // aggregates, so the look-back below mostly finds them ready instead of waiting.
   // Record columns that are known before the shading (metadata, segment start) are parked in
@@ -783,7 +796,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     meta.wavelength = PARK(2);
     meta.index = PARK(3);
     PARK(5) = r.ox; PARK(6) = r.oy; PARK(7) = r.oz;
-    sh = interact_compute(scene, meta, r, t, prim, lds_prims);
+    sh = interact_compute(scene, meta, r, t, prim);
   }
   STAMP(5);
   if (wave == 0) {
@@ -793,7 +806,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     e_live = (unsigned)tile * PRT_BLOCK; e_carry = (unsigned)tile * PRT_BLOCK;
     if (lane == 0) tile_store(tiles_cur + tile, tile_pack(TILE_PREFIX, e_live + agg_live, e_carry + agg_carry));
 #else
-    bool ok = lookback(tiles_cur, tile, agg_live, agg_carry, e_live, e_carry);
+    bool ok = lookback(tiles_cur, tile, agg_live, agg_carry, e_live, e_carry, early);
 #endif
     if (ctrl->pad == 1 && tile == 3) ok = false;  // test hook: pretend the spin expired
     if (!ok && lane == 0) atomicExch(&ctrl->error, PRT_ERR_STALL);
@@ -1107,9 +1120,8 @@ static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + PRT_BLOCK 
 static inline size_t lds_bytes(int slots) { return (size_t)slots * PRT_BLOCK * 12; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // the fused kernel parks 8 float64 per lane behind the hit lists
-static const int kMaxStagedPrims = 48;  // 48 x 264 B = 12.4 KiB next to the 16 KiB of parking rows
-static inline size_t lds_bytes_fused(int slots, int prims_staged) {
-  return (size_t)((3 * slots + 1) / 2 + 8) * PRT_BLOCK * sizeof(double) + (size_t)prims_staged * sizeof(DevPrim);
+static inline size_t lds_bytes_fused(int slots) {
+  return (size_t)((3 * slots + 1) / 2 + 8) * PRT_BLOCK * sizeof(double);
 }
 
 static SceneDev trace_scene_dev(const prt_scene* s, const DeviceCopy* c) {
@@ -1498,12 +1510,9 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
   double* buf[2] = {(double*)(w + l.rays_a), (double*)(w + l.rays_b)};
   const int keep_absorbed = (flags & PRT_TRACE_KEEP_ABSORBED) ? 1 : 0;
   SceneDev sd = trace_scene_dev(s, c);
-  // experiment knob PRT_LDS_PRIMS=1: shade from an LDS copy of the primitive table, per lane, without the
-  // waterfall.  Measured slower on every BASELINE scene (+6 % config 2, +17 % config 3, +10 % config 4):
-  // the waterfall's wave-uniform branches and batched L1 reads beat per-lane ds_reads and divergent code.
-  sd.n_prims_staged = getenv("PRT_LDS_PRIMS") && (int)s->dev_prims.size() <= kMaxStagedPrims ? (int)s->dev_prims.size() : 0;
-  size_t lds = lds_bytes_fused(sd.lds_slots, sd.n_prims_staged);
-  if (lds > kMaxLdsBytes) { sd.n_prims_staged = 0; lds = lds_bytes_fused(sd.lds_slots, 0); }
+  // (shading from an LDS copy of the primitive table was tried in two forms -- per lane without the
+  // waterfall, and inside the waterfall -- and measured 2-17 % slower than the batched L1 reads)
+  const size_t lds = lds_bytes_fused(sd.lds_slots);
   const int n_slots = generation_limit + 1;
   // PRT_TEST_STALL=1 makes one tile report an expired look-back so that the tests can exercise
   // the fallback to the three-kernel path.

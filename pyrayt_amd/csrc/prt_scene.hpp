@@ -30,7 +30,6 @@ struct SceneDev {
   int n_instr;
   int lds_slots;
   unsigned long long absorber_mask = 0;  // bit p: primitive p (< 64) has the absorbing material
-  int n_prims_staged = 0;                // generation kernel: primitives it copies to LDS for the shading (0: none)
 };
 
 struct Program {

@@ -4,7 +4,7 @@ stamps: 0 start | 1 origin/direction rows arrived | 2 nearest hit done | 3 barri
         4 metadata rows arrived | 5 shaded | 6 look-back + barrier 2 passed | 7 stores issued"""
 import sys
 import numpy as np
-GHZ = 2.4
+GHZ = 0.1  # s_memrealtime: 100 MHz, one clock for the whole chip
 t = np.fromfile(sys.argv[1], dtype=np.int64).reshape(-1, 8)
 t = t[(t[:, 0] > 0) & (t[:, 7] > t[:, 0])]
 t0 = t[:, 0].min()
