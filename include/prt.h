@@ -272,6 +272,14 @@ int prt_frame_reduce(int device, const double* rows, int64_t ld, int64_t n_rows,
 #define PRT_VARIANT_KLANES 3      /* ... with the surface-parallel nearest-hit kernel (K lanes per ray,
                                      shuffle min-reduce; environment PRT_HIT_VARIANT=lanes4|lanes8|lanes16) */
 int prt_trace_stats(const prt_scene* scene, double* out8);
+/* counters of this scene since it was created: out4 = { traces re-run on the three-kernel path after a
+ * look-back gave up, traces repeated because a dense-mode hint did not hold, generation launches made in
+ * dense mode, 0 }.  Dense mode: a generation in which the previous trace of the same scene and ray count
+ * recorded every ray and carried all or none of them on is launched on the assumption that it will
+ * again -- every tile then knows its output position without the look-back; each tile checks the
+ * assumption on its own counts and a miss repeats the trace without assumptions (results are exact
+ * either way; PRT_NO_HINTS=1 in the environment turns the hints off). */
+int prt_trace_telemetry(const prt_scene* scene, int64_t* out4);
 
 /* ---- renderers (second consumer of the intersect path) ----------
  * tinygfx/g3d/renderers.py: an OrthographicCamera grid (world_objects.py:499-537) is pushed

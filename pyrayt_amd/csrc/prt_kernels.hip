@@ -484,6 +484,7 @@ __global__ void k_publish(const FusedCtrl* __restrict__ ctrl, const GenCtrl* __r
   if (k == 0) __hip_atomic_store(&host->epoch, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+#define PRT_ERR_SPECULATION (-101) /* internal: a generation launched in dense mode was not dense -> host re-runs without hints */
 #define PRT_ERR_STALL (-100) /* internal: look-back gave up -> host falls back to the unfused path */
 
 // tile status word for the decoupled look-back: [63:62] status, [61:31] live, [30:0] carried.
@@ -706,7 +707,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
              GenCtrl* __restrict__ gen, int g, unsigned long long* __restrict__ tiles_cur,
              unsigned long long* __restrict__ tiles_next, double next_generation, int relaunch,
              double ray_offset, int keep_absorbed, HostMirror* mirror, unsigned long long epoch,
-             int mirror_slot, int batch_last) {
+             int mirror_slot, int batch_last, int assume) {
   __shared__ int s_wave_live[4], s_wave_carry[4];
   __shared__ unsigned s_excl[2];
   // A ticket from one atomic word would also give start-ordered tile numbers, but a single
@@ -777,8 +778,24 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     agg_carry += s_wave_carry[w];
   }
   STAMP(3);
-  if (threadIdx.x == 0 && tile > 0)
+  // Dense mode (assume != 0): the previous trace of this scene and ray count recorded every ray of this
+  // generation and carried all (1) or none (2) of them on, so the host launched it on the assumption
+  // that it will again: every tile's prefix is then its index times the tile size -- no status words,
+  // no look-back, no second barrier.  Each tile checks the assumption on its own counts; a tile that
+  // finds it wrong raises PRT_ERR_SPECULATION and the host repeats the trace without assumptions.
+  // The totals of a dense generation are the assumption itself, so tile 0 hands over to g + 1; the host
+  // learns the outcome from the kernel behind the batch (k_publish), which the stream runs after every
+  // tile has checked itself.
+  bool finisher = false;
+  if (assume) {
+    if (threadIdx.x == 0) {
+      const int64_t mine = (n - (int64_t)tile * PRT_BLOCK) < PRT_BLOCK ? (n - (int64_t)tile * PRT_BLOCK) : PRT_BLOCK;
+      const bool holds = (int64_t)agg_live == mine && (int64_t)agg_carry == (assume == 1 ? mine : 0);
+      if (!holds && !failed) atomicExch(&ctrl->error, PRT_ERR_SPECULATION);
+    }
+  } else if (threadIdx.x == 0 && tile > 0) {
     tile_store(tiles_cur + tile, tile_pack(TILE_AGGREGATE, agg_live, agg_carry));
+  }
   unsigned long long early = ~0ull;
 #ifdef PRT_LOOKBACK_EARLY
   if (wave == 0) early = lookback_early(tiles_cur, tile);
@@ -799,6 +816,13 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     sh = interact_compute(scene, meta, r, t, prim);
   }
   STAMP(5);
+  const int64_t last_tile = (n - 1) / PRT_BLOCK;
+  int64_t excl_live, excl_carry;
+  if (assume) {
+    finisher = tile == 0;
+    excl_live = (int64_t)tile * PRT_BLOCK;
+    excl_carry = assume == 1 ? (int64_t)tile * PRT_BLOCK : 0;
+  } else {
   if (wave == 0) {
     unsigned e_live, e_carry;
 #if defined(PRT_ABLATE) && (PRT_ABLATE & 16)
@@ -813,12 +837,16 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     if (lane == 0) { s_excl[0] = e_live; s_excl[1] = e_carry; }
   }
   __syncthreads();
+  excl_live = s_excl[0];
+  excl_carry = s_excl[1];
+  finisher = tile == last_tile;
+  }
   STAMP(6);
-  const int64_t excl_live = s_excl[0], excl_carry = s_excl[1];
 
-  const int64_t last_tile = (n - 1) / PRT_BLOCK;
-  if (tile == last_tile && threadIdx.x == 0) {  // totals are known here: hand over to g + 1
-    const int64_t total_live = excl_live + agg_live, total_carry = excl_carry + agg_carry;
+  if (finisher && threadIdx.x == 0) {  // totals are known here: hand over to g + 1
+    // (dense mode: the totals are the assumption itself; if it failed the error word says so)
+    const int64_t total_live = assume ? n : excl_live + agg_live;
+    const int64_t total_carry = assume ? (assume == 1 ? n : 0) : excl_carry + agg_carry;
     const int64_t next_in = (total_live == 0) ? 0 : total_carry;
     gen[g].n_live = total_live;
     gen[g].n_carry = total_carry;
@@ -1501,7 +1529,7 @@ static int await_epoch(DeviceCopy* c, unsigned long long epoch, hipStream_t st) 
 static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int64_t n, int64_t ld,
                            int generation_limit, double ray_offset, double* rows_out,
                            int64_t rows_cap, int64_t* rows_per_generation, char* w, int flags,
-                           hipStream_t st) {
+                           hipStream_t st, bool allow_hints) {
   const TraceLayout l = trace_layout(n);
   FusedCtrl* ctrl = (FusedCtrl*)(w + l.fctrl);
   GenCtrl* gen = (GenCtrl*)(w + l.gen);
@@ -1537,13 +1565,14 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
   // the generation kernels tell the host themselves unless an error can still be raised after the
   // last tile has its totals (only PRT_ERR_UNTRACABLE, at store time) or an experiment kernel runs
   // (the stall test hook raises its fake error from a tile that no successor waits for: same path)
-  bool in_kernel_publish = !s->has_untracable && !test_stall && getenv("PRT_PUBLISH_KERNEL") == nullptr;
-#ifdef PRT_EXPERIMENTS
-  if (two_per_lane) in_kernel_publish = false;
-#endif
+  const bool publish_in_kernel = !s->has_untracable && !test_stall && getenv("PRT_PUBLISH_KERNEL") == nullptr;
+  // Hints from the previous trace of this scene with this many rays (PRT_NO_HINTS=1 turns them off).
+  const bool use_hints = allow_hints && s->hint_n == n && s->hint_keep_absorbed == keep_absorbed &&
+                         getenv("PRT_NO_HINTS") == nullptr && !test_stall;
   int64_t bound = n, total_rows = 0;
   int g = 0, error = 0;
   bool done = false;
+  std::vector<char> seen_mode;
   while (g < generation_limit && !done) {
     // Generations are launched blind, a batch at a time, and the host looks at the counts once per
     // batch.  A scene traced before most likely runs as many generations as last time: launching
@@ -1554,6 +1583,13 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
     rc = settle_timing(s, c);
     if (rc) return rc;
     const unsigned long long epoch = ++c->epoch;
+    // a batch with a dense-mode generation is published by the kernel behind it (see k_generation)
+    bool in_kernel_publish = publish_in_kernel;
+    for (int b = 0; b < batch; ++b)
+      if (use_hints && g + b < (int)s->hint_mode.size() && s->hint_mode[g + b]) in_kernel_publish = false;
+#ifdef PRT_EXPERIMENTS
+    if (two_per_lane) in_kernel_publish = false;
+#endif
     HIP_TRY(hipEventRecord(c->ev0, st));
     for (int b = 0; b < batch; ++b) {
       const int gg = g + b;
@@ -1569,12 +1605,17 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
         continue;
       }
 #endif
+      // dense-mode hint of the previous trace for this generation (the kernel reads the generation's
+      // ray count on the device and checks the assumption tile by tile)
+      int assume = 0;
+      if (use_hints && gg < (int)s->hint_mode.size()) assume = s->hint_mode[gg];
+      s->dense_launches += assume ? 1 : 0;
       auto kernel = culls ? k_generation<true> : k_generation<false>;
       hipLaunchKernelGGL(kernel, dim3(blocks_for(bound)), dim3(PRT_BLOCK), lds + lds_pad, st, sd, src,
                          src_ld, buf[gg & 1], n, rows_out, rows_cap, ctrl, gen, gg, tiles[gg & 1],
                          tiles[(gg + 1) & 1], (double)(gg + 1), relaunch, ray_offset, keep_absorbed,
                          in_kernel_publish ? c->mirror_dev : (HostMirror*)nullptr, epoch, b,
-                         b + 1 == batch ? 1 : 0);
+                         b + 1 == batch ? 1 : 0, assume);
     }
     HIP_TRY(hipEventRecord(c->ev1, st));
     c->timing_pending = true;
@@ -1599,6 +1640,9 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
       s->stats[5] += (double)host_gen[b].n_carry;
       rows_per_generation[g + b] = host_gen[b].n_live;
       total_rows += host_gen[b].n_live;
+      const bool all_live = host_gen[b].n_live == host_gen[b].n_in;
+      seen_mode.push_back(all_live && host_gen[b].n_carry == host_gen[b].n_in ? 1
+                          : all_live && host_gen[b].n_carry == 0 ? 2 : 0);
     }
     if (!done) bound = host_gen[batch].n_in;
     if (bound == 0) done = true;
@@ -1612,8 +1656,12 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
     }
   }
 #endif
+  if (error == PRT_ERR_SPECULATION) return PRT_ERR_SPECULATION;
   if (error) return trace_error(error);
   s->last_generations = (int)s->stats[0];
+  s->hint_n = n;
+  s->hint_keep_absorbed = keep_absorbed;
+  s->hint_mode = seen_mode;
   // k_fused_reinit behind the last batch has cleared the control words for a next trace of this shape
   c->ready_workspace = w;
   c->ready_n = n;
@@ -1646,7 +1694,22 @@ extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64
   }
   s->stats[7] = PRT_VARIANT_FUSED;
   int64_t rc64 = trace_fused(s, c, rays, n, ld, generation_limit, ray_offset, rows_out, rows_cap,
-                             rows_per_generation, (char*)workspace, flags, (hipStream_t)stream);
+                             rows_per_generation, (char*)workspace, flags, (hipStream_t)stream, true);
+  if (rc64 == PRT_ERR_SPECULATION) {
+    // a generation assumed dense was not (the rays or the scene changed since the hints were taken):
+    // nothing of this attempt is kept; run again without assumptions, which also renews the hints
+    s->speculation_misses += 1;
+    s->hint_n = -1;
+    for (int g = 0; g < generation_limit; ++g) rows_per_generation[g] = 0;
+    rc = settle_timing(s, c);
+    if (rc) return rc;
+    const double fallbacks = s->stats[6];
+    for (double& v : s->stats) v = 0;
+    s->stats[6] = fallbacks;
+    s->stats[7] = PRT_VARIANT_FUSED;
+    rc64 = trace_fused(s, c, rays, n, ld, generation_limit, ray_offset, rows_out, rows_cap,
+                       rows_per_generation, (char*)workspace, flags, (hipStream_t)stream, false);
+  }
   if (rc64 == PRT_ERR_STALL) {  // never observed outside the test hook; see lookback()
     for (int g = 0; g < generation_limit; ++g) rows_per_generation[g] = 0;
     rc = settle_timing(s, c);
@@ -1671,6 +1734,15 @@ extern "C" int prt_debug_slow_counters(unsigned long long* out4, int reset) {
   return PRT_OK;
 }
 #endif
+
+extern "C" int prt_trace_telemetry(const prt_scene* s, int64_t* out4) {
+  if (!s || !out4) return fail(PRT_ERR_ARG, "null argument");
+  out4[0] = s->lookback_fallbacks;
+  out4[1] = s->speculation_misses;
+  out4[2] = s->dense_launches;
+  out4[3] = 0;
+  return PRT_OK;
+}
 
 extern "C" int prt_trace_stats(const prt_scene* s, double* out8) {
   if (!s || !out8) return fail(PRT_ERR_ARG, "null argument");

@@ -52,6 +52,7 @@ def _declare(lib):
         "prt_trace": (c_i64, [c_p, c_int, c_p, c_i64, c_i64, c_int, c_d, c_p, c_i64, c_p, c_p,
                               c_int, c_p]),
         "prt_trace_stats": (c_int, [c_p, c_p]),
+        "prt_trace_telemetry": (c_int, [c_p, c_p]),
         "prt_generate_rays": (c_int, [c_int, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p]),
         "prt_camera_rays": (c_int, [c_int, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
         "prt_render_hits": (c_int, [c_p, c_int, c_p, c_i64, c_i64, c_p, c_p, c_p]),
@@ -89,7 +90,7 @@ EXPORTED_SYMBOLS = (
     "prt_version", "prt_last_error", "prt_device_count", "prt_scene_create", "prt_scene_destroy",
     "prt_scene_component_rows", "prt_scene_info", "prt_intersect", "prt_propagate", "prt_world_normals",
     "prt_material_trace", "prt_interact_workspace_bytes", "prt_interact",
-    "prt_trace_workspace_bytes", "prt_trace", "prt_trace_stats", "prt_generate_rays",
+    "prt_trace_workspace_bytes", "prt_trace", "prt_trace_stats", "prt_trace_telemetry", "prt_generate_rays",
     "prt_camera_rays", "prt_render_hits", "prt_gooch_shade", "prt_gooch_mix", "prt_render",
     "prt_edge_workspace_bytes", "prt_edge_canvas", "prt_reflect", "prt_refract", "prt_binomial_root",
     "prt_smallest_positive_root", "prt_dot", "prt_array_csg", "prt_primitive_intersect",
@@ -285,6 +286,13 @@ class DeviceScene:
                 "kernel_ms": float(out[2]), "kernel_launches": int(out[3]),
                 "rows": int(out[4]), "rays_carried": int(out[5]),
                 "lookback_fallbacks": int(out[6]), "variant": int(out[7])}
+
+    def telemetry(self):
+        """Counters since the scene was created (``prt_trace_telemetry``)."""
+        out = (ctypes.c_int64 * 4)()
+        _check(library().prt_trace_telemetry(self.handle, out))
+        return {"lookback_fallbacks": int(out[0]), "speculation_misses": int(out[1]),
+                "dense_launches": int(out[2])}
 
     # --- per-state entry points -----------------------------------------------------------------
     def propagate(self, rays):

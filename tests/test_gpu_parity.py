@@ -544,3 +544,45 @@ def test_baseline_configs_at_full_size(name, args, limit):
     sub_rows, sub_counts = ds.trace(dev(rays[:, pick]), limit)
     assert sub_counts == want_counts and np.array_equal(sub_rows.cpu().numpy().T, got)
     ds.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# dense-mode hints: a repeated trace launches the generations that were dense last time without the
+# look-back; a hint that does not hold must cost a repeat, never a wrong frame
+# ---------------------------------------------------------------------------------------------
+def test_dense_mode_hints_repeat_and_miss(monkeypatch):
+    from pyrayt_amd.engine import DeviceScene
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    CountedObject.reset_ids()
+    parts, rays = scenes.config2(scenes.product_api(), 50_000)
+    snap = SceneSnapshot(parts)
+    flat = helpers.flat_scene(snap)
+    ds = DeviceScene(snap)
+    want, want_counts = orc.trace(flat, rays, 10)
+    first, counts = ds.trace(dev(rays), 10)
+    assert counts == want_counts and ds.telemetry()["dense_launches"] == 0
+    first = first.cpu().numpy().copy()
+    again, counts = ds.trace(dev(rays), 10)               # generations 0 and 2 are dense (all carried / none carried)
+    tele = ds.telemetry()
+    assert tele["dense_launches"] >= 2 and tele["speculation_misses"] == 0
+    assert counts == want_counts and np.array_equal(again.cpu().numpy(), first)
+    helpers.assert_frames_match(first.T, want, what="config2 hinted")
+    # same ray count, but a third of the rays now miss everything: generation 0 is no longer dense
+    other = rays.copy()
+    other[5, ::3] = 5.0
+    other[4:7] /= np.linalg.norm(other[4:7], axis=0)
+    want2, want2_counts = orc.trace(flat, other, 10)
+    got2, counts2 = ds.trace(dev(other), 10)
+    assert ds.telemetry()["speculation_misses"] == 1
+    assert counts2 == want2_counts
+    helpers.assert_frames_match(got2.cpu().numpy().T, want2, what="config2 after a missed hint")
+    got3, counts3 = ds.trace(dev(other), 10)              # hints renewed from the repeat
+    assert counts3 == want2_counts and np.array_equal(got3.cpu().numpy(), got2.cpu().numpy())
+    assert ds.telemetry()["speculation_misses"] == 1
+    monkeypatch.setenv("PRT_NO_HINTS", "1")
+    before = ds.telemetry()["dense_launches"]
+    got4, _ = ds.trace(dev(other), 10)
+    assert ds.telemetry()["dense_launches"] == before and np.array_equal(got4.cpu().numpy(), got2.cpu().numpy())
+    ds.close()
