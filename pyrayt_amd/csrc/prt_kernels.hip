@@ -469,21 +469,6 @@ struct HostMirror {
 };
 static_assert(offsetof(HostMirror, gen) == 64, "mirror header");
 
-__global__ void k_publish(const FusedCtrl* __restrict__ ctrl, const GenCtrl* __restrict__ gen, int count,
-                          HostMirror* host, unsigned long long epoch) {
-  const int k = threadIdx.x;
-  if (k < count) {
-    host->gen[k].n_in = gen[k].n_in;
-    host->gen[k].row_base = gen[k].row_base;
-    host->gen[k].n_live = gen[k].n_live;
-    host->gen[k].n_carry = gen[k].n_carry;
-  }
-  if (k == 0) host->error = ctrl->error;
-  __threadfence_system();
-  __syncthreads();
-  if (k == 0) __hip_atomic_store(&host->epoch, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 #define PRT_ERR_SPECULATION (-101) /* internal: a generation launched in dense mode was not dense -> host re-runs without hints */
 #define PRT_ERR_STALL (-100) /* internal: look-back gave up -> host falls back to the unfused path */
 
@@ -784,7 +769,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   // no look-back, no second barrier.  Each tile checks the assumption on its own counts; a tile that
   // finds it wrong raises PRT_ERR_SPECULATION and the host repeats the trace without assumptions.
   // The totals of a dense generation are the assumption itself, so tile 0 hands over to g + 1; the host
-  // learns the outcome from the kernel behind the batch (k_publish), which the stream runs after every
+  // learns the outcome from the kernel behind the batch (k_fused_reinit), which the stream runs after every
   // tile has checked itself.
   bool finisher = false;
   if (assume) {
@@ -856,7 +841,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
       // The host is told from here, not by a copy after the launch: the counts of this generation go to
       // host-mapped memory, and the generation that ends the trace (or the batch) raises the epoch word
       // the host spins on.  Errors that can still be raised after this point are ruled out by the
-      // caller (scenes with untracable materials take the k_publish path).
+      // caller (scenes with untracable materials are published by k_fused_reinit behind the batch).
       mirror->gen[mirror_slot].n_in = n;
       mirror->gen[mirror_slot].row_base = row_base;
       mirror->gen[mirror_slot].n_live = total_live;
@@ -1027,9 +1012,26 @@ __global__ void k_fused_init(FusedCtrl* ctrl, GenCtrl* gen, int n_gen_slots,
 // end of a fused trace, enqueued blind behind a batch: if the trace is over (the slot behind the batch
 // holds no rays, or the generation limit is reached) clear the control words for the next trace of the
 // same shape -- off the host's critical path; otherwise leave everything for the next batch.
+// When the generation kernels of the batch did not tell the host themselves (mirror != null here), the
+// counts of slots [first_slot, first_slot + count) are published first -- without
+// a launch of its own.
 __global__ void k_fused_reinit(FusedCtrl* ctrl, GenCtrl* gen, int n_gen_slots, int end_slot, int limit,
-                               unsigned long long* tiles0, int64_t n_tiles, int64_t n, int test_stall) {
+                               unsigned long long* tiles0, int64_t n_tiles, int64_t n, int test_stall,
+                               HostMirror* mirror, unsigned long long epoch, int first_slot, int count) {
   const bool over = end_slot >= limit || gen[end_slot].n_in == 0 || ctrl->error != 0;
+  if (mirror) {
+    const int k = threadIdx.x;
+    if (k < count) {
+      mirror->gen[k].n_in = gen[first_slot + k].n_in;
+      mirror->gen[k].row_base = gen[first_slot + k].row_base;
+      mirror->gen[k].n_live = gen[first_slot + k].n_live;
+      mirror->gen[k].n_carry = gen[first_slot + k].n_carry;
+    }
+    if (k == 0) mirror->error = ctrl->error;
+    __threadfence_system();
+    __syncthreads();
+    if (k == 0) __hip_atomic_store(&mirror->epoch, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (!over) return;
   // every block must see the same `over`: the slot is rewritten below, so sync through a second launch
   // is avoided by letting block 0 alone touch the slots and only after all blocks have read them --
@@ -1567,6 +1569,12 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
   // (the stall test hook raises its fake error from a tile that no successor waits for: same path)
   const bool publish_in_kernel = !s->has_untracable && !test_stall && getenv("PRT_PUBLISH_KERNEL") == nullptr;
   // Hints from the previous trace of this scene with this many rays (PRT_NO_HINTS=1 turns them off).
+  // After a miss the hints rest for 2, 4, 8 ... 64 traces (a caller that alternates between ray sets of
+  // different shapes must not pay a repeat every time).
+  if (allow_hints && s->hint_holdoff > 0) {
+    s->hint_holdoff -= 1;
+    allow_hints = false;
+  }
   const bool use_hints = allow_hints && s->hint_n == n && s->hint_keep_absorbed == keep_absorbed &&
                          getenv("PRT_NO_HINTS") == nullptr && !test_stall;
   int64_t bound = n, total_rows = 0;
@@ -1619,12 +1627,11 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
     }
     HIP_TRY(hipEventRecord(c->ev1, st));
     c->timing_pending = true;
-    if (!in_kernel_publish)
-      hipLaunchKernelGGL(k_publish, dim3(1), dim3(kMaxBatch + 4), 0, st, (const FusedCtrl*)ctrl,
-                         (const GenCtrl*)(gen + g), batch + 1, c->mirror_dev, epoch);
-    // clears the control words for the next trace if this batch turns out to end the trace
+    // behind the batch: tell the host if the generation kernels did not, and clear the control words
+    // for the next trace if this batch turns out to end the trace
     hipLaunchKernelGGL(k_fused_reinit, dim3(1), dim3(1024), 0, st, ctrl, gen, n_slots, g + batch,
-                       generation_limit, tiles[0], (int64_t)blocks_for(n), n, test_stall);
+                       generation_limit, tiles[0], (int64_t)blocks_for(n), n, test_stall,
+                       in_kernel_publish ? (HostMirror*)nullptr : c->mirror_dev, epoch, g, batch + 1);
     HIP_TRY(hipGetLastError());
     rc = await_epoch(c, epoch, st);
     if (rc) return rc;
@@ -1662,6 +1669,7 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
   s->hint_n = n;
   s->hint_keep_absorbed = keep_absorbed;
   s->hint_mode = seen_mode;
+  if (use_hints) s->hint_misses_in_a_row = 0;
   // k_fused_reinit behind the last batch has cleared the control words for a next trace of this shape
   c->ready_workspace = w;
   c->ready_n = n;
@@ -1699,6 +1707,8 @@ extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64
     // a generation assumed dense was not (the rays or the scene changed since the hints were taken):
     // nothing of this attempt is kept; run again without assumptions, which also renews the hints
     s->speculation_misses += 1;
+    s->hint_misses_in_a_row = std::min(s->hint_misses_in_a_row + 1, 6);
+    s->hint_holdoff = 1 << s->hint_misses_in_a_row;
     s->hint_n = -1;
     for (int g = 0; g < generation_limit; ++g) rows_per_generation[g] = 0;
     rc = settle_timing(s, c);

@@ -77,6 +77,8 @@ struct prt_scene {
   std::vector<char> hint_mode;  // per generation: 0 general, 1 every ray recorded and carried on, 2 recorded, none carried
   long speculation_misses = 0;  // traces that had to be repeated because a hint did not hold
   long dense_launches = 0;      // generation launches made in dense mode so far
+  int hint_holdoff = 0;         // traces still to run without hints after a miss (doubles with every miss in a row)
+  int hint_misses_in_a_row = 0;
 };
 
 static int leaves_under(const prt_scene* s, int node) {
