@@ -589,3 +589,25 @@ def test_dense_mode_hints_repeat_and_miss(monkeypatch):
     got4, _ = ds.trace(dev(other), 10)
     assert ds.telemetry()["dense_launches"] == before and np.array_equal(got4.cpu().numpy(), got2.cpu().numpy())
     ds.close()
+
+
+def test_dense_mode_hints_across_limits_flags_and_sizes():
+    """Hints survive what may change between two traces of one scene object: generation limit, the
+    keep-absorbed flag, the ray count, a first batch that is shorter than the trace."""
+    from pyrayt_amd.engine import DeviceScene
+
+    fx = helpers.load("scene_config3.npz")       # seven generations, two of them lose rays
+    ds = device_scene(helpers.scene_of(fx))
+    rays = dev(fx["rays0"])
+    want = fx["frame"]
+    for limit, flags in ((10, 0), (10, 0), (3, 0), (10, 0), (10, 1), (10, 1), (10, 0), (2, 2), (10, 0)):
+        rows, counts = ds.trace(rays, limit, flags=flags)
+        got = rows.cpu().numpy().T
+        keep = want[:, 0] < limit                   # rows of the first `limit` generations
+        helpers.assert_frames_match(got, want[keep], what=f"config3 limit {limit} flags {flags}")
+    assert ds.telemetry()["speculation_misses"] == 0 and ds.telemetry()["dense_launches"] > 0
+    half = dev(np.ascontiguousarray(fx["rays0"][:, ::2]))
+    rows, _ = ds.trace(half, 10)                   # another ray count: no hints, then its own
+    rows2, _ = ds.trace(half, 10)
+    assert np.array_equal(rows.cpu().numpy(), rows2.cpu().numpy())
+    ds.close()
