@@ -768,15 +768,37 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   // that it will again: every tile's prefix is then its index times the tile size -- no status words,
   // no look-back, no second barrier.  Each tile checks the assumption on its own counts; a tile that
   // finds it wrong raises PRT_ERR_SPECULATION and the host repeats the trace without assumptions.
-  // The totals of a dense generation are the assumption itself, so tile 0 hands over to g + 1; the host
-  // learns the outcome from the kernel behind the batch (k_fused_reinit), which the stream runs after every
-  // tile has checked itself.
+  // The totals of a dense generation are the assumption itself, so tile 0 hands over to g + 1.
   bool finisher = false;
+  // the generation that ends the batch (known at launch in this mode) also tells the host: its tiles
+  // check in on counters kept in the otherwise unused status buffer (cleared by the next generation like
+  // any status word), and the last one to arrive publishes, with every tile's verdict visible to it
+  const bool publish_here = assume && mirror != nullptr && (assume == 2 || batch_last);
   if (assume) {
     if (threadIdx.x == 0) {
       const int64_t mine = (n - (int64_t)tile * PRT_BLOCK) < PRT_BLOCK ? (n - (int64_t)tile * PRT_BLOCK) : PRT_BLOCK;
       const bool holds = (int64_t)agg_live == mine && (int64_t)agg_carry == (assume == 1 ? mine : 0);
-      if (!holds && !failed) atomicExch(&ctrl->error, PRT_ERR_SPECULATION);
+      if (!holds && !failed) {
+        // (the returned value is waited for: the verdict is in place before this tile checks in below)
+        const int before = atomicExch(&ctrl->error, PRT_ERR_SPECULATION);
+        asm volatile("" ::"v"(before) : "memory");
+      }
+      finisher = tile == 0;
+      if (publish_here) {
+        // Two levels (64 tiles to a counter, the last of each on to the root): thousands of increments of
+        // one address would serialise for longer than the generation runs.  Relaxed on purpose: an
+        // agent-scope release / acquire writes back and invalidates this XCD's L2 -- per tile, that tripled
+        // the generation's run time -- and the words involved (counters, error) are only ever touched
+        // by agent-scope atomics, which meet at the memory side like the look-back's status words.
+        const unsigned long long last = (unsigned long long)((n - 1) / PRT_BLOCK), group = (unsigned long long)tile >> 6;
+        const unsigned long long members = group == (last >> 6) ? (last & 63) + 1 : 64;
+        bool done = __hip_atomic_fetch_add(tiles_cur + (group << 6), 1ull, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT) == members - 1;
+        if (done && (last >> 6) > 0)
+          done = __hip_atomic_fetch_add(tiles_cur + 32, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                 (last >> 6);
+        finisher = done;
+      }
     }
   } else if (threadIdx.x == 0 && tile > 0) {
     tile_store(tiles_cur + tile, tile_pack(TILE_AGGREGATE, agg_live, agg_carry));
@@ -804,7 +826,6 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   const int64_t last_tile = (n - 1) / PRT_BLOCK;
   int64_t excl_live, excl_carry;
   if (assume) {
-    finisher = tile == 0;
     excl_live = (int64_t)tile * PRT_BLOCK;
     excl_carry = assume == 1 ? (int64_t)tile * PRT_BLOCK : 0;
   } else {
@@ -1591,10 +1612,7 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
     rc = settle_timing(s, c);
     if (rc) return rc;
     const unsigned long long epoch = ++c->epoch;
-    // a batch with a dense-mode generation is published by the kernel behind it (see k_generation)
     bool in_kernel_publish = publish_in_kernel;
-    for (int b = 0; b < batch; ++b)
-      if (use_hints && g + b < (int)s->hint_mode.size() && s->hint_mode[g + b]) in_kernel_publish = false;
 #ifdef PRT_EXPERIMENTS
     if (two_per_lane) in_kernel_publish = false;
 #endif

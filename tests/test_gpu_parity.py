@@ -591,6 +591,41 @@ def test_dense_mode_hints_repeat_and_miss(monkeypatch):
     ds.close()
 
 
+@pytest.mark.parametrize("n", [5_000, 32_768, 50_000, 16_385 * 4])
+def test_dense_mode_miss_in_the_generation_that_ends_the_trace(n):
+    """The generation that ends a hinted batch tells the host itself: its tiles check in on counters
+    (one level up to 64 tiles, two above) and the last to arrive publishes -- with the verdict of every
+    tile, also when the assumption failed in a single one of them."""
+    from pyrayt_amd.engine import DeviceScene
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    CountedObject.reset_ids()
+    parts, rays = scenes.config2(scenes.product_api(), n)
+    snap = SceneSnapshot(parts)
+    flat = helpers.flat_scene(snap)
+    ds = DeviceScene(snap)
+    want, want_counts = orc.trace(flat, rays, 1)
+    for _ in range(3):                                    # one generation: it is first and last at once
+        got, counts = ds.trace(dev(rays), 1)
+        assert counts == want_counts
+    helpers.assert_frames_match(got.cpu().numpy().T, want, what="one dense generation")
+    assert ds.telemetry()["dense_launches"] == 2 and ds.telemetry()["speculation_misses"] == 0
+    for victim in (0, n // 2, n - 1):                     # one ray of one tile misses everything
+        other = rays.copy()
+        other[4:7, victim] = (0.0, 1.0, 0.0)
+        want2, want2_counts = orc.trace(flat, other, 1)
+        assert want2_counts == [n - 1]
+        ds2 = DeviceScene(snap)
+        for _ in range(2):
+            ds2.trace(dev(rays), 1)
+        got2, counts2 = ds2.trace(dev(other), 1)
+        assert ds2.telemetry()["speculation_misses"] == 1 and counts2 == want2_counts
+        helpers.assert_frames_match(got2.cpu().numpy().T, want2, what=f"ray {victim} misses")
+        ds2.close()
+    ds.close()
+
+
 def test_dense_mode_hints_across_limits_flags_and_sizes():
     """Hints survive what may change between two traces of one scene object: generation limit, the
     keep-absorbed flag, the ray count, a first batch that is shorter than the trace."""
