@@ -48,8 +48,12 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--spinup-ms", type=float, default=60.0,
+                    help="untimed traces before the warmup steps until this much wall time has passed: a GPU "
+                         "that has been idle runs its first ~10 ms of work at lower clocks (measured: 7 %% on "
+                         "the kernel), which a short --steps/--warmup would otherwise be quoted on")
     ap.add_argument("--rays", type=int, default=RAYS_PER_GPU,
                     help="rays of the job (strong scaling) / per GPU (weak scaling)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
@@ -131,6 +135,11 @@ def main():
     def step():
         return scene.trace(rays_dev, limit, flags=args.flags, out=block)
 
+    spinup_steps = 0
+    t_spin = time.perf_counter()
+    while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+        step()
+        spinup_steps += 1
     for _ in range(args.warmup):
         rows, counts = step()
     torch.cuda.synchronize(device)
@@ -259,6 +268,7 @@ def main():
             # secondary metric of SURVEY.md section 8d: rays alive at generation entry x primitives
             "primitive_tests_per_s": ray_generations * len(snap.prims) * world / elapsed,
             "trace_flags": args.flags,
+            "spinup_steps_untimed": spinup_steps,
             "parallelism": f"ray data-parallel x{world} (contiguous id shards), no collective in the timed region",
         },
         "roofline": {

@@ -1549,6 +1549,17 @@ static int await_epoch(DeviceCopy* c, unsigned long long epoch, hipStream_t st) 
   return PRT_OK;
 }
 
+#ifdef PRT_HOST_PROFILE
+#include <time.h>
+static double g_hp[8]; static long g_hp_n;
+static inline double hp_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+#define HP(k) g_hp_t[k] = hp_now()
+static double g_hp_t[8];
+extern "C" void prt_debug_host_profile(double* out9) { for (int k = 0; k < 8; ++k) out9[k] = g_hp[k]; out9[8] = (double)g_hp_n; }
+#else
+#define HP(k)
+#endif
+
 static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int64_t n, int64_t ld,
                            int generation_limit, double ray_offset, double* rows_out,
                            int64_t rows_cap, int64_t* rows_per_generation, char* w, int flags,
@@ -1609,14 +1620,17 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
     int want = kGenerationBatch;
     if (g == 0 && s->last_generations > 0) want = std::min(s->last_generations, kMaxBatch);
     const int batch = std::min(want, generation_limit - g);
+    HP(1);
     rc = settle_timing(s, c);
     if (rc) return rc;
+    HP(2);
     const unsigned long long epoch = ++c->epoch;
     bool in_kernel_publish = publish_in_kernel;
 #ifdef PRT_EXPERIMENTS
     if (two_per_lane) in_kernel_publish = false;
 #endif
     HIP_TRY(hipEventRecord(c->ev0, st));
+    HP(3);
     for (int b = 0; b < batch; ++b) {
       const int gg = g + b;
       const double* src = (gg == 0) ? rays : buf[(gg - 1) & 1];
@@ -1642,6 +1656,7 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
                          tiles[(gg + 1) & 1], (double)(gg + 1), relaunch, ray_offset, keep_absorbed,
                          in_kernel_publish ? c->mirror_dev : (HostMirror*)nullptr, epoch, b,
                          b + 1 == batch ? 1 : 0, assume);
+      if (b == 0) HP(4);
     }
     HIP_TRY(hipEventRecord(c->ev1, st));
     c->timing_pending = true;
@@ -1651,8 +1666,10 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
                        generation_limit, tiles[0], (int64_t)blocks_for(n), n, test_stall,
                        in_kernel_publish ? (HostMirror*)nullptr : c->mirror_dev, epoch, g, batch + 1);
     HIP_TRY(hipGetLastError());
+    HP(5);
     rc = await_epoch(c, epoch, st);
     if (rc) return rc;
+    HP(6);
     const GenCtrl* host_gen = c->mirror->gen;
     s->stats[3] += batch;
     error = c->mirror->error;
@@ -1700,6 +1717,7 @@ extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64
                              int generation_limit, double ray_offset, double* rows_out,
                              int64_t rows_cap, int64_t* rows_per_generation, void* workspace,
                              int flags, void* stream) {
+  HP(0);
   DeviceCopy* c;
   int rc = on_device(s, device, &c);
   if (rc) return rc;
@@ -1749,6 +1767,11 @@ extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64
     rc64 = trace_unfused(s, c, rays, n, ld, generation_limit, ray_offset, rows_out, rows_cap,
                          rows_per_generation, (char*)workspace, flags, (hipStream_t)stream);
   }
+#ifdef PRT_HOST_PROFILE
+  HP(7);
+  for (int k = 1; k < 8; ++k) g_hp[k] += g_hp_t[k] - g_hp_t[0];
+  g_hp_n += 1;
+#endif
   return rc64;
 }
 

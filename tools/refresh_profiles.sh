@@ -12,16 +12,16 @@ cd $R
 (cd tools/ubench && make -s copy_f64 >/dev/null 2>&1)
 python3 bench.py > $out/bench.json 2> $out/bench.err
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $out/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace -- python3 $R/bench.py --no-cpu-baseline > $out/trace.log 2>&1
 for cfg in "config3 4000000" "config4 8000000" "config5 2000000"; do
   set -- $cfg
-  python3 $R/bench.py --workload $1 --rays $2 --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_$1.json 2>> $out/bench.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace_$1 -- python3 $R/bench.py --workload $1 --rays $2 --steps 5 --warmup 2 --no-cpu-baseline > $out/trace_$1.log 2>&1
+  python3 $R/bench.py --workload $1 --rays $2 --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_$1.json 2>> $out/bench.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace_$1 -- python3 $R/bench.py --workload $1 --rays $2 --steps 50 --warmup 5 --no-cpu-baseline > $out/trace_$1.log 2>&1
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o render -- python3 $R/tools/render_bench.py --width 640 8192 --cpu-pixels 20000 > $out/render.log 2>&1
 cd $R
 bash tools/traffic.sh > $out/traffic.log 2>&1
-bash tools/sq.sh gen python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+bash tools/sq.sh gen python3 $R/bench.py --steps 3 --warmup 1 --spinup-ms 0 --no-cpu-baseline > /dev/null 2>&1
 bash tools/sq.sh hit python3 $R/tools/hit_only.py 6 > /dev/null 2>&1
 python3 tools/sq.py gpurun_out/sq gen > $out/sq_counters.txt
 python3 tools/sq.py gpurun_out/sq hit >> $out/sq_counters.txt
