@@ -253,8 +253,14 @@ int prt_place_rows(int device, const double* staging, int64_t stride_rank, int64
  * _pyrayt.py:349-354), and reduce spot positions (y1, z1) and axis intercepts
  * x0 - x_tilt * y0 / y_tilt per group.  One pass over the block; out is (n_groups, 8) float64 on
  * the device: count, sum(y1 - py), sum(z1 - pz), sum((y1 - py)^2 + (z1 - pz)^2), sum(focus - pf),
- * sum((focus - pf)^2), sum(wavelength), sum(intensity), with pivots = (py, pz, pf) or NULL for 0.
- * surface / generation: NaN selects every row; rays_per_source <= 0: a single group. */
+ * sum((focus - pf)^2), sum(wavelength), sum(intensity), with pivots = DEVICE (n_groups, 3) float64, per
+ * group the (py, pz, pf) its rows are measured from (a second pass about the first pass's means gives
+ * well-conditioned second moments), or NULL for 0.
+ * surface / generation: NaN selects every row; rays_per_source <= 0: a single group.
+ * Every wave keeps the sums of the group it is in in registers (rows are ordered by id, so groups come
+ * in runs) and adds them to the output when the group changes; with few groups the waves spread
+ * those atomics over 64 copies of the output in a stream-ordered scratch block (hipMallocAsync) that
+ * a second kernel folds.  Stream-ordered; no host synchronisation. */
 int prt_frame_reduce(int device, const double* rows, int64_t ld, int64_t n_rows, double surface,
                      double generation, double rays_per_source, int n_groups, const double* pivots,
                      double* out, void* stream);

@@ -77,11 +77,14 @@ class DeviceFrame:
         dev = rows.device
         out = torch.empty((n_groups, 8), dtype=torch.float64, device=dev)
         nan = float("nan")
-        piv = (ctypes.c_double * 3)(*pivots) if pivots is not None else None
+        piv = None
+        if pivots is not None:  # (n_groups, 3) on the device: what each group's rows are measured from
+            piv = torch.from_numpy(np.ascontiguousarray(pivots, dtype=np.float64).reshape(n_groups, 3)).to(dev)
         engine._check(engine.library().prt_frame_reduce(
             dev.index or 0, rows.data_ptr(), rows.stride(0), rows.shape[1],
             nan if surface is None else float(surface), nan if generation is None else float(generation),
-            float(rays_per_source or 0), n_groups, piv, out.data_ptr(), engine._stream_ptr(torch, dev)))
+            float(rays_per_source or 0), n_groups, piv.data_ptr() if piv is not None else None, out.data_ptr(),
+            engine._stream_ptr(torch, dev)))
         return out.cpu().numpy()
 
     def group_stats(self, surface=None, generation=None, rays_per_source=None, n_groups=None):
@@ -103,16 +106,16 @@ class DeviceFrame:
         first = self._reduce(surface, generation, rays_per_source, n_groups, None)
         count = first[:, 0]
         safe = np.where(count > 0, count, 1.0)
-        # one pivot for the whole pass (the kernel takes three scalars): the overall means
-        total = max(count.sum(), 1.0)
-        pivots = (first[:, 1].sum() / total, first[:, 2].sum() / total, first[:, 4].sum() / total)
+        # second pass about every group's own means of the first: the second moments are then sums of
+        # squared deviations, not differences of large numbers (coincident points give exactly zero)
+        pivots = np.stack([first[:, 1] / safe, first[:, 2] / safe, first[:, 4] / safe], axis=1)
         second = self._reduce(surface, generation, rays_per_source, n_groups, pivots)
         dy, dz, df = second[:, 1] / safe, second[:, 2] / safe, second[:, 4] / safe
         var_r = np.maximum(second[:, 3] / safe - dy ** 2 - dz ** 2, 0.0)
         var_f = np.maximum(second[:, 5] / safe - df ** 2, 0.0)
         frame = pd.DataFrame({
-            "count": count.astype(np.int64), "y": pivots[0] + dy, "z": pivots[1] + dz,
-            "rms_radius": np.sqrt(var_r), "focus": pivots[2] + df, "focus_std": np.sqrt(var_f),
+            "count": count.astype(np.int64), "y": pivots[:, 0] + dy, "z": pivots[:, 1] + dz,
+            "rms_radius": np.sqrt(var_r), "focus": pivots[:, 2] + df, "focus_std": np.sqrt(var_f),
             "wavelength": second[:, 6] / safe, "intensity": second[:, 7] / safe,
         })
         frame.index.name = "source_id"
