@@ -504,20 +504,9 @@ __device__ __forceinline__ unsigned long long tile_load(unsigned long long* p) {
 #ifndef PRT_LOOKBACK_LANES
 #define PRT_LOOKBACK_LANES 32  // words inspected per poll: polls are fabric traffic; 16-32 measured best (64: +1-2 %, 8: +7 %)
 #endif
-// The first poll of a tile's look-back, issued right after its aggregate is published and consumed
-// only after the shading: a round trip to the fabric hidden behind useful work.  Status words only
-// move forward (invalid -> aggregate -> prefix), so an older snapshot is still a valid one.
-__device__ __forceinline__ unsigned long long lookback_early(unsigned long long* state, int tile) {
-  const int lane = threadIdx.x & 63;
-  const int idx = tile - 1 - lane;
-  unsigned long long w = tile_pack(TILE_PREFIX, 0, 0);
-  if (idx >= 0) w = lane < PRT_LOOKBACK_LANES ? tile_load(state + idx) : TILE_INVALID;
-  return w;
-}
-
 __device__ __forceinline__ bool lookback(unsigned long long* state, int tile, unsigned agg_live,
                                          unsigned agg_carry, unsigned& excl_live,
-                                         unsigned& excl_carry, unsigned long long early = ~0ull) {
+                                         unsigned& excl_carry) {
   // One poll fetches PRT_LOOKBACK_WINDOWS x 64 predecessor words (lane l: tiles base - l, base - 64 - l,
   // ...), all loads in flight together: a poll is a round trip to the fabric (~1 us under load, the
   // words are device-scope), and the nearest inclusive prefix is typically 40-130 tiles back
@@ -534,10 +523,6 @@ __device__ __forceinline__ bool lookback(unsigned long long* state, int tile, un
       const int idx = base - 64 * k - lane;
       w[k] = tile_pack(TILE_PREFIX, 0, 0);  // before tile 0: empty prefix
       if (idx >= 0) w[k] = lane < PRT_LOOKBACK_LANES ? tile_load(state + idx) : TILE_INVALID;
-    }
-    if (early != ~0ull) {  // the first window was fetched before the shading (lookback_early)
-      w[0] = early;
-      early = ~0ull;
     }
     bool closed = false, stalled = false;
     int consumed = 0;
@@ -700,13 +685,6 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   const int tile = blockIdx.x;
   const int64_t n = gen[g].n_in;
   if ((int64_t)tile * PRT_BLOCK >= n) return;  // uniform per workgroup; never a predecessor
-#ifdef PRT_STAGGER
-  // experiment: de-phase the workgroups that start together (co-resident ones are 256 apart)
-  if (blockIdx.x < 1024) {
-    const int steps = (blockIdx.x >> 8) * PRT_STAGGER;
-    for (int k = 0; k < steps; ++k) __builtin_amdgcn_s_sleep(127);
-  }
-#endif
   // A tile that sees an error raised earlier does no work but MUST still publish its (empty)
   // aggregate: tiles behind it may already be waiting on it.
   const bool failed = ctrl->error != 0;
@@ -803,10 +781,6 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   } else if (threadIdx.x == 0 && tile > 0) {
     tile_store(tiles_cur + tile, tile_pack(TILE_AGGREGATE, agg_live, agg_carry));
   }
-  unsigned long long early = ~0ull;
-#ifdef PRT_LOOKBACK_EARLY
-  if (wave == 0) early = lookback_early(tiles_cur, tile);
-#endif
   // Shade BEFORE asking where the results go: the predecessors get this long to publish their
   // aggregates, so the look-back below mostly finds them ready instead of waiting.
   // Record columns that are known before the shading (metadata, segment start) are parked in
@@ -836,7 +810,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     e_live = (unsigned)tile * PRT_BLOCK; e_carry = (unsigned)tile * PRT_BLOCK;
     if (lane == 0) tile_store(tiles_cur + tile, tile_pack(TILE_PREFIX, e_live + agg_live, e_carry + agg_carry));
 #else
-    bool ok = lookback(tiles_cur, tile, agg_live, agg_carry, e_live, e_carry, early);
+    bool ok = lookback(tiles_cur, tile, agg_live, agg_carry, e_live, e_carry);
 #endif
     if (ctrl->pad == 1 && tile == 3) ok = false;  // test hook: pretend the spin expired
     if (!ok && lane == 0) atomicExch(&ctrl->error, PRT_ERR_STALL);
@@ -908,112 +882,6 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   STAMP(7);
 }
 
-#ifdef PRT_EXPERIMENTS  // measured slower than k_generation; not part of the product build
-// Two rays per lane.  A wave's lifetime in k_generation is mostly latency that does not depend
-// on how much arithmetic it carries (step fetches, uniform branches, barriers, the look-back, the
-// load / store round trips) and the VALUs idle about half the time, so a lane that owns two
-// independent rays amortises all of that over twice the work: a tile is 512 rays (ray slot 0:
-// i = 512*tile + tid, slot 1: i + 256), every program step is fetched once and applied to both.
-#ifndef PRT_GEN2_WAVES
-#define PRT_GEN2_WAVES 3
-#endif
-__global__ void __launch_bounds__(PRT_BLOCK, PRT_GEN2_WAVES)
-k_generation2(SceneDev scene, const double* __restrict__ rays, int64_t ld, double* __restrict__ next,
-              int64_t ld_next, double* __restrict__ rows, int64_t ld_rows, FusedCtrl* __restrict__ ctrl,
-              GenCtrl* __restrict__ gen, int g, unsigned long long* __restrict__ tiles_cur,
-              unsigned long long* __restrict__ tiles_next, double next_generation, int relaunch,
-              double ray_offset, int keep_absorbed) {
-  constexpr int R = 2;
-  constexpr int TILE = R * PRT_BLOCK;
-  __shared__ int s_wave_live[R][4], s_wave_carry[R][4];
-  __shared__ unsigned s_excl[2];
-  const int tile = blockIdx.x;
-  const int64_t n = gen[g].n_in;
-  if ((int64_t)tile * TILE >= n) return;  // uniform per workgroup; never a predecessor
-  const bool failed = ctrl->error != 0;   // still publishes its (empty) aggregate below
-  const int64_t row_base = gen[g].row_base;
-  if (threadIdx.x == 0) tiles_next[tile] = TILE_INVALID;
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int64_t idx[R];
-  Ray8 r[R];
-  double t[R];
-  int prim[R];
-  bool live[R], carry[R];
-#pragma unroll
-  for (int k = 0; k < R; ++k) {
-    idx[k] = (int64_t)tile * TILE + k * PRT_BLOCK + threadIdx.x;
-    r[k] = Ray8{0, 0, 0, 1, 0, 0, 0, 0};
-    if (idx[k] < n && !failed) r[k] = load_ray8(rays, ld, idx[k]);
-  }
-  nearest_hit_n<R>(scene.code, scene.n_instr, r, scene.lds_slots, t, prim);
-  int live_rank[R], carry_rank[R];
-#pragma unroll
-  for (int k = 0; k < R; ++k) {
-    const bool valid = idx[k] < n && !failed;
-    live[k] = valid && is_live(r[k], prim[k]);
-    carry[k] = live[k] && (keep_absorbed || scene.prims[prim[k]].mat_kind != MAT_ABSORBER);
-    const unsigned long long m_live = __ballot(live[k]), m_carry = __ballot(carry[k]);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    live_rank[k] = __popcll(m_live & below);
-    carry_rank[k] = __popcll(m_carry & below);
-    if (lane == 0) {
-      s_wave_live[k][wave] = __popcll(m_live);
-      s_wave_carry[k][wave] = __popcll(m_carry);
-    }
-  }
-  __syncthreads();
-  // order inside the tile: all of ray slot 0 (ids tile*512 ..+255), then slot 1
-  unsigned agg_live = 0, agg_carry = 0;
-#pragma unroll
-  for (int k = 0; k < R; ++k) {
-    live_rank[k] += agg_live;
-    carry_rank[k] += agg_carry;
-    for (int w = 0; w < PRT_BLOCK / 64; ++w) {
-      if (w < wave) { live_rank[k] += s_wave_live[k][w]; carry_rank[k] += s_wave_carry[k][w]; }
-      agg_live += s_wave_live[k][w];
-      agg_carry += s_wave_carry[k][w];
-    }
-  }
-  if (threadIdx.x == 0 && tile > 0)
-    tile_store(tiles_cur + tile, tile_pack(TILE_AGGREGATE, agg_live, agg_carry));
-  // shade both rays before asking where the results go
-  Shaded sh[R];
-#pragma unroll
-  for (int k = 0; k < R; ++k) {
-    sh[k].ok = true;
-    if (live[k]) sh[k] = interact_compute(scene, load_meta(rays, ld, idx[k]), r[k], t[k], prim[k]);
-  }
-  if (wave == 0) {
-    unsigned e_live, e_carry;
-    const bool ok = lookback(tiles_cur, tile, agg_live, agg_carry, e_live, e_carry);
-    if (!ok && lane == 0) atomicExch(&ctrl->error, PRT_ERR_STALL);
-    if (lane == 0) { s_excl[0] = e_live; s_excl[1] = e_carry; }
-  }
-  __syncthreads();
-  const int64_t excl_live = s_excl[0], excl_carry = s_excl[1];
-  const int64_t last_tile = (n - 1) / TILE;
-  if (tile == last_tile && threadIdx.x == 0) {
-    const int64_t total_live = excl_live + agg_live, total_carry = excl_carry + agg_carry;
-    gen[g].n_live = total_live;
-    gen[g].n_carry = total_carry;
-    gen[g + 1].n_in = (total_live == 0) ? 0 : total_carry;
-    gen[g + 1].row_base = row_base + total_live;
-  }
-  if (row_base + excl_live + agg_live > ld_rows) {  // uniform per workgroup (ld_rows == rows_cap)
-    if (threadIdx.x == 0) atomicExch(&ctrl->error, PRT_ERR_ROWS_CAP);
-    return;
-  }
-#pragma unroll
-  for (int k = 0; k < R; ++k) {
-    if (!live[k]) continue;
-    interact_store(sh[k], r[k], carry[k], row_base + excl_live + live_rank[k],
-                   excl_carry + carry_rank[k], next, ld_next, rows, ld_rows, next_generation,
-                   relaunch, ray_offset);
-    if (!sh[k].ok) atomicExch(&ctrl->error, PRT_ERR_UNTRACABLE);
-  }
-}
-#endif  // PRT_EXPERIMENTS
 
 // start of a fused trace: clear the control slots and tile buffer 0
 __global__ void k_fused_init(FusedCtrl* ctrl, GenCtrl* gen, int n_gen_slots,
@@ -1149,9 +1017,6 @@ static int raise_lds_limits() {
   HIP_TRY(hipFuncSetAttribute((const void*)k_hit_lanes<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_generation<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_generation<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
-#ifdef PRT_EXPERIMENTS
-  HIP_TRY(hipFuncSetAttribute((const void*)k_generation2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
-#endif
   HIP_TRY(hipFuncSetAttribute((const void*)k_intersect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   return PRT_OK;
 }
@@ -1591,10 +1456,6 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
 
   size_t lds_pad = 0;  // experiment: PRT_LDS_PAD=<bytes> lowers occupancy without touching the code
   if (const char* pad_env = getenv("PRT_LDS_PAD")) lds_pad = (size_t)atol(pad_env);
-#ifdef PRT_EXPERIMENTS
-  const char* rpl_env = getenv("PRT_RAYS_PER_LANE");
-  const bool two_per_lane = rpl_env && rpl_env[0] == '2' && 2 * lds <= kMaxLdsBytes;
-#endif
   const bool culls = count_steps(s->trace_program.code, I_BOX) > 0;
   // the generation kernels tell the host themselves unless an error can still be raised after the
   // last tile has its totals (only PRT_ERR_UNTRACABLE, at store time) or an experiment kernel runs
@@ -1626,9 +1487,6 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
     HP(2);
     const unsigned long long epoch = ++c->epoch;
     bool in_kernel_publish = publish_in_kernel;
-#ifdef PRT_EXPERIMENTS
-    if (two_per_lane) in_kernel_publish = false;
-#endif
     HIP_TRY(hipEventRecord(c->ev0, st));
     HP(3);
     for (int b = 0; b < batch; ++b) {
@@ -1636,15 +1494,6 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
       const double* src = (gg == 0) ? rays : buf[(gg - 1) & 1];
       const int64_t src_ld = (gg == 0) ? ld : n;
       const int relaunch = (gg + 1 != generation_limit) ? 1 : 0;
-#ifdef PRT_EXPERIMENTS
-      if (two_per_lane) {
-        const unsigned grid2 = (unsigned)((bound + 2 * PRT_BLOCK - 1) / (2 * PRT_BLOCK));
-        hipLaunchKernelGGL(k_generation2, dim3(grid2), dim3(PRT_BLOCK), 2 * lds, st, sd, src, src_ld,
-                           buf[gg & 1], n, rows_out, rows_cap, ctrl, gen, gg, tiles[gg & 1],
-                           tiles[(gg + 1) & 1], (double)(gg + 1), relaunch, ray_offset, keep_absorbed);
-        continue;
-      }
-#endif
       // dense-mode hint of the previous trace for this generation (the kernel reads the generation's
       // ray count on the device and checks the assumption tile by tile)
       int assume = 0;

@@ -509,6 +509,7 @@ def test_device_frame_selections_match_pandas():
     ("config3", (4_000_000,), 10),          # Cooke triplet, 12 primitives, 4M rays
     ("config4", (1_000_000,), 10),          # prism, 8 wavelengths x 1M rays
     ("config5", (2_000_000,), 10),          # 16M rays / 8 GPUs
+    ("config5", (16_000_000,), 10),         # ... and all 16M of them on one GPU (the largest BASELINE job)
 ])
 def test_baseline_configs_at_full_size(name, args, limit):
     from oracle import c_oracle
