@@ -16,6 +16,12 @@
  * prt_scene_create() and never retains caller pointers beyond a call (stream-ordered work
  * excepted: buffers must stay alive until the stream has drained).
  * Errors: 0 = OK, negative = error; prt_last_error() returns a thread-local message.
+ * Threads: the stateless entry points (prt_reflect ... prt_generate_rays, prt_place_rows,
+ * prt_frame_reduce) may be called from any thread; a prt_scene (like the reference's RayTracer,
+ * _pyrayt.py:227-246, which holds its state between trace() calls) carries per-scene state between
+ * calls -- trace statistics, the dense-mode hints, the host mirror the kernels publish to -- and
+ * serves one caller at a time.  Concurrent traces use one scene object per host thread
+ * (tools/two_stream_probe.py); a prt_comm likewise belongs to one thread.
  */
 #ifndef PRT_H
 #define PRT_H
