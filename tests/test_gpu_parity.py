@@ -642,6 +642,15 @@ def test_dense_mode_hints_across_limits_flags_and_sizes():
         keep = want[:, 0] < limit                   # rows of the first `limit` generations
         helpers.assert_frames_match(got, want[keep], what=f"config3 limit {limit} flags {flags}")
     assert ds.telemetry()["speculation_misses"] == 0 and ds.telemetry()["dense_launches"] > 0
+    # a record block that is too small is reported from the dense generations as from the others
+    # (the wrapper then grows it and repeats), and an exact-fit block works
+    total = want.shape[0]
+    for cap in (rays.shape[1] * 2, total, total - 1):
+        rows, counts = ds.trace(rays, 10, rows_cap=cap)
+        helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"config3 rows_cap {cap}")
+    block = torch.empty((15, total - 1), dtype=torch.float64, device="cuda:0")
+    with pytest.raises(RuntimeError, match="rows_cap"):
+        ds.trace(rays, 10, out=block)              # a caller's block is never replaced
     half = dev(np.ascontiguousarray(fx["rays0"][:, ::2]))
     rows, _ = ds.trace(half, 10)                   # another ray count: no hints, then its own
     rows2, _ = ds.trace(half, 10)
