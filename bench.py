@@ -18,7 +18,9 @@ kernel inside the library, pyrayt_amd/csrc/prt_gather.hpp) is timed separately a
 region and reported under "gather" and "value_with_gather" -- it is not part of `value`.
 
 rank 0 prints ONE JSON line.  `roofline` is for the generation kernel(s): algorithmic bytes
-(328 B per ray alive at generation entry) over the HIP-event time of
+(state read + record row + state written per ray and generation: 80 + 120 + 80 B with the state rows
+the generations carry between them, 104 B for the caller's 13-row set in generation 0; SURVEY.md
+section 8d's figure with all 13 rows carried is 328 B) over the HIP-event time of
 those launches measured inside the library on the launch stream.  `cpu_baseline` is the numpy
 oracle (a port of the reference's path, validated against it) timed on this host, rank 0, N=1.
 """
@@ -41,7 +43,11 @@ WORKLOADS = {
 }
 RAYS_PER_GPU = 1_000_000
 GENERATION_LIMIT = 10
-BYTES_PER_RAY_GENERATION = 328  # 104 B state read + 104 B state write + 120 B record row
+# 80 B state read + 80 B state write + 120 B record row: between generations the state goes without its
+# rows 3, 7, 8 (w = 1, w = 0, generation number: the same in every ray, include/prt.h "compact state");
+# generation 0 reads the caller's 13 rows (104 B).  With all 13 rows in use it would be 104 + 104 + 120 = 328.
+STATE_BYTES, STATE_BYTES_FULL, ROW_BYTES = 80, 104, 120
+BYTES_PER_RAY_GENERATION = 2 * STATE_BYTES + ROW_BYTES
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -229,10 +235,15 @@ def main():
         return
 
     value = total_rows_per_step * args.steps / elapsed
-    # algorithmic bytes: 104 B state read per ray alive at generation entry,
-    # 120 B record row per recorded ray, 104 B next state per ray that goes on; = 328 B per
-    # ray-generation when every ray is recorded and goes on
-    algorithmic_bytes = 104.0 * ray_generations + 120.0 * rows_recorded + 104.0 * rays_carried
+    # algorithmic bytes: the state of every ray alive at generation entry is read
+    # (104 B from the caller's 13-row set in generation 0, 80 B afterwards), 120 B are written per
+    # recorded row and 80 B of next state per ray that goes on (SURVEY.md section 8d counts 328 B per
+    # ray-generation with all 13 rows carried; a scene that fell back to that form is counted that way)
+    full_rows = scene.telemetry()["full_rows_fallbacks"] > 0 or os.environ.get("PRT_FULL_ROWS") is not None
+    state = STATE_BYTES_FULL if full_rows else STATE_BYTES
+    first_generation = float(n) * args.steps
+    algorithmic_bytes = (STATE_BYTES_FULL * first_generation + state * (ray_generations - first_generation) +
+                         ROW_BYTES * rows_recorded + state * rays_carried)
     achieved = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     traffic = None
     traffic_file = os.path.join(ROOT, "profiles", "r2", "traffic.json")
@@ -285,7 +296,8 @@ def main():
             "avg_launch_ms": kernel_ms / launches if launches else 0,
             "launches_per_step": launches / args.steps,
             "kernel_ms_per_step": kernel_ms / args.steps,
-            "bytes_per_ray_generation_if_all_survive": BYTES_PER_RAY_GENERATION,
+            "bytes_per_ray_generation_if_all_survive": 2 * state + ROW_BYTES,
+            "state_rows": "all 13" if full_rows else "10 of 13 between generations (w rows and generation row implied)",
         },
         "end_to_end_trace": end_to_end,
     }

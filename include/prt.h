@@ -286,11 +286,18 @@ int prt_frame_reduce(int device, const double* rows, int64_t ld, int64_t n_rows,
 int prt_trace_stats(const prt_scene* scene, double* out8);
 /* counters of this scene since it was created: out4 = { traces re-run on the three-kernel path after a
  * look-back gave up, traces repeated because a dense-mode hint did not hold, generation launches made in
- * dense mode, 0 }.  Dense mode: a generation in which the previous trace of the same scene and ray count
+ * dense mode, traces repeated with all 13 state rows (see below; at most one per scene) }.  Dense mode: a generation in which the previous trace of the same scene and ray count
  * recorded every ray and carried all or none of them on is launched on the assumption that it will
  * again -- every tile then knows its output position without the look-back; each tile checks the
  * assumption on its own counts and a miss repeats the trace without assumptions (results are exact
- * either way; PRT_NO_HINTS=1 in the environment turns the hints off). */
+ * either way; PRT_NO_HINTS=1 in the environment turns the hints off).
+ * Compact state: between the generations of a trace the ray state goes without its rows 3, 7 and 8
+ * (origin w, direction w, generation): in a ray set that starts like RaySet's defaults
+ * (pyrayt/_pyrayt.py:29-36: w = 1 / 0, generation 0) they hold 1, +0 and the generation's number in every
+ * generation, bit for bit, so they are neither written nor read (24 of 104 B each way).  Generation 0
+ * checks the caller's rows, every generation checks the rays it hands on; the first ray that differs
+ * makes the library repeat the trace with all rows and keep doing so for this scene (PRT_FULL_ROWS=1
+ * forces that form). */
 int prt_trace_telemetry(const prt_scene* scene, int64_t* out4);
 
 /* ---- renderers (second consumer of the intersect path) ----------

@@ -1014,7 +1014,10 @@ __device__ __forceinline__ void run_step(const DevInstr* in, const Ray8& ray, co
 // step record is fetched once (one batch of scalar loads) and applied to the lane's R rays,
 // whose arithmetic is independent and interleaves.
 // CULL: the program may contain I_BOX steps (compiled out of the kernels that never see one).
-template <int R, bool RENDER = false, bool CULL = true>
+// ANY_W: the rays may carry an origin w other than 1 (the object-space origin is then M^-1 (o, w), not
+// the image of the world point o: _pyrayt.py / world_objects.py:360-383 multiply the translation by w),
+// which the cull steps' world-space argument does not cover: such a ray takes every component.
+template <int R, bool RENDER = false, bool CULL = true, bool ANY_W = true>
 __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code, int n_instr,
                                               const Ray8 (&ray)[R], int slots, double (&best_t)[R],
                                               int (&best_prim)[R]) {
@@ -1039,7 +1042,7 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
     if (CULL && !RENDER && step.kind == I_BOX) {
       bool wanted = false;
 #pragma unroll
-      for (int k = 0; k < R; ++k) wanted = wanted || may_reach(step.data, ray[k], best_t[k]);
+      for (int k = 0; k < R; ++k) wanted = wanted || may_reach(step.data, ray[k], best_t[k]) || (ANY_W && ray[k].ow != 1.0);
       PRT_COUNT(2, true);
       PRT_COUNT(3, !wanted);
       if (__ballot(wanted) == 0ull) pc += step.a0;  // no lane of the wave needs this component
@@ -1070,14 +1073,14 @@ __device__ __forceinline__ void component_candidate(const DevInstr* code, int fi
       chain_step(reinterpret_cast<const DevChain*>(in), in->a0, ray, t, prim);
       pc += CHAIN_SLOTS - 1;
     } else if (kind == I_BOX) {
-      if (!may_reach(in->data, ray, PRT_INF)) return;  // the cull step leads its component
+      if (ray.ow == 1.0 && !may_reach(in->data, ray, PRT_INF)) return;  // the cull step leads its component
     } else {
       run_step<false>(in, ray, lists, ra, rb, t, prim);
     }
   }
 }
 
-template <bool RENDER = false, bool CULL = true>
+template <bool RENDER = false, bool CULL = true, bool ANY_W = true>
 __device__ __forceinline__ void nearest_hit(const DevPrim* __restrict__ prims,
                                             const DevInstr* __restrict__ code, int n_instr,
                                             const Ray8& ray, const LaneLists& lists, double& best_t,
@@ -1086,7 +1089,7 @@ __device__ __forceinline__ void nearest_hit(const DevPrim* __restrict__ prims,
   const Ray8 rays1[1] = {ray};
   double t1[1];
   int p1[1];
-  nearest_hit_n<1, RENDER, CULL>(code, n_instr, rays1, lists.total, t1, p1);
+  nearest_hit_n<1, RENDER, CULL, ANY_W>(code, n_instr, rays1, lists.total, t1, p1);
   best_t = t1[0];
   best_prim = p1[0];
 }

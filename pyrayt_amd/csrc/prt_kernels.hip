@@ -471,6 +471,7 @@ static_assert(offsetof(HostMirror, gen) == 64, "mirror header");
 
 #define PRT_ERR_SPECULATION (-101) /* internal: a generation launched in dense mode was not dense -> host re-runs without hints */
 #define PRT_ERR_STALL (-100) /* internal: look-back gave up -> host falls back to the unfused path */
+#define PRT_ERR_FULL_ROWS (-102) /* internal: a ray set needs the rows the compact form leaves out -> host re-runs with all 13 */
 
 // tile status word for the decoupled look-back: [63:62] status, [61:31] live, [30:0] carried.
 // One naturally aligned 8-byte word written by one agent-scope store: payload and flag cannot
@@ -619,7 +620,16 @@ __device__ __forceinline__ int64_t uniform64(int64_t v) {
 
 // interact_store through buffer descriptors: `rec` / `nxt` already point at this workgroup's first
 // column of row 0, lane offsets are rank * 8 bytes
-__device__ __forceinline__ void interact_store_rows(const Shaded& s, const Ray8& r, bool carry, unsigned row_bytes,
+// homogeneous coordinates of a well-formed ray: origin w exactly 1, direction w exactly +0 (bit for bit:
+// a -0 is kept apart because it can decide the sign of a zero sum in the object-space transform)
+__device__ __forceinline__ bool w_is_trivial(double ow, double dw) {
+  return ow == 1.0 && __double_as_longlong(dw) == 0ll;
+}
+
+// compact: the next state goes without its rows 3, 7 and 8 (see k_generation); returns false if a ray
+// that goes on does not have the values the reader will assume for them
+template <bool COMPACT>
+__device__ __forceinline__ bool interact_store_rows(const Shaded& s, const Ray8& r, bool carry, unsigned row_bytes,
                                                     unsigned next_bytes, double* __restrict__ nxt, int64_t ld_next,
                                                     double* __restrict__ rec, int64_t ld_rows,
                                                     double next_generation, int relaunch, double ray_offset) {
@@ -647,17 +657,21 @@ __device__ __forceinline__ void interact_store_rows(const Shaded& s, const Ray8&
     row_store<PRT_STORE_AUX_NEXT>(nxt + 0 * ld_next, next_bytes, qx);
     row_store<PRT_STORE_AUX_NEXT>(nxt + 1 * ld_next, next_bytes, qy);
     row_store<PRT_STORE_AUX_NEXT>(nxt + 2 * ld_next, next_bytes, qz);
-    row_store<PRT_STORE_AUX_NEXT>(nxt + 3 * ld_next, next_bytes, qw);
+    if (!COMPACT) row_store<PRT_STORE_AUX_NEXT>(nxt + 3 * ld_next, next_bytes, qw);
     row_store<PRT_STORE_AUX_NEXT>(nxt + 4 * ld_next, next_bytes, s.dx);
     row_store<PRT_STORE_AUX_NEXT>(nxt + 5 * ld_next, next_bytes, s.dy);
     row_store<PRT_STORE_AUX_NEXT>(nxt + 6 * ld_next, next_bytes, s.dz);
-    row_store<PRT_STORE_AUX_NEXT>(nxt + 7 * ld_next, next_bytes, s.dw);
-    row_store<PRT_STORE_AUX_NEXT>(nxt + 8 * ld_next, next_bytes, next_generation);
+    if (!COMPACT) {
+      row_store<PRT_STORE_AUX_NEXT>(nxt + 7 * ld_next, next_bytes, s.dw);
+      row_store<PRT_STORE_AUX_NEXT>(nxt + 8 * ld_next, next_bytes, next_generation);
+    }
     row_store<PRT_STORE_AUX_NEXT>(nxt + 9 * ld_next, next_bytes, s.intensity);
     row_store<PRT_STORE_AUX_NEXT>(nxt + 10 * ld_next, next_bytes, s.wavelength);
     row_store<PRT_STORE_AUX_NEXT>(nxt + 11 * ld_next, next_bytes, s.index);
     row_store<PRT_STORE_AUX_NEXT>(nxt + 12 * ld_next, next_bytes, s.id);
+    if (COMPACT && relaunch) return w_is_trivial(qw, s.dw);  // (!relaunch: nobody reads this state)
   }
+  return true;
 }
 
 // Register-allocated for 5 waves per SIMD (96 VGPRs, no spills -- possible because the record
@@ -670,7 +684,7 @@ __device__ __forceinline__ void interact_store_rows(const Shaded& s, const Ray8&
 #endif
 // CULL = the trace program carries component cull steps (scenes of three or more components);
 // the instantiation without them is the one the register budget above was tuned for.
-template <bool CULL>
+template <bool CULL, bool COMPACT>
 __global__ void __launch_bounds__(PRT_BLOCK, PRT_GEN_WAVES)
 k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double* __restrict__ next,
              int64_t ld_next, double* __restrict__ rows, int64_t ld_rows, FusedCtrl* __restrict__ ctrl,
@@ -704,18 +718,44 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     // LDS (nothing needs them before the shading), so no second trip to HBM after the hit phase
     const double* tile_rays = rays + (int64_t)tile * PRT_BLOCK;
     const unsigned lane_bytes = threadIdx.x * 8u;
+    // Compact state (the default; a scene falls back to all 13 rows the first time a ray set needs
+    // them): between the generations of a trace the homogeneous w rows (3, 7) and the generation row
+    // (8) hold what every well-formed ray set holds there -- 1, +0 and the generation's number -- so
+    // the generations neither write nor read them: 24 B of the 104 B state, each way.  Generation 0
+    // reads the caller's 13 rows and checks; every generation checks the rays it hands on; a ray
+    // that differs raises PRT_ERR_FULL_ROWS and the host repeats the trace with all rows in use.
+    // (COMPACT is a template parameter: the form with all 13 rows is the kernel it was before.)
     r.ox = row_load(tile_rays + 0 * ld, lane_bytes); r.oy = row_load(tile_rays + 1 * ld, lane_bytes);
-    r.oz = row_load(tile_rays + 2 * ld, lane_bytes); r.ow = row_load(tile_rays + 3 * ld, lane_bytes);
+    r.oz = row_load(tile_rays + 2 * ld, lane_bytes);
+    if (!COMPACT) r.ow = row_load(tile_rays + 3 * ld, lane_bytes);
     r.dx = row_load(tile_rays + 4 * ld, lane_bytes); r.dy = row_load(tile_rays + 5 * ld, lane_bytes);
-    r.dz = row_load(tile_rays + 6 * ld, lane_bytes); r.dw = row_load(tile_rays + 7 * ld, lane_bytes);
-    PARK(0) = row_load(tile_rays + 8 * ld, lane_bytes); PARK(1) = row_load(tile_rays + 9 * ld, lane_bytes);
+    r.dz = row_load(tile_rays + 6 * ld, lane_bytes);
+    if (!COMPACT) {
+      r.dw = row_load(tile_rays + 7 * ld, lane_bytes);
+      PARK(0) = row_load(tile_rays + 8 * ld, lane_bytes);
+    }
+    PARK(1) = row_load(tile_rays + 9 * ld, lane_bytes);
     PARK(2) = row_load(tile_rays + 10 * ld, lane_bytes); PARK(3) = row_load(tile_rays + 11 * ld, lane_bytes);
     PARK(4) = row_load(tile_rays + 12 * ld, lane_bytes);
+    if (COMPACT) {
+      if (g > 0) {  // uniform
+        r.ow = 1.0;
+        r.dw = 0.0;
+        PARK(0) = next_generation - 1.0;  // (small integers: exact)
+      } else {
+        r.ow = row_load(tile_rays + 3 * ld, lane_bytes);
+        r.dw = row_load(tile_rays + 7 * ld, lane_bytes);
+        const double generation = row_load(tile_rays + 8 * ld, lane_bytes);
+        PARK(0) = generation;
+        if (!(w_is_trivial(r.ow, r.dw) && generation == 0.0)) atomicExch(&ctrl->error, PRT_ERR_FULL_ROWS);
+      }
+    }
 #ifdef PRT_TIMING
     if (r.ox + r.oy + r.oz + r.ow + r.dx + r.dy + r.dz + r.dw == 1.2345e300) t = 0;  // force the wait here
     STAMP(1);
 #endif
-    nearest_hit<false, CULL>(scene.prims, scene.code, scene.n_instr, r, lists, t, prim);
+    // (COMPACT: every origin w is 1 -- assumed from generation 1 on, checked above in generation 0)
+    nearest_hit<false, CULL, !COMPACT>(scene.prims, scene.code, scene.n_instr, r, lists, t, prim);
     live = is_live(r, prim);
     // absorbed rays are recorded and dropped; which primitives absorb is a bit mask for the first 64
     // (one scalar test instead of a per-lane table lookup in HBM)
@@ -874,9 +914,10 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   interact_store(sh, r, carry, threadIdx.x, threadIdx.x, next, ld_next, rows, ld_rows,
                  next_generation, relaunch, ray_offset);
 #else
-  interact_store_rows(sh, r, carry, (unsigned)live_rank * 8u, (unsigned)carry_rank * 8u,
-                      next + uniform64(excl_carry), ld_next, rows + uniform64(row_base + excl_live), ld_rows,
-                      next_generation, relaunch, ray_offset);
+  if (!interact_store_rows<COMPACT>(sh, r, carry, (unsigned)live_rank * 8u, (unsigned)carry_rank * 8u,
+                                    next + uniform64(excl_carry), ld_next, rows + uniform64(row_base + excl_live),
+                                    ld_rows, next_generation, relaunch, ray_offset))
+    atomicExch(&ctrl->error, PRT_ERR_FULL_ROWS);
 #endif
   if (!sh.ok) atomicExch(&ctrl->error, PRT_ERR_UNTRACABLE);
   STAMP(7);
@@ -1015,8 +1056,10 @@ static int raise_lds_limits() {
   HIP_TRY(hipFuncSetAttribute((const void*)k_hit_lanes<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_hit_lanes<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_hit_lanes<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
-  HIP_TRY(hipFuncSetAttribute((const void*)k_generation<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
-  HIP_TRY(hipFuncSetAttribute((const void*)k_generation<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_generation<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_generation<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_generation<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_generation<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_intersect, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   return PRT_OK;
 }
@@ -1428,7 +1471,7 @@ extern "C" void prt_debug_host_profile(double* out9) { for (int k = 0; k < 8; ++
 static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int64_t n, int64_t ld,
                            int generation_limit, double ray_offset, double* rows_out,
                            int64_t rows_cap, int64_t* rows_per_generation, char* w, int flags,
-                           hipStream_t st, bool allow_hints) {
+                           hipStream_t st, bool allow_hints, bool compact) {
   const TraceLayout l = trace_layout(n);
   FusedCtrl* ctrl = (FusedCtrl*)(w + l.fctrl);
   GenCtrl* gen = (GenCtrl*)(w + l.gen);
@@ -1499,7 +1542,8 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
       int assume = 0;
       if (use_hints && gg < (int)s->hint_mode.size()) assume = s->hint_mode[gg];
       s->dense_launches += assume ? 1 : 0;
-      auto kernel = culls ? k_generation<true> : k_generation<false>;
+      auto kernel = compact ? (culls ? k_generation<true, true> : k_generation<false, true>)
+                            : (culls ? k_generation<true, false> : k_generation<false, false>);
       hipLaunchKernelGGL(kernel, dim3(blocks_for(bound)), dim3(PRT_BLOCK), lds + lds_pad, st, sd, src,
                          src_ld, buf[gg & 1], n, rows_out, rows_cap, ctrl, gen, gg, tiles[gg & 1],
                          tiles[(gg + 1) & 1], (double)(gg + 1), relaunch, ray_offset, keep_absorbed,
@@ -1547,7 +1591,7 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
     }
   }
 #endif
-  if (error == PRT_ERR_SPECULATION) return PRT_ERR_SPECULATION;
+  if (error == PRT_ERR_SPECULATION || error == PRT_ERR_FULL_ROWS) return error;
   if (error) return trace_error(error);
   s->last_generations = (int)s->stats[0];
   s->hint_n = n;
@@ -1586,15 +1630,27 @@ extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64
                          rows_per_generation, (char*)workspace, flags, (hipStream_t)stream);
   }
   s->stats[7] = PRT_VARIANT_FUSED;
-  int64_t rc64 = trace_fused(s, c, rays, n, ld, generation_limit, ray_offset, rows_out, rows_cap,
-                             rows_per_generation, (char*)workspace, flags, (hipStream_t)stream, true);
-  if (rc64 == PRT_ERR_SPECULATION) {
-    // a generation assumed dense was not (the rays or the scene changed since the hints were taken):
-    // nothing of this attempt is kept; run again without assumptions, which also renews the hints
-    s->speculation_misses += 1;
-    s->hint_misses_in_a_row = std::min(s->hint_misses_in_a_row + 1, 6);
-    s->hint_holdoff = 1 << s->hint_misses_in_a_row;
-    s->hint_n = -1;
+  int64_t rc64 = 0;
+  bool allow_hints = true;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    rc64 = trace_fused(s, c, rays, n, ld, generation_limit, ray_offset, rows_out, rows_cap, rows_per_generation,
+                       (char*)workspace, flags, (hipStream_t)stream, allow_hints,
+                       !s->full_rows && getenv("PRT_FULL_ROWS") == nullptr);
+    if (rc64 != PRT_ERR_SPECULATION && rc64 != PRT_ERR_FULL_ROWS) break;
+    if (rc64 == PRT_ERR_SPECULATION) {
+      // a generation assumed dense was not (the rays or the scene changed since the hints were taken):
+      // nothing of this attempt is kept; run again without assumptions, which also renews the hints
+      s->speculation_misses += 1;
+      s->hint_misses_in_a_row = std::min(s->hint_misses_in_a_row + 1, 6);
+      s->hint_holdoff = 1 << s->hint_misses_in_a_row;
+      s->hint_n = -1;
+      allow_hints = false;
+    } else {
+      // a ray needs the state rows the compact form leaves out (homogeneous w other than 1 / +0, or a
+      // ray set that does not start at generation 0): this scene traces with all 13 rows from now on
+      s->full_rows = true;
+      s->full_rows_fallbacks += 1;
+    }
     for (int g = 0; g < generation_limit; ++g) rows_per_generation[g] = 0;
     rc = settle_timing(s, c);
     if (rc) return rc;
@@ -1602,8 +1658,6 @@ extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64
     for (double& v : s->stats) v = 0;
     s->stats[6] = fallbacks;
     s->stats[7] = PRT_VARIANT_FUSED;
-    rc64 = trace_fused(s, c, rays, n, ld, generation_limit, ray_offset, rows_out, rows_cap,
-                       rows_per_generation, (char*)workspace, flags, (hipStream_t)stream, false);
   }
   if (rc64 == PRT_ERR_STALL) {  // never observed outside the test hook; see lookback()
     for (int g = 0; g < generation_limit; ++g) rows_per_generation[g] = 0;
@@ -1640,7 +1694,7 @@ extern "C" int prt_trace_telemetry(const prt_scene* s, int64_t* out4) {
   out4[0] = s->lookback_fallbacks;
   out4[1] = s->speculation_misses;
   out4[2] = s->dense_launches;
-  out4[3] = 0;
+  out4[3] = s->full_rows_fallbacks;
   return PRT_OK;
 }
 

@@ -76,6 +76,8 @@ struct prt_scene {
   int hint_keep_absorbed = 0;
   std::vector<char> hint_mode;  // per generation: 0 general, 1 every ray recorded and carried on, 2 recorded, none carried
   long speculation_misses = 0;  // traces that had to be repeated because a hint did not hold
+  bool full_rows = false;       // a ray set of this scene needed the state rows the compact form leaves out
+  long full_rows_fallbacks = 0; // traces that had to be repeated for that reason (at most one per scene)
   long dense_launches = 0;      // generation launches made in dense mode so far
   int hint_holdoff = 0;         // traces still to run without hints after a miss (doubles with every miss in a row)
   int hint_misses_in_a_row = 0;

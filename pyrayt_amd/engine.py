@@ -292,7 +292,7 @@ class DeviceScene:
         out = (ctypes.c_int64 * 4)()
         _check(library().prt_trace_telemetry(self.handle, out))
         return {"lookback_fallbacks": int(out[0]), "speculation_misses": int(out[1]),
-                "dense_launches": int(out[2])}
+                "dense_launches": int(out[2]), "full_rows_fallbacks": int(out[3])}
 
     # --- per-state entry points -----------------------------------------------------------------
     def propagate(self, rays):

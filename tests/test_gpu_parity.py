@@ -548,6 +548,70 @@ def test_baseline_configs_at_full_size(name, args, limit):
 
 
 # ---------------------------------------------------------------------------------------------
+# compact state: rows 3, 7, 8 of the ray state are not carried between generations while they hold
+# what RaySet's defaults put there; a ray set that differs anywhere must get all 13 rows
+# ---------------------------------------------------------------------------------------------
+def _odd_rays(kind, rays):
+    odd = rays.copy()
+    k = odd.shape[1] // 3
+    if kind == "origin_w":
+        odd[3, k] = 2.0
+    elif kind == "direction_w":
+        odd[7, k] = 1e-3
+    elif kind == "minus_zero_direction_w":
+        odd[7, k] = -0.0
+    elif kind == "generation_offset":
+        odd[8] = 5.0
+    elif kind == "one_generation":
+        odd[8, k] = 1.0
+    return odd
+
+
+@pytest.mark.parametrize("kind", ["origin_w", "direction_w", "minus_zero_direction_w", "generation_offset",
+                                  "one_generation"])
+def test_ray_sets_that_need_all_state_rows(kind):
+    from pyrayt_amd.engine import DeviceScene
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    CountedObject.reset_ids()
+    parts, rays = scenes.config3(scenes.product_api(), 20_000)
+    snap = SceneSnapshot(parts)
+    flat = helpers.flat_scene(snap)
+    ds = DeviceScene(snap)
+    good, good_counts = ds.trace(dev(rays), 10)
+    assert ds.telemetry()["full_rows_fallbacks"] == 0        # RaySet defaults: compact state
+    want_good, want_good_counts = orc.trace(flat, rays, 10)
+    assert good_counts == want_good_counts
+    helpers.assert_frames_match(good.cpu().numpy().T, want_good, what="config3 compact")
+    odd = _odd_rays(kind, rays)
+    want, want_counts = orc.trace(flat, odd, 10)
+    for turn in range(2):                                     # the repeat, then straight with all rows
+        rows, counts = ds.trace(dev(odd), 10)
+        assert counts == want_counts and ds.telemetry()["full_rows_fallbacks"] == 1, (kind, turn)
+        helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"{kind} turn {turn}")
+    again, _ = ds.trace(dev(rays), 10)                        # the scene stays on all rows: same frame
+    assert np.array_equal(again.cpu().numpy(), good.cpu().numpy())
+    ds.close()
+
+
+def test_compact_and_full_state_rows_give_the_same_frame(monkeypatch):
+    from pyrayt_amd.engine import DeviceScene
+
+    for name in ("scene_config2.npz", "scene_config3.npz", "scene_config5.npz", "scene_mirrors_and_stops.npz"):
+        fx = helpers.load(name)
+        rays, limit = dev(fx["rays0"]), int(fx["generation_limit"])
+        ds = device_scene(helpers.scene_of(fx))
+        compact, counts = ds.trace(rays, limit)
+        monkeypatch.setenv("PRT_FULL_ROWS", "1")
+        full, full_counts = ds.trace(rays, limit)
+        monkeypatch.delenv("PRT_FULL_ROWS")
+        assert counts == full_counts and np.array_equal(compact.cpu().numpy(), full.cpu().numpy(), equal_nan=True)
+        helpers.assert_frames_match(compact.cpu().numpy().T, fx["frame"], what=name)
+        ds.close()
+
+
+# ---------------------------------------------------------------------------------------------
 # dense-mode hints: a repeated trace launches the generations that were dense last time without the
 # look-back; a hint that does not hold must cost a repeat, never a wrong frame
 # ---------------------------------------------------------------------------------------------
