@@ -18,10 +18,10 @@ kernel inside the library, pyrayt_amd/csrc/prt_gather.hpp) is timed separately a
 region and reported under "gather" and "value_with_gather" -- it is not part of `value`.
 
 rank 0 prints ONE JSON line.  `roofline` is for the generation kernel(s): algorithmic bytes
-(state read + record row + state written per ray and generation: 80 + 120 + 80 B with the state rows
-the generations carry between them, 104 B for the caller's 13-row set in generation 0; SURVEY.md
-section 8d's figure with all 13 rows carried is 328 B) over the HIP-event time of
-those launches measured inside the library on the launch stream.  `cpu_baseline` is the numpy
+(328 B per ray alive at generation entry that is recorded and goes on) over the
+HIP-event time of those launches measured inside the library on the launch stream; the bytes the
+kernel actually moves (it carries 10 of the 13 state rows between generations) are reported next
+to it as `moved_bytes_per_launch` / `moved_frac`.  `cpu_baseline` is the numpy
 oracle (a port of the reference's path, validated against it) timed on this host, rank 0, N=1.
 """
 import argparse
@@ -43,11 +43,11 @@ WORKLOADS = {
 }
 RAYS_PER_GPU = 1_000_000
 GENERATION_LIMIT = 10
-# 80 B state read + 80 B state write + 120 B record row: between generations the state goes without its
-# rows 3, 7, 8 (w = 1, w = 0, generation number: the same in every ray, include/prt.h "compact state");
-# generation 0 reads the caller's 13 rows (104 B).  With all 13 rows in use it would be 104 + 104 + 120 = 328.
+BYTES_PER_RAY_GENERATION = 328  # 104 B state read + 104 B state write + 120 B record row
+# what the kernel moves: between generations the state goes without its rows 3, 7, 8 (w = 1, w = +0,
+# generation number: the same in every ray, include/prt.h "compact state"); generation 0 reads the
+# caller's 13 rows
 STATE_BYTES, STATE_BYTES_FULL, ROW_BYTES = 80, 104, 120
-BYTES_PER_RAY_GENERATION = 2 * STATE_BYTES + ROW_BYTES
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -235,15 +235,18 @@ def main():
         return
 
     value = total_rows_per_step * args.steps / elapsed
-    # algorithmic bytes: the state of every ray alive at generation entry is read
-    # (104 B from the caller's 13-row set in generation 0, 80 B afterwards), 120 B are written per
-    # recorded row and 80 B of next state per ray that goes on (SURVEY.md section 8d counts 328 B per
-    # ray-generation with all 13 rows carried; a scene that fell back to that form is counted that way)
+    # algorithmic bytes, SURVEY.md section 8d's per-unit figures (13-row state read 104 B, record row
+    # 120 B, 13-row next state 104 B; = 328 B per ray-generation when every ray is recorded and goes on),
+    # counted exactly: state read per ray alive at generation entry, row per recorded ray, next state
+    # per ray that goes on.  The kernel moves less than that: between generations it carries 10 of the
+    # 13 state rows (include/prt.h "compact state"), i.e. 80 B where the figure says 104 -- reported next
+    # to it as `moved_bytes_per_launch`, which is what `traffic` (PMC) has to be compared with.
+    algorithmic_bytes = 104.0 * ray_generations + 120.0 * rows_recorded + 104.0 * rays_carried
     full_rows = scene.telemetry()["full_rows_fallbacks"] > 0 or os.environ.get("PRT_FULL_ROWS") is not None
     state = STATE_BYTES_FULL if full_rows else STATE_BYTES
     first_generation = float(n) * args.steps
-    algorithmic_bytes = (STATE_BYTES_FULL * first_generation + state * (ray_generations - first_generation) +
-                         ROW_BYTES * rows_recorded + state * rays_carried)
+    moved_bytes = (STATE_BYTES_FULL * first_generation + state * (ray_generations - first_generation) +
+                   ROW_BYTES * rows_recorded + state * rays_carried)
     achieved = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     traffic = None
     traffic_file = os.path.join(ROOT, "profiles", "r2", "traffic.json")
@@ -296,7 +299,9 @@ def main():
             "avg_launch_ms": kernel_ms / launches if launches else 0,
             "launches_per_step": launches / args.steps,
             "kernel_ms_per_step": kernel_ms / args.steps,
-            "bytes_per_ray_generation_if_all_survive": 2 * state + ROW_BYTES,
+            "bytes_per_ray_generation_if_all_survive": BYTES_PER_RAY_GENERATION,
+            "moved_bytes_per_launch": moved_bytes / launches if launches else 0,
+            "moved_frac": moved_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms > 0 else 0.0,
             "state_rows": "all 13" if full_rows else "10 of 13 between generations (w rows and generation row implied)",
         },
         "end_to_end_trace": end_to_end,
