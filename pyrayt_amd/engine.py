@@ -201,6 +201,7 @@ class DeviceScene:
         return dict(zip(keys, (int(v) for v in out)))
 
     def close(self):
+        self._view_of = self._view = None
         if self._handle:
             library().prt_scene_destroy(self._handle)
             self._handle = ctypes.c_void_p()
@@ -249,10 +250,16 @@ class DeviceScene:
             _check(total)
             break
         self._cap_hint = (n, limit, cap)
-        per_generation = [int(c) for c in counts]
+        per_generation = counts[:]
         while per_generation and per_generation[-1] == 0:
             per_generation.pop()
-        return rows[:, :total], per_generation
+        if out is None:
+            return rows[:, :total], per_generation
+        # (slicing a tensor costs about 2 us: a loop that re-traces into its own block with the same
+        # outcome gets the view it got last time)
+        if getattr(self, "_view_of", None) is not out or self._view_total != total:
+            self._view_of, self._view_total, self._view = out, total, out[:, :total]
+        return self._view, per_generation
 
     def _rows_cap(self, torch, n, limit, dev):
         """Columns of the record block.  n * limit always suffices (one row per ray and generation)
