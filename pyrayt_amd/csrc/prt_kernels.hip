@@ -689,16 +689,23 @@ __global__ void __launch_bounds__(PRT_BLOCK, PRT_GEN_WAVES)
 k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double* __restrict__ next,
              int64_t ld_next, double* __restrict__ rows, int64_t ld_rows, FusedCtrl* __restrict__ ctrl,
              GenCtrl* __restrict__ gen, int g, unsigned long long* __restrict__ tiles_cur,
-             unsigned long long* __restrict__ tiles_next, double next_generation, int relaunch,
+             unsigned long long* __restrict__ tiles_next, double next_generation, int generation_limit,
              double ray_offset, int keep_absorbed, HostMirror* mirror, unsigned long long epoch,
              int mirror_slot, int batch_last, int assume) {
+  const int relaunch = (g + 1 != generation_limit) ? 1 : 0;  // the state written here is traced further
   __shared__ int s_wave_live[4], s_wave_carry[4];
   __shared__ unsigned s_excl[2];
   // A ticket from one atomic word would also give start-ordered tile numbers, but a single
   // word hands out only ~80 tickets/us chip-wide: 4k tiles would cost ~50 us per generation.
   const int tile = blockIdx.x;
   const int64_t n = gen[g].n_in;
-  if ((int64_t)tile * PRT_BLOCK >= n) return;  // uniform per workgroup; never a predecessor
+  if ((int64_t)tile * PRT_BLOCK >= n) {  // uniform per workgroup; never a predecessor
+    // The grid always covers the ray count the trace started with, so that every launch recycles the
+    // whole of the other status buffer (below) whatever is left of the rays: the launch behind this one
+    // -- of this trace or of the next -- then finds its buffer clean without a kernel in between.
+    if (threadIdx.x == 0) tiles_next[tile] = TILE_INVALID;
+    return;
+  }
   // A tile that sees an error raised earlier does no work but MUST still publish its (empty)
   // aggregate: tiles behind it may already be waiting on it.
   const bool failed = ctrl->error != 0;
@@ -872,6 +879,10 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     gen[g].n_carry = total_carry;
     gen[g + 1].n_in = next_in;
     gen[g + 1].row_base = row_base + total_live;
+    // (the end of the trace: launches queued blind behind it must find empty generations, whatever an
+    // earlier trace left in their slots)
+    if (next_in == 0)
+      for (int k = g + 2; k <= generation_limit; ++k) gen[k].n_in = 0;
     if (mirror) {
       // The host is told from here, not by a copy after the launch: the counts of this generation go to
       // host-mapped memory, and the generation that ends the trace (or the batch) raises the epoch word
@@ -939,12 +950,11 @@ __global__ void k_fused_init(FusedCtrl* ctrl, GenCtrl* gen, int n_gen_slots,
   if (i == 0) { ctrl->error = 0; ctrl->pad = test_stall; ctrl->rows_cap = 0; }
 }
 
-// end of a fused trace, enqueued blind behind a batch: if the trace is over (the slot behind the batch
-// holds no rays, or the generation limit is reached) clear the control words for the next trace of the
-// same shape -- off the host's critical path; otherwise leave everything for the next batch.
-// When the generation kernels of the batch did not tell the host themselves (mirror != null here), the
-// counts of slots [first_slot, first_slot + count) are published first -- without
-// a launch of its own.
+// Behind a batch whose generation kernels could not tell the host themselves (scenes that can raise
+// PRT_ERR_UNTRACABLE at store time, the look-back test hook): publish the counts of slots [first_slot,
+// first_slot + count) and the error word, and if the batch ended the trace (the slot behind it holds no
+// rays, the generation limit is reached, or an error is set) clear the control words for the next trace
+// of the same shape.  Traces that publish from their generation kernels never run this kernel.
 __global__ void k_fused_reinit(FusedCtrl* ctrl, GenCtrl* gen, int n_gen_slots, int end_slot, int limit,
                                unsigned long long* tiles0, int64_t n_tiles, int64_t n, int test_stall,
                                HostMirror* mirror, unsigned long long epoch, int first_slot, int count) {
@@ -1492,9 +1502,11 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
   // The control words of a trace (generation slots, tile words, error word) are cleared on the stream
   // right after the previous trace of the same shape finished, off the critical path; only a first
   // trace, or one with another workspace / ray count, clears them here.
-  if (!(c->ready_workspace == w && c->ready_n == n && c->ready_slots == n_slots && c->ready_stall == test_stall))
+  if (!(c->ready_workspace == w && c->ready_n == n && c->ready_slots == n_slots && c->ready_stall == test_stall)) {
     hipLaunchKernelGGL(k_fused_init, dim3(64), dim3(256), 0, st, ctrl, gen, n_slots, tiles[0],
                        (int64_t)blocks_for(n), n, test_stall);
+    c->flip = 0;
+  }
   c->ready_workspace = nullptr;
 
   size_t lds_pad = 0;  // experiment: PRT_LDS_PAD=<bytes> lowers occupancy without touching the code
@@ -1536,7 +1548,6 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
       const int gg = g + b;
       const double* src = (gg == 0) ? rays : buf[(gg - 1) & 1];
       const int64_t src_ld = (gg == 0) ? ld : n;
-      const int relaunch = (gg + 1 != generation_limit) ? 1 : 0;
       // dense-mode hint of the previous trace for this generation (the kernel reads the generation's
       // ray count on the device and checks the assumption tile by tile)
       int assume = 0;
@@ -1544,20 +1555,28 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
       s->dense_launches += assume ? 1 : 0;
       auto kernel = compact ? (culls ? k_generation<true, true> : k_generation<false, true>)
                             : (culls ? k_generation<true, false> : k_generation<false, false>);
-      hipLaunchKernelGGL(kernel, dim3(blocks_for(bound)), dim3(PRT_BLOCK), lds + lds_pad, st, sd, src,
-                         src_ld, buf[gg & 1], n, rows_out, rows_cap, ctrl, gen, gg, tiles[gg & 1],
-                         tiles[(gg + 1) & 1], (double)(gg + 1), relaunch, ray_offset, keep_absorbed,
+      // launches, not generations, alternate between the two status buffers, across traces too: every
+      // launch works on the one the launch before it left clean and cleans the other (k_generation)
+      hipLaunchKernelGGL(kernel, dim3(blocks_for(n)), dim3(PRT_BLOCK), lds + lds_pad, st, sd, src,
+                         src_ld, buf[gg & 1], n, rows_out, rows_cap, ctrl, gen, gg, tiles[c->flip],
+                         tiles[c->flip ^ 1], (double)(gg + 1), generation_limit, ray_offset, keep_absorbed,
                          in_kernel_publish ? c->mirror_dev : (HostMirror*)nullptr, epoch, b,
                          b + 1 == batch ? 1 : 0, assume);
+      c->flip ^= 1;
       if (b == 0) HP(4);
     }
     HIP_TRY(hipEventRecord(c->ev1, st));
     c->timing_pending = true;
-    // behind the batch: tell the host if the generation kernels did not, and clear the control words
-    // for the next trace if this batch turns out to end the trace
-    hipLaunchKernelGGL(k_fused_reinit, dim3(1), dim3(1024), 0, st, ctrl, gen, n_slots, g + batch,
-                       generation_limit, tiles[0], (int64_t)blocks_for(n), n, test_stall,
-                       in_kernel_publish ? (HostMirror*)nullptr : c->mirror_dev, epoch, g, batch + 1);
+    // Behind the batch, only when the generation kernels did not tell the host themselves: a one-block
+    // kernel that does (and re-arms the control words if the batch turns out to end the trace).  In
+    // the usual case nothing runs behind the batch: the status buffers recycle each other, a
+    // generation slot is always written by the launch before the one that reads it, and the error
+    // word of a trace that succeeded is still zero.
+    if (!in_kernel_publish) {
+      hipLaunchKernelGGL(k_fused_reinit, dim3(1), dim3(1024), 0, st, ctrl, gen, n_slots, g + batch,
+                         generation_limit, tiles[0], (int64_t)blocks_for(n), n, test_stall, c->mirror_dev, epoch,
+                         g, batch + 1);
+    }
     HIP_TRY(hipGetLastError());
     HP(5);
     rc = await_epoch(c, epoch, st);
@@ -1593,12 +1612,13 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
 #endif
   if (error == PRT_ERR_SPECULATION || error == PRT_ERR_FULL_ROWS) return error;
   if (error) return trace_error(error);
+  if (!publish_in_kernel) c->flip = 0;  // (k_fused_reinit cleared buffer 0; the next launch cleans buffer 1)
   s->last_generations = (int)s->stats[0];
   s->hint_n = n;
   s->hint_keep_absorbed = keep_absorbed;
   s->hint_mode = seen_mode;
   if (use_hints) s->hint_misses_in_a_row = 0;
-  // k_fused_reinit behind the last batch has cleared the control words for a next trace of this shape
+  // the control words are as a next trace of this shape needs them (see the launch loop)
   c->ready_workspace = w;
   c->ready_n = n;
   c->ready_slots = n_slots;

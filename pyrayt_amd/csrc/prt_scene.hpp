@@ -54,6 +54,7 @@ struct DeviceCopy {
   const void* ready_workspace = nullptr;
   int64_t ready_n = -1;
   int ready_slots = 0, ready_stall = 0;
+  int flip = 0;  // which of the two tile-status buffers the next generation launch works on
 };
 
 struct prt_scene {

@@ -1,5 +1,6 @@
 #!/bin/bash
-# per-generation launch durations of a bench workload (rocprofv3 kernel trace): tools/gen_profile.sh <workload> <rays> [ENV=V ...]
+# per-generation launch durations and the gaps between launches of a bench workload (rocprofv3 kernel
+# trace): tools/gen_profile.sh <workload> <rays> [ENV=V ...]
 W=$1; N=$2; shift 2
 for kv in "$@"; do export "$kv"; done
 cd /tmp && export TMPDIR=/tmp
@@ -9,14 +10,15 @@ python3 - <<'PY'
 import csv, glob
 f = glob.glob('/tmp/genprof/**/*kernel_trace.csv', recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if 'k_generation' in r['Kernel_Name'] or 'reinit' in r['Kernel_Name']]
-# split into traces at reinit
-traces, cur = [], []
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+traces, cur, prev_end = [], [], None
 for r in rows:
-    d = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+    a, b = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+    gap = (a - prev_end) / 1e3 if prev_end is not None else 0.0
+    prev_end = b
+    cur.append((gap, (b - a) / 1e3, 'reinit' in r['Kernel_Name']))
     if 'reinit' in r['Kernel_Name']:
         traces.append(cur); cur = []
-    else:
-        cur.append(d / 1e3)
-last = traces[-4:]
-for t in last: print(' '.join(f'{d:7.1f}' for d in t), ' | sum %.1f us' % sum(t))
+for t in traces[-4:]:
+    print(' '.join(f'[{g:5.1f}] {d:6.1f}{"r" if re else ""}' for g, d, re in t), ' | kernels %.1f us, gaps %.1f us' % (sum(d for _, d, re in t if not re), sum(g for g, _, _ in t[1:])))
 PY
