@@ -124,6 +124,15 @@ int prt_scene_create(const prt_prim* prims, int n_prims, const prt_node* nodes, 
                      const int32_t* roots, int n_roots, const prt_material* mats, int n_mats,
                      prt_scene** out);
 void prt_scene_destroy(prt_scene* scene);
+/* The same components with other numbers in them -- a part moved, a radius or a glass changed: what a
+ * design loop does between two RayTracer.trace() calls (examples/lens_design.ipynb; upstream simply
+ * walks the mutated Python objects again, _pyrayt.py:377).  Recompiles on the host and overwrites the
+ * scene's tables in place: device buffers, pinned memory, events and what the scene learnt from its
+ * previous trace stay.  Returns 0, or 1 -- scene untouched -- when the snapshot does not have the old
+ * one's shape (a table or program would change size): build a new scene then.  Synchronises the
+ * device (the previous trace may still be reading the tables). */
+int prt_scene_update(prt_scene* scene, const prt_prim* prims, int n_prims, const prt_node* nodes, int n_nodes,
+                     const int32_t* roots, int n_roots, const prt_material* mats, int n_mats);
 /* rows of the hit list component `root` returns from intersect(): 2 * (#leaves under it) */
 int prt_scene_component_rows(const prt_scene* scene, int root);
 /* what the scene compiled to (no counterpart upstream; host-only, needs no GPU):

@@ -570,6 +570,62 @@ extern "C" void prt_scene_destroy(prt_scene* s) {
   delete s;
 }
 
+// The same scene with other numbers in it (a part moved, a radius or a glass changed): recompile on
+// the host and overwrite the tables in place -- device buffers, the host mirror, the events, the
+// hints of the previous trace and the telemetry all stay.  Returns 1 (and leaves the scene as it
+// was) when the new description does not have the old one's shape, i.e. when a program or table
+// would change size: the caller then builds a new scene.
+extern "C" int prt_scene_update(prt_scene* s, const prt_prim* prims, int n_prims, const prt_node* nodes,
+                                int n_nodes, const int32_t* roots, int n_roots, const prt_material* mats,
+                                int n_mats) {
+  if (!s) return fail(PRT_ERR_ARG, "scene is null");
+  prt_scene* t = nullptr;
+  const int rc = prt_scene_create(prims, n_prims, nodes, n_nodes, roots, n_roots, mats, n_mats, &t);
+  if (rc) return rc;
+  auto same_program = [](const Program& a, const Program& b) {
+    return a.code.size() == b.code.size() && a.lds_slots == b.lds_slots &&
+           a.component_first.size() == b.component_first.size();
+  };
+  bool same = t->dev_prims.size() == s->dev_prims.size() && same_program(t->trace_program, s->trace_program) &&
+              same_program(t->render_program, s->render_program) &&
+              t->component_programs.size() == s->component_programs.size() &&
+              t->has_untracable == s->has_untracable;
+  for (size_t k = 0; same && k < t->component_programs.size(); ++k)
+    same = same_program(t->component_programs[k], s->component_programs[k]);
+  if (!same) {
+    prt_scene_destroy(t);
+    return 1;
+  }
+  for (size_t d = 0; d < s->per_device.size(); ++d) {
+    DeviceCopy& c = s->per_device[d];
+    if (!c.prims) continue;
+    HIP_TRY(hipSetDevice((int)d));
+    HIP_TRY(hipDeviceSynchronize());  // the last trace may still be draining: it reads these tables
+    auto put = [](void* dst, const void* src, size_t bytes) {
+      return bytes ? hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+    };
+    HIP_TRY(put(c.prims, t->dev_prims.data(), t->dev_prims.size() * sizeof(DevPrim)));
+    HIP_TRY(put(c.trace_code, t->trace_program.code.data(), t->trace_program.code.size() * sizeof(DevInstr)));
+    HIP_TRY(put(c.trace_component_first, t->trace_program.component_first.data(),
+                t->trace_program.component_first.size() * sizeof(int32_t)));
+    HIP_TRY(put(c.render_code, t->render_program.code.data(), t->render_program.code.size() * sizeof(DevInstr)));
+    for (size_t k = 0; k < t->component_programs.size(); ++k)
+      HIP_TRY(put(c.component_code[k], t->component_programs[k].code.data(),
+                  t->component_programs[k].code.size() * sizeof(DevInstr)));
+  }
+  s->prims.swap(t->prims);
+  s->nodes.swap(t->nodes);
+  s->roots.swap(t->roots);
+  s->mats.swap(t->mats);
+  s->dev_prims.swap(t->dev_prims);
+  std::swap(s->trace_program, t->trace_program);
+  std::swap(s->render_program, t->render_program);
+  s->component_programs.swap(t->component_programs);
+  s->component_result.swap(t->component_result);
+  prt_scene_destroy(t);  // (never reached a device: host memory only)
+  return PRT_OK;
+}
+
 extern "C" int prt_scene_info(const prt_scene* s, int64_t* out8) {
   if (!s || !out8) return fail(PRT_ERR_ARG, "null argument");
   const int64_t culls = count_steps(s->trace_program.code, I_BOX);

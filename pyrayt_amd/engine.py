@@ -39,6 +39,7 @@ def _declare(lib):
         "prt_device_count": (c_int, []),
         "prt_scene_create": (c_int, [c_p, c_int, c_p, c_int, c_p, c_int, c_p, c_int, ctypes.POINTER(c_p)]),
         "prt_scene_destroy": (None, [c_p]),
+        "prt_scene_update": (c_int, [c_p, c_p, c_int, c_p, c_int, c_p, c_int, c_p, c_int]),
         "prt_scene_component_rows": (c_int, [c_p, c_int]),
         "prt_scene_info": (c_int, [c_p, c_p]),
         "prt_intersect": (c_int, [c_p, c_int, c_int, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
@@ -87,7 +88,7 @@ def _declare(lib):
 
 
 EXPORTED_SYMBOLS = (
-    "prt_version", "prt_last_error", "prt_device_count", "prt_scene_create", "prt_scene_destroy",
+    "prt_version", "prt_last_error", "prt_device_count", "prt_scene_create", "prt_scene_destroy", "prt_scene_update",
     "prt_scene_component_rows", "prt_scene_info", "prt_intersect", "prt_propagate", "prt_world_normals",
     "prt_material_trace", "prt_interact_workspace_bytes", "prt_interact",
     "prt_trace_workspace_bytes", "prt_trace", "prt_trace_stats", "prt_trace_telemetry", "prt_generate_rays",
@@ -178,6 +179,22 @@ class DeviceScene:
                 len(roots), mats.ctypes.data, len(mats), ctypes.byref(self._handle),
             )
         )
+
+    def update(self, snapshot):
+        """Put another snapshot of the same components into this scene (``prt_scene_update``): True if
+        it fitted -- device tables overwritten in place, hints and telemetry kept -- False if the
+        snapshot has another shape and a new DeviceScene is needed."""
+        prims = np.ascontiguousarray(snapshot.prims)
+        nodes = np.ascontiguousarray(snapshot.nodes)
+        roots = np.ascontiguousarray(snapshot.roots)
+        mats = np.ascontiguousarray(snapshot.materials)
+        rc = library().prt_scene_update(self.handle, prims.ctypes.data, len(prims), nodes.ctypes.data, len(nodes),
+                                        roots.ctypes.data, len(roots), mats.ctypes.data, len(mats))
+        if rc == 1:
+            return False
+        _check(rc)
+        self.snapshot = snapshot
+        return True
 
     @classmethod
     def from_components(cls, components):

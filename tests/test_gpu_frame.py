@@ -92,10 +92,12 @@ def test_trace_keeps_the_device_frame_and_converts_lazily():
         assert np.isclose(stats.loc[sid, "y"], rows["y1"].mean(), atol=1e-12)
         rms = np.sqrt(((rows["y1"] - rows["y1"].mean()) ** 2 + (rows["z1"] - rows["z1"].mean()) ** 2).mean())
         assert np.isclose(stats.loc[sid, "rms_radius"], rms, rtol=1e-9)
-    # a second trace of the unchanged system re-uses the compiled scene
-    first_scene = tracer._scene_cache[1]
-    tracer.trace()
-    assert tracer._scene_cache[1] is first_scene
+    # a second trace of the unchanged system re-uses the compiled scene ...
+    first_key, first_scene = tracer._scene_cache
+    before = tracer.trace()
+    assert tracer._scene_cache[1] is first_scene and tracer._scene_cache[0] == first_key
+    # ... and a moved part goes into the same scene object (prt_scene_update): new tables, nothing rebuilt
     lens.move_x(0.01)
-    tracer.trace()
-    assert tracer._scene_cache[1] is not first_scene
+    after = tracer.trace()
+    assert tracer._scene_cache[1] is first_scene and tracer._scene_cache[0] != first_key
+    assert not np.array_equal(before.to_numpy(), after.to_numpy())

@@ -548,6 +548,66 @@ def test_baseline_configs_at_full_size(name, args, limit):
 
 
 # ---------------------------------------------------------------------------------------------
+# a design loop: the same parts with other numbers go into the scene object that is already there
+# ---------------------------------------------------------------------------------------------
+def test_scene_update_in_place_equals_a_new_scene():
+    from pyrayt_amd.engine import DeviceScene
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    api = scenes.product_api()
+    CountedObject.reset_ids()
+    parts, rays = scenes.config3(api, 30_000)
+    ds = DeviceScene(SceneSnapshot(parts))
+    device_rays = dev(rays)
+    ds.trace(device_rays, 10)
+    ds.trace(device_rays, 10)                                   # hints in place
+    for step in range(4):
+        parts[1].move_x(0.05).rotate_y(0.3)                       # the flint element wanders
+        parts[4].move_x(-0.1)
+        snap = SceneSnapshot(parts)
+        assert ds.update(snap) is True
+        want, want_counts = orc.trace(helpers.flat_scene(snap), rays, 10)
+        for turn in range(2):
+            rows, counts = ds.trace(device_rays, 10)
+            assert counts == want_counts, (step, turn)
+            helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"updated scene step {step} turn {turn}")
+        fresh = DeviceScene(snap)
+        rows_fresh, _ = fresh.trace(device_rays, 10)
+        assert np.array_equal(rows_fresh.cpu().numpy(), rows.cpu().numpy(), equal_nan=True)
+        t, surf = ds.propagate(device_rays)                       # the per-component programs were updated too
+        t_fresh, surf_fresh = fresh.propagate(device_rays)
+        assert torch.equal(surf, surf_fresh) and torch.equal(t, t_fresh)
+        fresh.close()
+    # another shape (one part fewer) does not fit: the scene stays as it was
+    assert ds.update(SceneSnapshot(parts[:-1] + [])) is False or len(parts) == 1
+    rows_after, _ = ds.trace(device_rays, 10)
+    assert np.array_equal(rows_after.cpu().numpy(), rows.cpu().numpy(), equal_nan=True)
+    ds.close()
+
+
+def test_raytracer_keeps_its_scene_when_a_part_moves():
+    import pyrayt_amd as pyrayt
+
+    lens = pyrayt.components.biconvex_lens(2, 2, 0.25, aperture=1)
+    src = pyrayt.components.ConeOfRays(cone_angle=6).move_x(-1.9)
+    det = pyrayt.components.baffle((1, 1)).move_x(1)
+    tracer = pyrayt.RayTracer(src, [lens, det], rays_per_source=10_000)
+    tracer.trace_device()
+    scene = tracer._device_scene()
+    spots = []
+    for _ in range(3):
+        det.move_x(0.05)
+        frame = tracer.trace_device()
+        assert tracer._device_scene() is scene                   # updated in place, not rebuilt
+        spots.append(float(frame.group_stats(surface=det.get_id())["rms_radius"].iloc[0]))
+        want = pyrayt.RayTracer(src, [lens, det], rays_per_source=10_000).trace()
+        got = tracer.get_results()
+        assert np.array_equal(got.to_numpy(), want.to_numpy(), equal_nan=True)
+    assert spots[0] != spots[1] != spots[2]                       # the detector really moved
+
+
+# ---------------------------------------------------------------------------------------------
 # compact state: rows 3, 7, 8 of the ray state are not carried between generations while they hold
 # what RaySet's defaults put there; a ray set that differs anywhere must get all 13 rows
 # ---------------------------------------------------------------------------------------------

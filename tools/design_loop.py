@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""A design loop as the reference's lens_design notebook runs it: move a part, trace, read the spot size off
+the detector -- timed per stage, with the result never leaving the GPU (RayTracer.trace_device +
+DeviceFrame.group_stats)."""
+import cProfile, os, pstats, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import pyrayt_amd as pyrayt
+
+lens = pyrayt.components.biconvex_lens(2, 2, 0.25, aperture=1)
+src = pyrayt.components.ConeOfRays(cone_angle=6).move_x(-1.9)
+det = pyrayt.components.baffle((1, 1)).move_x(1)
+tracer = pyrayt.RayTracer(src, [lens, det], rays_per_source=1_000_000)
+for _ in range(3):
+    tracer.trace_device()
+
+
+def iteration(move):
+    if move:
+        det.move_x(1e-4)
+    frame = tracer.trace_device()
+    return frame.group_stats(surface=det.get_id())["rms_radius"].iloc[0]
+
+
+for move in (False, True):
+    for _ in range(3):
+        iteration(move)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(30):
+        rms = iteration(move)
+    dt = (time.perf_counter() - t0) / 30
+    print(f"{'moving the detector' if move else 'unchanged system'}: {dt * 1e3:.3f} ms per iteration (rms spot {rms:.3e})")
+if "--profile" in sys.argv:
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(30):
+        iteration(True)
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
