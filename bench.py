@@ -49,6 +49,7 @@ BYTES_PER_RAY_GENERATION = 328  # 104 B state read + 104 B
 # caller's 13 rows
 STATE_BYTES, STATE_BYTES_FULL, ROW_BYTES = 80, 104, 120
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+COPY_GBS = 6300.0               # what a bare copy with the kernel's row pattern reaches (tools/ubench/copy_f64: 5.7-6.4 TB/s)
 
 
 def parse_args():
@@ -291,6 +292,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
+            "frac_of_measured_copy": achieved / COPY_GBS,
             "traffic": traffic,
             "traffic_source": "profiles/r2/traffic.json (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, "
                               "calibrated; same command, separate passes)" if traffic else None,
