@@ -279,6 +279,15 @@ int prt_place_rows(int device, const double* staging, int64_t stride_rank, int64
 int prt_frame_reduce(int device, const double* rows, int64_t ld, int64_t n_rows, double surface,
                      double generation, double rays_per_source, int n_groups, const double* pivots,
                      double* out, void* stream);
+/* The statistics themselves in one stream-ordered call (two prt_frame_reduce passes, the second about
+ * the first one's per-group means, computed on the device): out = (n_groups, 8) float64 on the device,
+ * per group count, mean y1, mean z1, rms spot radius about that centroid, mean axis intercept, its
+ * standard deviation, mean wavelength, mean intensity (NaN in 1..7 for a group without rows).
+ * workspace: prt_frame_stats_workspace_bytes(n_groups) device bytes. */
+int64_t prt_frame_stats_workspace_bytes(int n_groups);
+int prt_frame_stats(int device, const double* rows, int64_t ld, int64_t n_rows, double surface,
+                    double generation, double rays_per_source, int n_groups, double* out, void* workspace,
+                    void* stream);
 
 /* statistics of the last prt_trace on this scene (for bench.py's roofline):
  * out[0] = generations that found rays, out[1] = sum over generations of rays alive at entry,

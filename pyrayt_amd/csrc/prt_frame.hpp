@@ -138,3 +138,65 @@ extern "C" int prt_frame_reduce(int device, const double* rows, int64_t ld, int6
   HIP_TRY(hipGetLastError());
   return PRT_OK;
 }
+
+// ---- the statistics themselves, in one call ---------------------------------------------------------
+// Two reduction passes without a trip to the host in between: the first pass's sums become per-group
+// pivots (means) on the device, the second pass accumulates about them, and a last small kernel turns
+// the sums into what the notebook looks at.  Per group: [0] count  [1] mean y1  [2] mean z1
+// [3] rms spot radius about that centroid  [4] mean axis intercept  [5] its standard deviation
+// [6] mean wavelength  [7] mean intensity; NaN in [1..7] for a group without rows.
+__global__ void __launch_bounds__(PRT_BLOCK)
+k_frame_pivots(const double* __restrict__ sums, int n_groups, double* __restrict__ pivots) {
+  const int g = blockIdx.x * PRT_BLOCK + threadIdx.x;
+  if (g >= n_groups) return;
+  const double count = sums[g * FRAME_STATS];
+  const double safe = count > 0 ? count : 1.0;
+  pivots[3 * g + 0] = sums[g * FRAME_STATS + 1] / safe;
+  pivots[3 * g + 1] = sums[g * FRAME_STATS + 2] / safe;
+  pivots[3 * g + 2] = sums[g * FRAME_STATS + 4] / safe;
+}
+
+__global__ void __launch_bounds__(PRT_BLOCK)
+k_frame_finish(const double* __restrict__ sums, const double* __restrict__ pivots, int n_groups,
+               double* __restrict__ out) {
+  const int g = blockIdx.x * PRT_BLOCK + threadIdx.x;
+  if (g >= n_groups) return;
+  const double* s = sums + (size_t)g * FRAME_STATS;
+  const double count = s[0];
+  const double safe = count > 0 ? count : 1.0;
+  const double dy = s[1] / safe, dz = s[2] / safe, df = s[4] / safe;
+  const double var_r = fmax(s[3] / safe - dy * dy - dz * dz, 0.0), var_f = fmax(s[5] / safe - df * df, 0.0);
+  const double nan = __longlong_as_double(0x7ff8000000000000ll);
+  double* o = out + (size_t)g * FRAME_STATS;
+  o[0] = count;
+  o[1] = count > 0 ? pivots[3 * g + 0] + dy : nan;
+  o[2] = count > 0 ? pivots[3 * g + 1] + dz : nan;
+  o[3] = count > 0 ? sqrt(var_r) : nan;
+  o[4] = count > 0 ? pivots[3 * g + 2] + df : nan;
+  o[5] = count > 0 ? sqrt(var_f) : nan;
+  o[6] = count > 0 ? s[6] / safe : nan;
+  o[7] = count > 0 ? s[7] / safe : nan;
+}
+
+// out: (n_groups, 8) float64 on the device; workspace: prt_frame_stats_workspace_bytes(n_groups) bytes
+extern "C" int64_t prt_frame_stats_workspace_bytes(int n_groups) {
+  return n_groups < 1 ? 0 : (int64_t)n_groups * (FRAME_STATS + 3) * (int64_t)sizeof(double);
+}
+
+extern "C" int prt_frame_stats(int device, const double* rows, int64_t ld, int64_t n_rows, double surface,
+                               double generation, double rays_per_source, int n_groups, double* out,
+                               void* workspace, void* stream) {
+  if (!workspace || !out || n_groups < 1) return fail(PRT_ERR_ARG, "bad buffers");
+  double* sums = (double*)workspace;
+  double* pivots = sums + (size_t)n_groups * FRAME_STATS;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = prt_frame_reduce(device, rows, ld, n_rows, surface, generation, rays_per_source, n_groups, nullptr, sums, st);
+  if (rc) return rc;
+  const dim3 grid((n_groups + PRT_BLOCK - 1) / PRT_BLOCK);
+  hipLaunchKernelGGL(k_frame_pivots, grid, dim3(PRT_BLOCK), 0, st, sums, n_groups, pivots);
+  rc = prt_frame_reduce(device, rows, ld, n_rows, surface, generation, rays_per_source, n_groups, pivots, sums, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_frame_finish, grid, dim3(PRT_BLOCK), 0, st, sums, pivots, n_groups, out);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}

@@ -79,6 +79,8 @@ def _declare(lib):
         "prt_place_workspace_bytes": (c_i64, [c_int, c_int]),
         "prt_place_rows": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_int, c_p, c_i64, c_p, c_p]),
         "prt_frame_reduce": (c_int, [c_int, c_p, c_i64, c_i64, c_d, c_d, c_d, c_int, c_p, c_p, c_p]),
+        "prt_frame_stats_workspace_bytes": (c_i64, [c_int]),
+        "prt_frame_stats": (c_int, [c_int, c_p, c_i64, c_i64, c_d, c_d, c_d, c_int, c_p, c_p, c_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = the library does not match prt.h
@@ -97,7 +99,8 @@ EXPORTED_SYMBOLS = (
     "prt_smallest_positive_root", "prt_dot", "prt_array_csg", "prt_primitive_intersect",
     "prt_primitive_normal", "prt_comm_unique_id", "prt_comm_create", "prt_comm_destroy",
     "prt_allgather_counts", "prt_allgather_workspace_bytes", "prt_allgather_rows",
-    "prt_place_workspace_bytes", "prt_place_rows", "prt_frame_reduce",
+    "prt_place_workspace_bytes", "prt_place_rows", "prt_frame_reduce", "prt_frame_stats_workspace_bytes",
+    "prt_frame_stats",
 )
 
 

@@ -11,7 +11,6 @@ done on the device, so that only what is looked at crosses PCIe.  The grouped re
 11-16) are one HIP kernel over the column block (``prt_frame_reduce``, ``csrc/prt_frame.hpp``);
 row selections that return a new frame are torch indexing -- plumbing around the result.
 """
-import ctypes
 
 import numpy as np
 import pandas as pd
@@ -65,28 +64,6 @@ class DeviceFrame:
         return DeviceFrame(self.rows[:, mask])
 
     # --- reductions the notebook does on the frame -------------------------------------------------
-    def _reduce(self, surface, generation, rays_per_source, n_groups, pivots):
-        """One pass of ``prt_frame_reduce``: (n_groups, 8) float64 on the host."""
-        import torch
-
-        from . import engine
-
-        rows = self.rows
-        if rows.stride(1) != 1:
-            rows = rows.contiguous()
-        dev = rows.device
-        out = torch.empty((n_groups, 8), dtype=torch.float64, device=dev)
-        nan = float("nan")
-        piv = None
-        if pivots is not None:  # (n_groups, 3) on the device: what each group's rows are measured from
-            piv = torch.from_numpy(np.ascontiguousarray(pivots, dtype=np.float64).reshape(n_groups, 3)).to(dev)
-        engine._check(engine.library().prt_frame_reduce(
-            dev.index or 0, rows.data_ptr(), rows.stride(0), rows.shape[1],
-            nan if surface is None else float(surface), nan if generation is None else float(generation),
-            float(rays_per_source or 0), n_groups, piv.data_ptr() if piv is not None else None, out.data_ptr(),
-            engine._stream_ptr(torch, dev)))
-        return out.cpu().numpy()
-
     def group_stats(self, surface=None, generation=None, rays_per_source=None, n_groups=None):
         """Per-source statistics of the rows that hit ``surface`` and / or belong to ``generation``
         (``examples/lens_design.ipynb`` cells 11-16: ``results.loc[results['surface'] == id]``
@@ -95,33 +72,43 @@ class DeviceFrame:
         Returns a DataFrame indexed by source id with columns ``count``, ``y`` / ``z`` (spot centroid
         of the end points), ``rms_radius`` (about that centroid), ``focus`` / ``focus_std`` (mean and
         spread of the x-axis intercepts ``x0 - x_tilt * y0 / y_tilt``, the notebook's paraxial-focus
-        estimate), ``wavelength`` and ``intensity`` (means).  One HIP reduction kernel, run twice: the
-        second pass accumulates about the first pass's means so the second moments are well
-        conditioned.  Without ``rays_per_source`` everything is one group."""
+        estimate), ``wavelength`` and ``intensity`` (means).  One library call (``prt_frame_stats``): the
+        HIP reduction kernel runs twice, the second pass about the first pass's per-group means so that
+        the second moments are well conditioned, and the final arithmetic happens on the device too.
+        Without ``rays_per_source`` everything is one group."""
         if rays_per_source:
             if n_groups is None:
                 n_groups = int(float(self["id"].max()) // rays_per_source) + 1 if len(self) else 1
         else:
             n_groups = 1
-        first = self._reduce(surface, generation, rays_per_source, n_groups, None)
-        count = first[:, 0]
-        safe = np.where(count > 0, count, 1.0)
-        # second pass about every group's own means of the first: the second moments are then sums of
-        # squared deviations, not differences of large numbers (coincident points give exactly zero)
-        pivots = np.stack([first[:, 1] / safe, first[:, 2] / safe, first[:, 4] / safe], axis=1)
-        second = self._reduce(surface, generation, rays_per_source, n_groups, pivots)
-        dy, dz, df = second[:, 1] / safe, second[:, 2] / safe, second[:, 4] / safe
-        var_r = np.maximum(second[:, 3] / safe - dy ** 2 - dz ** 2, 0.0)
-        var_f = np.maximum(second[:, 5] / safe - df ** 2, 0.0)
-        empty = count == 0  # (masked here: a .loc assignment on the finished frame costs a millisecond)
-        blank = lambda values: np.where(empty, np.nan, values)
+        stats = self._stats(surface, generation, rays_per_source, n_groups)
         frame = pd.DataFrame({
-            "count": count.astype(np.int64), "y": blank(pivots[:, 0] + dy), "z": blank(pivots[:, 1] + dz),
-            "rms_radius": blank(np.sqrt(var_r)), "focus": blank(pivots[:, 2] + df), "focus_std": blank(np.sqrt(var_f)),
-            "wavelength": blank(second[:, 6] / safe), "intensity": blank(second[:, 7] / safe),
+            "count": stats[:, 0].astype(np.int64), "y": stats[:, 1], "z": stats[:, 2], "rms_radius": stats[:, 3],
+            "focus": stats[:, 4], "focus_std": stats[:, 5], "wavelength": stats[:, 6], "intensity": stats[:, 7],
         })
         frame.index.name = "source_id"
         return frame
+
+    def _stats(self, surface, generation, rays_per_source, n_groups):
+        """``prt_frame_stats``: both reduction passes and the final arithmetic on the device, one
+        (n_groups, 8) block brought to the host."""
+        import torch
+
+        from . import engine
+
+        rows = self.rows
+        if rows.stride(1) != 1:
+            rows = rows.contiguous()
+        dev = rows.device
+        lib = engine.library()
+        out = torch.empty((n_groups, 8), dtype=torch.float64, device=dev)
+        work = torch.empty(int(lib.prt_frame_stats_workspace_bytes(n_groups)), dtype=torch.uint8, device=dev)
+        nan = float("nan")
+        engine._check(lib.prt_frame_stats(
+            dev.index or 0, rows.data_ptr(), rows.stride(0), rows.shape[1],
+            nan if surface is None else float(surface), nan if generation is None else float(generation),
+            float(rays_per_source or 0), n_groups, out.data_ptr(), work.data_ptr(), engine._stream_ptr(torch, dev)))
+        return out.cpu().numpy()
 
     def spot(self, plane=("y1", "z1")):
         """(centroid, rms radius) of the end points in a transverse plane."""
