@@ -249,3 +249,24 @@ def test_group_is_a_list_and_small_world_object_helpers():
     part = cg.Sphere()
     part.attach_to(group)
     assert part._parent is group
+
+
+def test_scene_update_keeps_the_object_for_the_same_shape_only():
+    """prt_scene_update is host-side work until a device holds the tables: same parts with other numbers
+    go into the existing scene, another shape is refused and leaves it untouched."""
+    import scenes
+    from pyrayt_amd import engine
+    from pyrayt_amd.g3d.objects import CountedObject
+
+    api = scenes.product_api()
+    CountedObject.reset_ids()
+    parts, _ = scenes.SCENES["config3"](api, 8)
+    ds = engine.DeviceScene.from_components(parts)
+    before = ds.info()
+    parts[1].move_x(0.25).rotate_y(1.0)
+    moved = SceneSnapshot(parts)
+    assert ds.update(moved) is True and ds.snapshot is moved and ds.info() == before
+    assert ds.update(SceneSnapshot(parts[:-1])) is False        # one component fewer: other tables
+    assert ds.snapshot is moved and ds.info() == before
+    assert ds.update(SceneSnapshot(parts + [api.components.baffle((1, 1)).move_x(90)])) is False
+    ds.close()
