@@ -1499,9 +1499,9 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
   const char* stall_env = getenv("PRT_TEST_STALL");
   const int test_stall = (stall_env && stall_env[0] == '1') ? 1 : 0;
   int rc;
-  // The control words of a trace (generation slots, tile words, error word) are cleared on the stream
-  // right after the previous trace of the same shape finished, off the critical path; only a first
-  // trace, or one with another workspace / ray count, clears them here.
+  // A trace leaves the control words (generation slots, tile status buffers, error word) as the next
+  // trace of the same shape needs them (see the launch loop); only a first trace, one with another
+  // workspace / ray count / limit, or one behind a trace that failed clears them here.
   if (!(c->ready_workspace == w && c->ready_n == n && c->ready_slots == n_slots && c->ready_stall == test_stall)) {
     hipLaunchKernelGGL(k_fused_init, dim3(64), dim3(256), 0, st, ctrl, gen, n_slots, tiles[0],
                        (int64_t)blocks_for(n), n, test_stall);
