@@ -219,9 +219,10 @@ int prt_generate_rays(int device, const prt_source* source, int64_t n_total, int
  *   rows_out (15, rows_cap) ld_rows = rows_cap: generation-major record rows
  *   rows_per_generation: HOST int64[generation_limit], rows recorded by each generation
  *   workspace: device scratch of prt_trace_workspace_bytes(n) bytes.  A scene that is traced again
- *     with the same workspace address, ray count and generation limit expects the workspace as its
- *     previous trace left it (the control words in it are not re-initialised): give a scene a
- *     workspace of its own, or do not reuse the address for anything else in between
+ *     with the same workspace address, ray count and generation limit finds the control words in it as
+ *     its previous trace left them and does not re-initialise them; the library notices when another
+ *     scene traced with that address in between (then it does), but not when something else wrote
+ *     there: do not hand the block to anything but prt_trace between two traces
  *   flags: PRT_TRACE_* bits
  * Returns the total number of rows (>= 0) or a negative error.  PRT_ERR_ROWS_CAP if rows_cap
  * is too small (n * generation_limit rows always suffices).  Synchronises the stream. */

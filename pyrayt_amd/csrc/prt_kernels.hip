@@ -21,11 +21,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/prt.h"
@@ -1372,6 +1375,20 @@ static int64_t trace_error(int error) {
 }
 
 // three kernels per generation + a host round trip (kept for A/B runs and cross-checks)
+// Who traced last with a given workspace address: a scene skips re-initialising the control words only
+// if nobody else used the block since its own last trace (another scene, or the other trace path of
+// the same one, marks the block as theirs before touching it).
+static std::mutex g_workspace_mutex;
+static std::unordered_map<const void*, unsigned long long> g_workspace_user;
+static std::atomic<unsigned long long> g_next_user{1};
+static bool workspace_taken_over(const void* w, unsigned long long user) {
+  std::lock_guard<std::mutex> lock(g_workspace_mutex);
+  unsigned long long& last = g_workspace_user[w];
+  const bool same = last == user;
+  last = user;
+  return !same;
+}
+
 static int64_t trace_unfused(prt_scene* s, DeviceCopy* c, const double* rays, int64_t n, int64_t ld,
                              int generation_limit, double ray_offset, double* rows_out,
                              int64_t rows_cap, int64_t* rows_per_generation, char* w, int flags,
@@ -1502,7 +1519,9 @@ static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int6
   // A trace leaves the control words (generation slots, tile status buffers, error word) as the next
   // trace of the same shape needs them (see the launch loop); only a first trace, one with another
   // workspace / ray count / limit, or one behind a trace that failed clears them here.
-  if (!(c->ready_workspace == w && c->ready_n == n && c->ready_slots == n_slots && c->ready_stall == test_stall)) {
+  if (c->user == 0) c->user = g_next_user.fetch_add(1);
+  const bool others = workspace_taken_over(w, c->user);
+  if (others || !(c->ready_workspace == w && c->ready_n == n && c->ready_slots == n_slots && c->ready_stall == test_stall)) {
     hipLaunchKernelGGL(k_fused_init, dim3(64), dim3(256), 0, st, ctrl, gen, n_slots, tiles[0],
                        (int64_t)blocks_for(n), n, test_stall);
     c->flip = 0;

@@ -55,6 +55,7 @@ struct DeviceCopy {
   int64_t ready_n = -1;
   int ready_slots = 0, ready_stall = 0;
   int flip = 0;  // which of the two tile-status buffers the next generation launch works on
+  unsigned long long user = 0;  // identity of this copy in the workspace registry (0: not drawn yet)
 };
 
 struct prt_scene {

@@ -547,6 +547,37 @@ def test_baseline_configs_at_full_size(name, args, limit):
     ds.close()
 
 
+def test_two_scenes_taking_turns_on_one_workspace():
+    """A scene leaves its control words in the workspace for its own next trace; a block that another
+    scene used in between is re-initialised (the library keeps track of who traced last with an address)."""
+    import ctypes
+
+    from pyrayt_amd import engine
+    from pyrayt_amd.engine import DeviceScene
+
+    fa, fb = helpers.load("scene_config2.npz"), helpers.load("scene_config5.npz")
+    n = 1000
+    ra = dev(np.ascontiguousarray(fa["rays0"][:, :n]))
+    rb = dev(np.ascontiguousarray(fb["rays0"][:, :n]))
+    a, b = device_scene(helpers.scene_of(fa)), device_scene(helpers.scene_of(fb))
+    want_a, _ = a.trace(ra, 10)
+    want_b, _ = b.trace(rb, 10)
+    want_a, want_b = want_a.cpu().numpy().copy(), want_b.cpu().numpy().copy()
+    lib = engine.library()
+    work = torch.empty(int(lib.prt_trace_workspace_bytes(n)), dtype=torch.uint8, device="cuda:0")
+    rows = torch.empty((15, n * 10), dtype=torch.float64, device="cuda:0")
+    counts = (ctypes.c_int64 * 10)()
+    stream = engine._stream_ptr(torch, rows.device)
+    for turn in range(6):
+        for scene, rays, want in ((a, ra, want_a), (b, rb, want_b), (a, ra, want_a)):
+            total = lib.prt_trace(scene.handle, 0, rays.data_ptr(), n, rays.stride(0), 10, engine.DEFAULT_RAY_OFFSET,
+                                  rows.data_ptr(), rows.shape[1], counts, work.data_ptr(), 0, stream)
+            assert total == want.shape[1], (turn, total)
+            assert np.array_equal(rows[:, :total].cpu().numpy(), want, equal_nan=True)
+    a.close()
+    b.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # a design loop: the same parts with other numbers go into the scene object that is already there
 # ---------------------------------------------------------------------------------------------
