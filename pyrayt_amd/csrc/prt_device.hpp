@@ -718,7 +718,11 @@ __device__ __forceinline__ void csg_keep(int op, const double (&lv)[ML], const d
       const bool outside = (px && !(ray.ox >= aabb[0] && ray.ox <= aabb[1])) ||
                            (py && !(ray.oy >= aabb[2] && ray.oy <= aabb[3])) ||
                            (pz && !(ray.oz >= aabb[4] && ray.oz <= aabb[5]));
-      touched = touched && !outside;
+      // (no crossing on any axis -- a zero-direction ray, e.g. an absorbed one carried along: upstream's
+      // box test then returns (-inf, +inf) or (+inf, +inf), never a finite entry, and csg.py:126-128
+      // drops the ray wherever it sits; a paraboloid child would still report the finite -c / 1 of its
+      // linear branch, primitives.py:361 -- found by fuzz seed 8061 of a 12 000-seed run)
+      touched = touched && !outside && !(px && py && pz);
       const bool grazing = (!px && ax < 1e-4) || (!py && ay < 1e-4) || (!pz && az < 1e-4);
       if (__ballot(grazing && any && robust) != 0ull) {
         if (grazing && any && robust) touched = touched && box_touched(aabb, ray);
@@ -851,6 +855,10 @@ __device__ __forceinline__ bool may_reach(const double* __restrict__ box, const 
   double t_in = 0.0, t_out = best_t;
   bool never = false;
   const double o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
+  // a direction so short that a leaf of the component may take one of upstream's degenerate branches
+  // without being parallel to anything (box[6], see short_direction_bound): the hit such a branch
+  // reports need not lie on the surface, so the box says nothing about it
+  if ((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2] < box[6]) return true;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const double inv = __builtin_amdgcn_rcp(d[k]);

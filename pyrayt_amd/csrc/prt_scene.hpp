@@ -309,6 +309,48 @@ static void pad_box(double* box) {
   for (int k = 0; k < 3; ++k) { box[2 * k] -= pad; box[2 * k + 1] += pad; }
 }
 
+// The cull steps argue geometrically: a finite positive entry of a component's hit list is a parameter at
+// which the ray is on one of the component's surfaces, hence inside its box.  That holds as long as no
+// leaf takes one of upstream's degenerate branches *spuriously* -- `isclose(a, 0)` / `isclose(d_z, 0)` with
+// their absolute 1e-8 thresholds on object-space quantities (primitives.py:346, 531, 683) fire for any ray
+// whose object-space direction is short, not only for one that really is parallel, and what the
+// branch then reports (e.g. the paraboloid's -c / b) is not a point of the surface.  So every cull
+// step carries the squared world-space direction length below which that can happen for one of its
+// leaves -- 1e-3 over the smallest squared singular value of the leaf's M^-1, i.e. |d_obj|^2 >= 1e-3:
+// a branch that fires there (|d_obj,xy|^2 <= 1e-8) means sin^2 of the angle to the axis <= 1e-5, and
+// the point its linear root names is off the surface by about that times the squared distance
+// travelled, far inside the 1e-3-of-the-diagonal padding for anything an optical bench holds -- and
+// may_reach lets shorter directions through.  For unit directions and objects of ordinary size the bound
+// is far below 1; for an object scaled up by more than ~30 it exceeds 1 and the component is simply
+// never culled.  (Found by the adv_still fixture.)
+static double min_singular_sq(const double* minv) {
+  // smallest eigenvalue of B = A^T A, A = the 3x3 linear part of the row-major 4x4 M^-1 (analytic
+  // symmetric 3x3 eigenvalues; the result is halved to stay below rounding)
+  double a[3][3], b[3][3];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) a[r][c] = minv[4 * r + c];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) b[i][j] = a[0][i] * a[0][j] + a[1][i] * a[1][j] + a[2][i] * a[2][j];
+  const double p1 = b[0][1] * b[0][1] + b[0][2] * b[0][2] + b[1][2] * b[1][2];
+  const double q = (b[0][0] + b[1][1] + b[2][2]) / 3.0;
+  if (p1 == 0.0) return 0.5 * std::min(b[0][0], std::min(b[1][1], b[2][2]));
+  const double p2 = (b[0][0] - q) * (b[0][0] - q) + (b[1][1] - q) * (b[1][1] - q) + (b[2][2] - q) * (b[2][2] - q) + 2 * p1;
+  const double p = std::sqrt(p2 / 6.0);
+  double c[3][3];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) c[i][j] = (b[i][j] - (i == j ? q : 0.0)) / p;
+  double det = c[0][0] * (c[1][1] * c[2][2] - c[1][2] * c[2][1]) - c[0][1] * (c[1][0] * c[2][2] - c[1][2] * c[2][0]) +
+               c[0][2] * (c[1][0] * c[2][1] - c[1][1] * c[2][0]);
+  const double rr = std::max(-1.0, std::min(1.0, det / 2.0));
+  const double phi = std::acos(rr) / 3.0;
+  const double smallest = q + 2 * p * std::cos(phi + 2.0943951023931953);  // + 2 pi / 3: the smallest root
+  return 0.5 * std::max(0.0, smallest);
+}
+static double short_direction_bound(const prt_scene* s, int node) {
+  const prt_node& n = s->nodes[node];
+  if (n.op != PRT_NODE_LEAF) return std::max(short_direction_bound(s, n.left), short_direction_bound(s, n.right));
+  const double sigma2 = min_singular_sq(s->prims[n.prim].minv);
+  return sigma2 > 0 ? 1e-3 / sigma2 : HUGE_VAL;
+}
+
 // count the steps of one kind in a program (a chain record spans CHAIN_SLOTS raw slots)
 static int count_steps(const std::vector<DevInstr>& code, int kind) {
   int n = 0;
@@ -385,6 +427,7 @@ static Operand compile_component(const prt_scene* s, int root_node, std::vector<
     double* box = in.data;
     if (solid_bounds(s, root_node, box)) {
       pad_box(box);
+      box[6] = short_direction_bound(s, root_node);
       box_at = code.size();
       code.push_back(in);
     }
@@ -452,9 +495,11 @@ static void compile_trace_run(prt_scene* s, int lo, int hi, bool grouped) {
       double* box = in.data;
       bool ok = true;
       for (int k = 0; k < 3; ++k) { box[2 * k] = HUGE_VAL; box[2 * k + 1] = -HUGE_VAL; }
+      double short_bound = 0.0;
       for (int c = at; c < end && ok; ++c) {
         double member[6];
         ok = solid_bounds(s, s->roots[c], member);
+        short_bound = std::max(short_bound, short_direction_bound(s, s->roots[c]));
         for (int k = 0; k < 3 && ok; ++k) {
           box[2 * k] = std::min(box[2 * k], member[2 * k]);
           box[2 * k + 1] = std::max(box[2 * k + 1], member[2 * k + 1]);
@@ -462,6 +507,7 @@ static void compile_trace_run(prt_scene* s, int lo, int hi, bool grouped) {
       }
       if (ok) {
         pad_box(box);
+        box[6] = short_bound;
         box_at = prog.code.size();
         prog.code.push_back(in);
       }

@@ -445,6 +445,46 @@ def adv_condenser(api):
     return [body, mirror, det], _rays_from(o, d, wavelength=0.59)
 
 
+def adv_still(api):
+    """Rays that do not move, or hardly: every component of the direction at or below numpy's isclose
+    threshold.  A CSG node drops such a ray whatever its children report (its cull box returns no finite
+    entry, csg.py:126-128) -- and a paraboloid child does report something, the finite -c / 1 of its
+    linear branch (primitives.py:361).  Found by fuzz seed 8061: a DIFFERENCE of two paraboloids."""
+    cg, matl = api.cg, api.materials
+    glass, mirror = matl.glass["BK7"], matl.mirror
+    twin = cg.csg.difference(
+        cg.Paraboloid(0.6, 1.2, material=glass).rotate_x(40).rotate_z(-25),
+        cg.Paraboloid(0.45, 1.0, material=glass).rotate_y(15).move(0.1, 0.05, 0.2),
+    ).move(-0.8, 0.0, -0.6)
+    capped = cg.csg.intersect(
+        cg.Paraboloid(0.5, 1.5, material=mirror),
+        cg.Cylinder(0.9, 0.2, 1.2, material=mirror),
+    ).move(1.5, 0.3, 0.0)
+    mixed = cg.csg.union(
+        cg.Sphere(0.7, material=glass),
+        cg.Cuboid.from_sides(1.0, 0.6, 0.8, material=glass).move(0.5, 0.0, 0.0),
+    ).move(0.0, 2.0, 0.5)
+    bare = cg.Paraboloid(0.4, 1.0, material=matl.absorber).move(0.0, -2.0, -0.5)
+    o, d = [], []
+    grid = np.linspace(-1.0, 1.0, 5)
+    for centre in ((-0.8, 0.0, -0.2), (1.5, 0.3, 0.6), (0.2, 2.0, 0.5), (0.0, -2.0, 0.0)):
+        for gx in grid:
+            for gy in grid[::2]:
+                for gz in grid:
+                    origin = [centre[0] + 0.6 * gx, centre[1] + 0.6 * gy, centre[2] + 0.6 * gz]
+                    o.append(origin); d.append([0.0, 0.0, 0.0])
+        for vec in ([1e-8, 0.0, 0.0], [1e-8, -1e-8, 1e-8], [5e-9, 5e-9, -5e-9], [1.001e-8, 0.0, 0.0],
+                    [0.0, 2e-8, 0.0], [1e-8, 1e-8, 2e-8], [0.0, 0.0, -1e-8], [3e-7, 0.0, 1e-9]):
+            for gx in grid[1::2]:
+                o.append([centre[0] + 0.3 * gx, centre[1] + 0.1, centre[2] + 0.2 * gx]); d.append(vec)
+    # ordinary rays through the same places, so that the fixture also carries real hits
+    for centre in ((-0.8, 0.0, -0.2), (1.5, 0.3, 0.6), (0.2, 2.0, 0.5), (0.0, -2.0, 0.0)):
+        for src in ((-4.0, 0.2, 0.1), (0.3, 4.0, -0.2), (0.1, -0.3, 4.0)):
+            oo, dd = _aimed(src, [np.asarray(centre) + 0.25 * np.array([gx, -gx, 0.5 * gx]) for gx in grid])
+            o += oo; d += dd
+    return [twin, capped, mixed, bare], _rays_from(o, d, wavelength=0.55)
+
+
 # ---------------------------------------------------------------------------------------------
 # renderer views (tinygfx/g3d/renderers.py): (surfaces, camera, light position)
 # ---------------------------------------------------------------------------------------------
@@ -547,4 +587,5 @@ SCENES = {
     "adv_stop": adv_stop,
     "adv_prism": adv_prism,
     "adv_condenser": adv_condenser,
+    "adv_still": adv_still,
 }

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""One seed of tests/test_gpu_fuzz.py::test_random_scene, verbosely: which rays differ between the HIP engine
+and the C oracle, under which program forms.  usage: diag_fuzz.py <seed> [out.npz]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import numpy as np, torch
+import helpers, scenes, test_gpu_fuzz as fz
+from oracle import c_oracle, prt_oracle
+from pyrayt_amd.engine import DeviceScene
+from pyrayt_amd.g3d.objects import CountedObject
+from pyrayt_amd.scene import SceneSnapshot
+
+seed = int(sys.argv[1])
+api = scenes.product_api()
+rng = np.random.default_rng(1000 + seed)
+CountedObject.reset_ids()
+parts = []
+for _ in range(rng.integers(1, 5)):
+    comp = fz.random_component(rng, api.cg, api.materials, depth=int(rng.integers(0, 4)))
+    comp.move(*rng.uniform(-2.0, 2.0, 3))
+    parts.append(comp)
+rays = scenes.random_rays(20_000, seed=5000 + seed, box=4.0, wavelength=0.55)
+rays[10] = rng.uniform(0.4, 0.8, rays.shape[1])
+snap = SceneSnapshot(parts)
+flat = helpers.flat_scene(snap)
+want_t, want_surf = c_oracle.propagate(flat, rays)
+np_t, np_surf = prt_oracle.propagate(flat, rays)
+print("numpy oracle == C oracle:", np.array_equal(np_surf, want_surf))
+for env in ({}, {"PRT_NO_CULL": "1"}, {"PRT_NO_CHAIN": "1"}, {"PRT_NO_CULL": "1", "PRT_NO_CHAIN": "1"}):
+    for k in ("PRT_NO_CULL", "PRT_NO_CHAIN"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    ds = DeviceScene(snap)
+    t, surf = ds.propagate(torch.from_numpy(rays).cuda())
+    surf, t = surf.cpu().numpy(), t.cpu().numpy()
+    bad = np.nonzero(surf != want_surf)[0]
+    print(env, ds.info(), "mismatching rays:", bad[:10], [(int(surf[i]), int(want_surf[i]), t[i], want_t[i]) for i in bad[:5]])
+    ds.close()
+if len(sys.argv) > 2:
+    np.savez(sys.argv[2], rays=rays, prims=snap.prims, nodes=snap.nodes, roots=snap.roots, materials=snap.materials)
+for i in np.nonzero(surf != want_surf)[0][:3]:
+    print("ray", i, "o", rays[0:4, i].tolist(), "d", rays[4:8, i].tolist())
