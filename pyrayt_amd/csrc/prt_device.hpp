@@ -651,6 +651,7 @@ __device__ unsigned long long g_slow[4];  // [0] implied nodes with survivors, [
 // parities, the keep rule per operation and the (lazily evaluated) cull box.  Neither list has to
 // be sorted or compacted for this: every quantity is a count of entries of the *other* list that
 // sort before an entry, and a dropped entry left in place as +inf sorts before nothing finite.
+#define kImpliedMinLen2 1e-2 /* see csg_keep and prt_scene.hpp box_contains_solid */
 template <int ML, int MR>
 __device__ __forceinline__ void csg_keep(int op, const double (&lv)[ML], const double (&rv)[MR],
                                          const double* __restrict__ aabb, const Ray8& ray,
@@ -701,7 +702,12 @@ __device__ __forceinline__ void csg_keep(int op, const double (&lv)[ML], const d
       hi = fmax(hi, keep_r[j] ? rv[j] : -PRT_INF);
     }
     const bool any = hi >= lo;  // false when nothing survived (lo = +inf, hi = -inf)
-    const bool robust = any && lo > -PRT_INF && (hi - lo) > 1e-6 * ((1.0 + fabs(lo)) + fabs(hi));
+    // (a short direction -- |d|^2 < 1e-2; the scene compiler implies the box only for nodes whose leaves
+    // keep unit directions at |d_obj|^2 >= 0.1 -- may send a leaf into one of upstream's degenerate
+    // branches without being parallel to anything, and what survives then need not lie in the solid:
+    // the exact test decides, like for a thin chord.  Found by the short-direction fuzz family.)
+    const bool short_d = (ray.dx * ray.dx + ray.dy * ray.dy) + ray.dz * ray.dz < kImpliedMinLen2;
+    const bool robust = any && !short_d && lo > -PRT_INF && (hi - lo) > 1e-6 * ((1.0 + fabs(lo)) + fabs(hi));
     PRT_COUNT(0, any);
     PRT_COUNT(1, any && !robust);
     if (any && !robust) touched = box_touched(aabb, ray);
@@ -896,9 +902,16 @@ __device__ __forceinline__ void chain_candidate(const DevChain* __restrict__ ch,
   } else {
     const double l4[4] = {keep_l[0] ? lv[0] : PRT_INF, keep_l[1] ? lv[1] : PRT_INF,
                           keep_r[0] ? rv[0] : PRT_INF, keep_r[1] ? rv[1] : PRT_INF};
+    // a positive survivor, or an odd number of crossings behind the ray: it is inside the first node's
+    // solid at 0+ (see the interpreter's right-leaf skip)
     bool positive = false;
+    int behind = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) positive = positive || (l4[k] > 0 && l4[k] < PRT_INF);
+    for (int k = 0; k < 4; ++k) {
+      positive = positive || (l4[k] > 0 && l4[k] < PRT_INF);
+      behind += l4[k] <= 0 ? 1 : 0;
+    }
+    positive = positive || (behind & 1);
     if (ch->op2 != CSG_UNION && __ballot(positive) == 0ull) return;
     double r2[2];
     surface_pair(T2 < 0 ? 0 : T2, ch->leaf[2], ch->leaf[2] + 6, ray, r2[0], r2[1]);
@@ -947,15 +960,23 @@ __device__ __forceinline__ void run_step(const DevInstr* in, const Ray8& ray, co
     if (in->pad[0] == 1) {
       // right leaf of an INTERSECT / DIFFERENCE node: not worth evaluating for this wave when no
       // lane's left operand (a3 mode, a4 base, a5 length) holds a positive entry
+      // "positive": a finite entry beyond 0 -- or the ray is inside the left solid at 0+, which the
+      // boundary crossings behind it tell by their parity (they alternate enter / exit): a slab or
+      // linear branch that reports (-inf, +inf) or (-5, +inf) has no finite positive entry and is all
+      // around the ray nevertheless (found by the short-direction fuzz family)
       bool has_positive;
       if (in->a3 == OPER_LDS) {
         has_positive = false;
+        int behind = 0;
         for (int k = 0; k < in->a5; ++k) {
           const double v = lists.get_t(in->a4 + k);
           has_positive = has_positive || (v > 0 && v < PRT_INF);
+          behind += v <= 0 ? 1 : 0;
         }
+        has_positive = has_positive || (behind & 1);
       } else {
-        has_positive = (ra.t0 > 0 && ra.t0 < PRT_INF) || (ra.t1 > 0 && ra.t1 < PRT_INF);
+        has_positive = (ra.t0 > 0 && ra.t0 < PRT_INF) || (ra.t1 > 0 && ra.t1 < PRT_INF) ||
+                       ((ra.t0 <= 0) != (ra.t1 <= 0));
       }
       if (__ballot(has_positive) == 0ull) {
         rb.t0 = PRT_INF; rb.t1 = PRT_INF; rb.prim = p;

@@ -102,6 +102,8 @@ static int leaves_under(const prt_scene* s, int node) {
 // one a further len(right) slots down so the same argument holds for the left one.
 static bool solid_bounds(const prt_scene* s, int node, double* box);
 
+static double short_direction_bound(const prt_scene* s, int node);
+
 struct Compiler {
   const prt_scene* s;
   std::vector<DevInstr>& out;
@@ -141,7 +143,11 @@ struct Compiler {
   // 500-seed fuzz tier: a stale, empty box culls every ray upstream).
   bool box_contains_solid(int node) const {
     const prt_node& n = s->nodes[node];
+    if (std::getenv("PRT_NO_IMPLIED") != nullptr) return false;  // test knob: every node tests its cull box exactly
     if (n.op == PRT_NODE_LEAF) return true;
+    // the argument needs every leaf to see directions of length >= 0.1 in object space as long as
+    // the world direction has |d|^2 >= kImpliedMinLen2 (csg_keep sends shorter ones to the exact test)
+    if (short_direction_bound(s, node) > kImpliedMinLen2) return false;
     bool structural = false;
     if (n.op == PRT_NODE_INTERSECT) structural = box_contains_solid(n.left) && box_contains_solid(n.right);
     if (n.op == PRT_NODE_DIFFERENCE) structural = box_contains_solid(n.left);

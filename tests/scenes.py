@@ -485,6 +485,43 @@ def adv_still(api):
     return [twin, capped, mixed, bare], _rays_from(o, d, wavelength=0.55)
 
 
+def _fuzz_scene(api, seed, n_rays=1500):
+    """Scene `seed` of tests/test_gpu_fuzz.py::test_random_scene (random CSG trees under random transforms)
+    with the rays whose directions were rescaled to lengths 1e-9 ... 10, and as many ordinary ones."""
+    import test_gpu_fuzz as fz
+
+    rng = np.random.default_rng(1000 + seed)
+    parts = []
+    for _ in range(rng.integers(1, 5)):
+        comp = fz.random_component(rng, api.cg, api.materials, depth=int(rng.integers(0, 4)))
+        comp.move(*rng.uniform(-2.0, 2.0, 3))
+        parts.append(comp)
+    rays = random_rays(20_000, seed=5000 + seed, box=4.0, wavelength=0.55)
+    rays[10] = rng.uniform(0.4, 0.8, rays.shape[1])
+    short = rng.choice(rays.shape[1] - 1000, size=600, replace=False) + 500
+    rays[4:7, short] *= 10.0 ** rng.uniform(-9.0, 1.0, size=600)
+    pick = np.concatenate([np.sort(short), np.arange(0, 20_000, 20_000 // (n_rays - 600))[: n_rays - 600]])
+    pick = np.unique(pick)
+    sub = np.ascontiguousarray(rays[:, pick])
+    sub[12] = np.arange(sub.shape[1])
+    return parts, sub
+
+
+def adv_short_a(api):
+    """Fuzz seed 53500: a slab that is all around a ray of length 1e-8 (-inf, +inf) and the sphere it cuts."""
+    return _fuzz_scene(api, 53500)
+
+
+def adv_short_b(api):
+    """Fuzz seed 50663: directions of length 1e-4 ... 1e-3 whose degenerate-branch hits upstream's cull box drops."""
+    return _fuzz_scene(api, 50663)
+
+
+def adv_short_c(api):
+    """Fuzz seed 32209: sixteen primitives in three deep trees, rays of length 1e-8."""
+    return _fuzz_scene(api, 32209)
+
+
 # ---------------------------------------------------------------------------------------------
 # renderer views (tinygfx/g3d/renderers.py): (surfaces, camera, light position)
 # ---------------------------------------------------------------------------------------------
@@ -588,4 +625,7 @@ SCENES = {
     "adv_prism": adv_prism,
     "adv_condenser": adv_condenser,
     "adv_still": adv_still,
+    "adv_short_a": adv_short_a,
+    "adv_short_b": adv_short_b,
+    "adv_short_c": adv_short_c,
 }

@@ -22,22 +22,39 @@ for _ in range(rng.integers(1, 5)):
     parts.append(comp)
 rays = scenes.random_rays(20_000, seed=5000 + seed, box=4.0, wavelength=0.55)
 rays[10] = rng.uniform(0.4, 0.8, rays.shape[1])
+short = rng.choice(rays.shape[1] - 1000, size=600, replace=False) + 500
+rays[4:7, short] *= 10.0 ** rng.uniform(-9.0, 1.0, size=600)
 snap = SceneSnapshot(parts)
 flat = helpers.flat_scene(snap)
 want_t, want_surf = c_oracle.propagate(flat, rays)
 np_t, np_surf = prt_oracle.propagate(flat, rays)
 print("numpy oracle == C oracle:", np.array_equal(np_surf, want_surf))
-for env in ({}, {"PRT_NO_CULL": "1"}, {"PRT_NO_CHAIN": "1"}, {"PRT_NO_CULL": "1", "PRT_NO_CHAIN": "1"}):
-    for k in ("PRT_NO_CULL", "PRT_NO_CHAIN"):
+for env in ({}, {"PRT_NO_CULL": "1"}, {"PRT_NO_IMPLIED": "1"}, {"PRT_NO_CULL": "1", "PRT_NO_CHAIN": "1", "PRT_NO_IMPLIED": "1"}):
+    for k in ("PRT_NO_CULL", "PRT_NO_CHAIN", "PRT_NO_IMPLIED"):
         os.environ.pop(k, None)
     os.environ.update(env)
     ds = DeviceScene(snap)
     t, surf = ds.propagate(torch.from_numpy(rays).cuda())
     surf, t = surf.cpu().numpy(), t.cpu().numpy()
     bad = np.nonzero(surf != want_surf)[0]
-    print(env, ds.info(), "mismatching rays:", bad[:10], [(int(surf[i]), int(want_surf[i]), t[i], want_t[i]) for i in bad[:5]])
+    print(env, "mismatching rays:", bad[:10], [(int(surf[i]), int(want_surf[i]), t[i], want_t[i]) for i in bad[:5]])
     ds.close()
 if len(sys.argv) > 2:
     np.savez(sys.argv[2], rays=rays, prims=snap.prims, nodes=snap.nodes, roots=snap.roots, materials=snap.materials)
 for i in np.nonzero(surf != want_surf)[0][:3]:
-    print("ray", i, "o", rays[0:4, i].tolist(), "d", rays[4:8, i].tolist())
+    print("ray", i, "o", rays[0:4, i].tolist(), "d", rays[4:8, i].tolist(), "|d|", np.linalg.norm(rays[4:7, i]))
+
+# per component: the engine's hit list against the numpy oracle's, for the first mismatching ray
+bad = np.nonzero(surf != want_surf)[0]
+if len(bad):
+    i = int(bad[0])
+    for k in ("PRT_NO_CULL", "PRT_NO_CHAIN", "PRT_NO_IMPLIED"):
+        os.environ.pop(k, None)
+    ds = DeviceScene(snap)
+    one = np.ascontiguousarray(rays[:, i:i + 1])
+    for root in range(len(flat["roots"])):
+        hits, ids = ds.intersect(root, torch.from_numpy(one).cuda())
+        want_h, want_i = prt_oracle.component_hits(flat, root, one[:8].reshape(2, 4, 1))
+        print("component", root, "\n   engine", hits.cpu().numpy().ravel(), ids.cpu().numpy().ravel(),
+              "\n   oracle", np.asarray(want_h).ravel(), np.asarray(want_i).ravel())
+    ds.close()
