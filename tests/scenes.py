@@ -485,15 +485,47 @@ def adv_still(api):
     return [twin, capped, mixed, bare], _rays_from(o, d, wavelength=0.55)
 
 
+# the generator of tests/test_gpu_fuzz.py::test_random_scene (here so that fixtures can be cut from its seeds)
+def random_surface(rng, cg, matl):
+    material = [matl.absorber, matl.mirror, matl.glass["ideal"], matl.glass["BK7"], matl.glass["SF2"]][
+        rng.integers(0, 5)]
+    kind = rng.integers(0, 5)
+    if kind == 0:
+        s = cg.Sphere(rng.uniform(0.4, 1.2), material=material)
+    elif kind == 1:
+        s = cg.Cylinder(rng.uniform(0.3, 0.9), -rng.uniform(0.2, 1.0), rng.uniform(0.2, 1.0), material=material)
+    elif kind == 2:
+        s = cg.XYPlane(rng.uniform(1.0, 3.0), rng.uniform(1.0, 3.0), material=material)
+    elif kind == 3:
+        s = cg.Cuboid.from_sides(*rng.uniform(0.5, 1.8, 3), material=material)
+    else:
+        s = cg.Paraboloid(rng.uniform(0.3, 1.0), rng.uniform(0.5, 1.5), material=material)
+    if rng.random() < 0.5:
+        s.scale(*rng.uniform(0.6, 1.5, 3))
+    s.rotate_x(rng.uniform(-180, 180)).rotate_y(rng.uniform(-180, 180)).rotate_z(rng.uniform(-180, 180))
+    s.move(*rng.uniform(-0.6, 0.6, 3))
+    return s
+
+
+def random_component(rng, cg, matl, depth):
+    if depth == 0 or rng.random() < 0.25:
+        return random_surface(rng, cg, matl)
+    op = [cg.csg.union, cg.csg.intersect, cg.csg.difference][rng.integers(0, 3)]
+    left = random_component(rng, cg, matl, depth - 1)
+    right = random_component(rng, cg, matl, depth - 1)
+    node = op(left, right)
+    if rng.random() < 0.5:
+        node.rotate_z(rng.uniform(-90, 90)).move(*rng.uniform(-0.3, 0.3, 3))
+    return node
+
+
 def _fuzz_scene(api, seed, n_rays=1500):
     """Scene `seed` of tests/test_gpu_fuzz.py::test_random_scene (random CSG trees under random transforms)
     with the rays whose directions were rescaled to lengths 1e-9 ... 10, and as many ordinary ones."""
-    import test_gpu_fuzz as fz
-
     rng = np.random.default_rng(1000 + seed)
     parts = []
     for _ in range(rng.integers(1, 5)):
-        comp = fz.random_component(rng, api.cg, api.materials, depth=int(rng.integers(0, 4)))
+        comp = random_component(rng, api.cg, api.materials, depth=int(rng.integers(0, 4)))
         comp.move(*rng.uniform(-2.0, 2.0, 3))
         parts.append(comp)
     rays = random_rays(20_000, seed=5000 + seed, box=4.0, wavelength=0.55)

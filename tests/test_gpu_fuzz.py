@@ -13,37 +13,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-def random_surface(rng, cg, matl):
-    material = [matl.absorber, matl.mirror, matl.glass["ideal"], matl.glass["BK7"], matl.glass["SF2"]][
-        rng.integers(0, 5)]
-    kind = rng.integers(0, 5)
-    if kind == 0:
-        s = cg.Sphere(rng.uniform(0.4, 1.2), material=material)
-    elif kind == 1:
-        s = cg.Cylinder(rng.uniform(0.3, 0.9), -rng.uniform(0.2, 1.0), rng.uniform(0.2, 1.0), material=material)
-    elif kind == 2:
-        s = cg.XYPlane(rng.uniform(1.0, 3.0), rng.uniform(1.0, 3.0), material=material)
-    elif kind == 3:
-        s = cg.Cuboid.from_sides(*rng.uniform(0.5, 1.8, 3), material=material)
-    else:
-        s = cg.Paraboloid(rng.uniform(0.3, 1.0), rng.uniform(0.5, 1.5), material=material)
-    if rng.random() < 0.5:
-        s.scale(*rng.uniform(0.6, 1.5, 3))
-    s.rotate_x(rng.uniform(-180, 180)).rotate_y(rng.uniform(-180, 180)).rotate_z(rng.uniform(-180, 180))
-    s.move(*rng.uniform(-0.6, 0.6, 3))
-    return s
-
-
-def random_component(rng, cg, matl, depth):
-    if depth == 0 or rng.random() < 0.25:
-        return random_surface(rng, cg, matl)
-    op = [cg.csg.union, cg.csg.intersect, cg.csg.difference][rng.integers(0, 3)]
-    left = random_component(rng, cg, matl, depth - 1)
-    right = random_component(rng, cg, matl, depth - 1)
-    node = op(left, right)
-    if rng.random() < 0.5:
-        node.rotate_z(rng.uniform(-90, 90)).move(*rng.uniform(-0.3, 0.3, 3))
-    return node
+random_surface, random_component = scenes.random_surface, scenes.random_component  # (shared with the fuzz-seed fixtures)
 
 
 def _seeds():
