@@ -706,7 +706,10 @@ __device__ __forceinline__ void csg_keep(int op, const double (&lv)[ML], const d
     // keep unit directions at |d_obj|^2 >= 0.1 -- may send a leaf into one of upstream's degenerate
     // branches without being parallel to anything, and what survives then need not lie in the solid:
     // the exact test decides, like for a thin chord.  Found by the short-direction fuzz family.)
-    const bool short_d = (ray.dx * ray.dx + ray.dy * ray.dy) + ray.dz * ray.dz < kImpliedMinLen2;
+    // (likewise a ray with homogeneous w components other than 1 / 0: its object-space image is
+    // M^-1 (o, w), not the image of the world ray the box was tested against)
+    const bool short_d = (ray.dx * ray.dx + ray.dy * ray.dy) + ray.dz * ray.dz < kImpliedMinLen2 ||
+                         ray.ow != 1.0 || ray.dw != 0.0;
     const bool robust = any && !short_d && lo > -PRT_INF && (hi - lo) > 1e-6 * ((1.0 + fabs(lo)) + fabs(hi));
     PRT_COUNT(0, any);
     PRT_COUNT(1, any && !robust);
@@ -1043,9 +1046,10 @@ __device__ __forceinline__ void run_step(const DevInstr* in, const Ray8& ray, co
 // step record is fetched once (one batch of scalar loads) and applied to the lane's R rays,
 // whose arithmetic is independent and interleaves.
 // CULL: the program may contain I_BOX steps (compiled out of the kernels that never see one).
-// ANY_W: the rays may carry an origin w other than 1 (the object-space origin is then M^-1 (o, w), not
-// the image of the world point o: _pyrayt.py / world_objects.py:360-383 multiply the translation by w),
-// which the cull steps' world-space argument does not cover: such a ray takes every component.
+// ANY_W: the rays may carry homogeneous w components other than 1 / 0 (the object-space ray is then
+// M^-1 (o, w_o), M^-1 (d, w_d), not the image of the world ray: world_objects.py:360-383 multiplies the
+// translation by w), which the cull steps' world-space argument does not cover: such a ray takes
+// every component.
 template <int R, bool RENDER = false, bool CULL = true, bool ANY_W = true>
 __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code, int n_instr,
                                               const Ray8 (&ray)[R], int slots, double (&best_t)[R],
@@ -1071,7 +1075,8 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
     if (CULL && !RENDER && step.kind == I_BOX) {
       bool wanted = false;
 #pragma unroll
-      for (int k = 0; k < R; ++k) wanted = wanted || may_reach(step.data, ray[k], best_t[k]) || (ANY_W && ray[k].ow != 1.0);
+      for (int k = 0; k < R; ++k)
+        wanted = wanted || may_reach(step.data, ray[k], best_t[k]) || (ANY_W && (ray[k].ow != 1.0 || ray[k].dw != 0.0));
       PRT_COUNT(2, true);
       PRT_COUNT(3, !wanted);
       if (__ballot(wanted) == 0ull) pc += step.a0;  // no lane of the wave needs this component
@@ -1102,7 +1107,7 @@ __device__ __forceinline__ void component_candidate(const DevInstr* code, int fi
       chain_step(reinterpret_cast<const DevChain*>(in), in->a0, ray, t, prim);
       pc += CHAIN_SLOTS - 1;
     } else if (kind == I_BOX) {
-      if (ray.ow == 1.0 && !may_reach(in->data, ray, PRT_INF)) return;  // the cull step leads its component
+      if (ray.ow == 1.0 && ray.dw == 0.0 && !may_reach(in->data, ray, PRT_INF)) return;  // the cull step leads its component
     } else {
       run_step<false>(in, ray, lists, ra, rb, t, prim);
     }

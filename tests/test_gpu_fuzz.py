@@ -43,6 +43,10 @@ def test_random_scene(seed):
     # (absolute thresholds) fire for short directions whether or not they are parallel to anything
     short = rng.choice(rays.shape[1] - 1000, size=600, replace=False) + 500
     rays[4:7, short] *= 10.0 ** rng.uniform(-9.0, 1.0, size=600)
+    # ... nor does it insist on homogeneous coordinates being 1 / 0: the 4x4 transforms take whatever is there
+    odd = rng.choice(400, size=40, replace=False) + 19_000
+    rays[3, odd[:20]] = rng.uniform(0.3, 3.0, 20) * rng.choice([-1.0, 1.0], 20)
+    rays[7, odd[20:]] = 10.0 ** rng.uniform(-6.0, -1.0, 20) * rng.choice([-1.0, 1.0], 20)
     snap = SceneSnapshot(parts)
     flat = helpers.flat_scene(snap)
     ds = DeviceScene(snap)
