@@ -124,6 +124,14 @@ def test_random_bench(seed):
     n = int(rng.choice([3_000, 20_000, 33_333]))
     rays = scenes.cone_rays(n, (-1.5, 0.0, 0.0), float(rng.uniform(2.0, 12.0)), 6000 + seed,
                             wavelength=float(rng.uniform(0.45, 0.7)))
+    # a few rays of the families that are not optics any more but that upstream traces all the same: directions
+    # of any length, homogeneous coordinates other than 1 / 0 (every third seed, so that most benches keep
+    # the compact state form and the rest exercise the fall-back to all 13 rows)
+    odd = rng.choice(n, size=60, replace=False)
+    rays[4:7, odd[:40]] *= 10.0 ** rng.uniform(-9.0, 1.0, size=40)
+    if seed % 3 == 0:
+        rays[3, odd[40:50]] = rng.uniform(0.3, 3.0, 10)
+        rays[7, odd[50:]] = 10.0 ** rng.uniform(-6.0, -1.0, 10)
     snap = SceneSnapshot(parts)
     flat = helpers.flat_scene(snap)
     limit = int(rng.integers(3, 14))
