@@ -56,6 +56,22 @@ def test_random_scene(seed):
     want_t, want_surf = c_oracle.propagate(flat, rays)
     assert np.array_equal(surf.cpu().numpy(), want_surf)
     assert np.allclose(t.cpu().numpy(), want_t, rtol=0, atol=helpers.ATOL)
+    # every component's own hit list (component.intersect(), csg.py:118-160) on a slice that holds all
+    # the degenerate families: values where finite, ids where the list has an entry
+    from oracle import prt_oracle
+
+    sub = np.concatenate([np.arange(0, 600), short[:300], odd, [rays.shape[1] - 1]])
+    rays8 = np.ascontiguousarray(rays[:8, sub])
+    for root in range(len(flat["roots"])):
+        hits, ids = ds.intersect(root, torch.from_numpy(rays8).to("cuda:0"))
+        want_hits, want_ids = prt_oracle.component_hits(flat, root, rays8.reshape(2, 4, -1))
+        got_hits, got_ids = hits.cpu().numpy(), ids.cpu().numpy()
+        want_hits = np.where(np.isnan(want_hits), np.inf, want_hits)       # upstream's NaN = miss
+        finite = np.isfinite(want_hits)
+        assert np.array_equal(np.isfinite(got_hits), finite), (seed, root)
+        assert np.allclose(got_hits[finite], want_hits[finite], rtol=1e-12, atol=helpers.ATOL), (seed, root)
+        assert np.array_equal(np.isneginf(got_hits), np.isneginf(want_hits)), (seed, root)
+        assert np.array_equal(got_ids[finite], np.asarray(want_ids)[finite]), (seed, root)
     # whole trace, reference-faithful bookkeeping (absorbed rays carried) and the default
     want, want_counts = c_oracle.trace(flat, rays, 6)
     for flags in (0, 1, 2):
