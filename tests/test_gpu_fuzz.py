@@ -37,6 +37,12 @@ def test_random_scene(seed):
         comp = random_component(rng, api.cg, api.materials, depth=int(rng.integers(0, 4)))
         comp.move(*rng.uniform(-2.0, 2.0, 3))
         parts.append(comp)
+    if seed % 7 == 3:  # a crowd of small parts: cull steps over runs of components, with rays from everywhere
+        crowd = np.random.default_rng(31_000 + seed)
+        for _ in range(int(crowd.integers(5, 10))):
+            comp = random_component(crowd, api.cg, api.materials, depth=int(crowd.integers(0, 3)))
+            comp.scale(*crowd.uniform(0.3, 0.7, 3)).move(*crowd.uniform(-3.0, 3.0, 3))
+            parts.append(comp)
     rays = scenes.random_rays(20_000, seed=5000 + seed, box=4.0, wavelength=0.55)
     rays[10] = rng.uniform(0.4, 0.8, rays.shape[1])
     # directions of any length: upstream never normalises what it is given, and its isclose() branches
