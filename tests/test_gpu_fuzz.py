@@ -17,10 +17,11 @@ random_surface, random_component = scenes.random_surface, scenes.random_componen
 
 
 def _seeds():
-    # the everyday tier, and the 500-seed tier for gpurun sessions: PRT_FUZZ_SEEDS=500 pytest -m gpu ...
+    # the everyday tier, and the soak tiers for gpurun sessions: PRT_FUZZ_SEEDS=60000 [PRT_FUZZ_FIRST=60000] pytest -m gpu -n 6 ...
     import os
 
-    return range(int(os.environ.get("PRT_FUZZ_SEEDS", "24")))
+    first = int(os.environ.get("PRT_FUZZ_FIRST", "0"))
+    return range(first, first + int(os.environ.get("PRT_FUZZ_SEEDS", "24")))
 
 
 @pytest.mark.parametrize("seed", _seeds())
@@ -43,6 +44,10 @@ def test_random_scene(seed):
             comp = random_component(crowd, api.cg, api.materials, depth=int(crowd.integers(0, 3)))
             comp.scale(*crowd.uniform(0.3, 0.7, 3)).move(*crowd.uniform(-3.0, 3.0, 3))
             parts.append(comp)
+    if seed % 11 == 5:  # parts of any size: upstream's absolute thresholds meet object-space directions of any length
+        giant = np.random.default_rng(57_000 + seed)
+        for comp in parts[: int(giant.integers(1, 3))]:
+            comp.scale(*(10.0 ** giant.uniform(-2.0, 2.5, 3)))
     rays = scenes.random_rays(20_000, seed=5000 + seed, box=4.0, wavelength=0.55)
     rays[10] = rng.uniform(0.4, 0.8, rays.shape[1])
     # directions of any length: upstream never normalises what it is given, and its isclose() branches
