@@ -633,11 +633,40 @@ def render_inside(api):
     return [behind, ahead, lens_behind, shell, around], camera, np.array((2.0, -4.0, 9.0, 1.0))
 
 
+def _render_fuzz(api, seed, pixels=56, span=9.0):
+    """Random CSG trees (the fuzz generator's) in front of, around and behind an orthographic camera."""
+    rng = np.random.default_rng(91_000 + seed)
+    parts = []
+    for _ in range(int(rng.integers(3, 7))):
+        comp = random_component(rng, api.cg, api.materials, depth=int(rng.integers(0, 4)))
+        comp.move(*rng.uniform(-2.5, 2.5, 3)).move_x(float(rng.uniform(-1.0, 5.0)))
+        parts.append(comp)
+    camera = api.cg.OrthographicCamera(pixels, span, 0.75).rotate_z(float(rng.uniform(-8, 8))).rotate_y(
+        float(rng.uniform(-8, 8))).move_x(float(rng.uniform(-3.0, 0.5)))
+    light = np.array((float(rng.uniform(-3, 3)), float(rng.uniform(-8, 8)), 9.0, 1.0))
+    return parts, camera, light
+
+
+def render_fuzz_a(api):
+    return _render_fuzz(api, 1)
+
+
+def render_fuzz_b(api):
+    return _render_fuzz(api, 2)
+
+
+def render_fuzz_c(api):
+    return _render_fuzz(api, 3)
+
+
 RENDER_SCENES = {
     "spheres": render_spheres,
     "bench_xy": render_bench_xy,
     "bench_xz": render_bench_xz,
     "inside": render_inside,
+    "fuzz_a": render_fuzz_a,
+    "fuzz_b": render_fuzz_b,
+    "fuzz_c": render_fuzz_c,
 }
 
 
