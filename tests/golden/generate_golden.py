@@ -632,7 +632,7 @@ def main():
         scene_fixture("stopped_lens", 10, 2048, allow_sensitive=True)
     if "adversarial" in which:  # rays on the thresholds of the engine's shortcuts (tests/scenes.py adv_*)
         for name in ("adv_lens", "adv_stop", "adv_prism", "adv_condenser", "adv_still", "adv_short_a", "adv_short_b",
-                     "adv_short_c"):
+                     "adv_short_c", "adv_bench_a", "adv_bench_b", "adv_bench_c"):
             scene_fixture(name, 6, allow_sensitive=True)
     if "stale" in which:  # upstream's cached cull box of a right-nested tree moved after construction
         scene_fixture("stale_box", 6, 3000, allow_sensitive=True)

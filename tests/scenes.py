@@ -539,6 +539,74 @@ def _fuzz_scene(api, seed, n_rays=1500):
     return parts, sub
 
 
+def random_part(rng, c, matl):
+    glass = [matl.glass["ideal"], matl.glass["BK7"], matl.glass["SF2"], matl.glass["SF5"]][rng.integers(0, 4)]
+    ap = float(rng.uniform(0.7, 1.4)) if rng.random() < 0.7 else (float(rng.uniform(0.7, 1.3)), float(rng.uniform(0.7, 1.3)))
+    radius = lambda: float(rng.uniform(1.5, 6.0) * (1 if rng.random() < 0.5 else -1))
+    kind = rng.integers(0, 8)
+    if kind == 0:
+        r1, r2 = radius(), radius()
+        if rng.random() < 0.2:
+            r1 = np.inf
+        elif rng.random() < 0.2:
+            r2 = np.inf
+        part = c.thick_lens(r1, r2, float(rng.uniform(0.15, 0.5)), aperture=ap, material=glass)
+    elif kind == 1:
+        r = abs(radius())
+        part = c.biconvex_lens(r, r, float(rng.uniform(0.2, 0.5)), aperture=ap, material=glass)
+    elif kind == 2:
+        part = c.plano_convex_lens(abs(radius()), float(rng.uniform(0.2, 0.5)), aperture=ap, material=glass)
+    elif kind == 3:
+        part = c.equilateral_prism(float(rng.uniform(0.6, 1.2)), float(rng.uniform(0.8, 1.5)), material=glass)
+    elif kind == 4:
+        part = c.plane_mirror(float(rng.uniform(0.05, 0.2)), aperture=ap).rotate_z(float(rng.uniform(100, 170)))
+    elif kind == 5:
+        part = c.spherical_mirror(abs(radius()) + 1.0, float(rng.uniform(0.1, 0.3)), aperture=ap).rotate_z(
+            float(rng.uniform(150, 180)))
+    elif kind == 6:
+        part = c.baffle((float(rng.uniform(0.3, 1.2)), float(rng.uniform(0.3, 1.2))))
+    else:
+        part = c.parabolic_mirror(float(rng.uniform(1.0, 3.0)), float(rng.uniform(0.1, 0.3)), aperture=ap).rotate_z(
+            float(rng.uniform(150, 180)))
+    if rng.random() < 0.5:  # a little tilt and decentre
+        part.rotate_y(float(rng.uniform(-4, 4))).rotate_z(float(rng.uniform(-4, 4)))
+        part.move(0.0, float(rng.uniform(-0.05, 0.05)), float(rng.uniform(-0.05, 0.05)))
+    return part
+
+
+def _fuzz_bench(api, seed, n=2500, limit_hint=None):
+    """Optical bench `seed` of tests/test_gpu_fuzz.py::test_random_bench (a train of factory parts and a
+    detector, a coherent cone of rays plus a few of the degenerate families)."""
+    rng = np.random.default_rng(77_000 + seed)
+    n_parts = int(rng.integers(1, 6)) if rng.random() < 0.8 else int(rng.integers(8, 13))
+    parts, x = [], 0.0
+    for _ in range(n_parts):
+        parts.append(random_part(rng, api.components, api.materials).move_x(x))
+        x += float(rng.uniform(0.5, 1.8))
+    parts.append(api.components.baffle((3.0, 3.0)).move_x(x + 0.5))
+    rng.choice([3_000, 20_000, 33_333])  # (keeps the stream in step with the test)
+    rays = cone_rays(n, (-1.5, 0.0, 0.0), float(rng.uniform(2.0, 12.0)), 6000 + seed,
+                     wavelength=float(rng.uniform(0.45, 0.7)))
+    odd = rng.choice(n, size=60, replace=False)
+    rays[4:7, odd[:40]] *= 10.0 ** rng.uniform(-9.0, 1.0, size=40)
+    return parts, rays
+
+
+def adv_bench_a(api):
+    """Fuzz bench seed 3: five lenses / prisms / mirrors."""
+    return _fuzz_bench(api, 3)
+
+
+def adv_bench_b(api):
+    """Fuzz bench seed 24: five parts."""
+    return _fuzz_bench(api, 24)
+
+
+def adv_bench_c(api):
+    """Fuzz bench seed 10: a train of eleven parts (cull steps over runs of parts)."""
+    return _fuzz_bench(api, 10)
+
+
 def adv_short_a(api):
     """Fuzz seed 53500: a slab that is all around a ray of length 1e-8 (-inf, +inf) and the sphere it cuts."""
     return _fuzz_scene(api, 53500)
@@ -693,4 +761,7 @@ SCENES = {
     "adv_short_a": adv_short_a,
     "adv_short_b": adv_short_b,
     "adv_short_c": adv_short_c,
+    "adv_bench_a": adv_bench_a,
+    "adv_bench_b": adv_bench_b,
+    "adv_bench_c": adv_bench_c,
 }

@@ -21,7 +21,7 @@ def built():
 
 @pytest.mark.parametrize("name", ["config1", "config2", "config3", "config4", "config5",
                                   "two_mirrors", "tutorial", "mirrors_and_stops", "stopped_lens",
-                                  "adv_lens", "adv_stop", "adv_prism", "adv_condenser", "adv_still", "adv_short_a", "adv_short_b", "adv_short_c", "stale_box"])
+                                  "adv_lens", "adv_stop", "adv_prism", "adv_condenser", "adv_still", "adv_short_a", "adv_short_b", "adv_short_c", "adv_bench_a", "adv_bench_b", "adv_bench_c", "stale_box"])
 def test_trace_matches_reference(name):
     fx = helpers.load(f"scene_{name}.npz")
     frame, counts = c_oracle.trace(helpers.scene_of(fx), fx["rays0"], int(fx["generation_limit"]))

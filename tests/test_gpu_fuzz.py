@@ -98,39 +98,7 @@ def test_random_scene(seed):
 # parts from eight), traced repeatedly so that the second and third trace run on the dense-mode
 # hints of the one before
 # ---------------------------------------------------------------------------------------------
-def random_part(rng, c, matl):
-    glass = [matl.glass["ideal"], matl.glass["BK7"], matl.glass["SF2"], matl.glass["SF5"]][rng.integers(0, 4)]
-    ap = float(rng.uniform(0.7, 1.4)) if rng.random() < 0.7 else (float(rng.uniform(0.7, 1.3)), float(rng.uniform(0.7, 1.3)))
-    radius = lambda: float(rng.uniform(1.5, 6.0) * (1 if rng.random() < 0.5 else -1))
-    kind = rng.integers(0, 8)
-    if kind == 0:
-        r1, r2 = radius(), radius()
-        if rng.random() < 0.2:
-            r1 = np.inf
-        elif rng.random() < 0.2:
-            r2 = np.inf
-        part = c.thick_lens(r1, r2, float(rng.uniform(0.15, 0.5)), aperture=ap, material=glass)
-    elif kind == 1:
-        r = abs(radius())
-        part = c.biconvex_lens(r, r, float(rng.uniform(0.2, 0.5)), aperture=ap, material=glass)
-    elif kind == 2:
-        part = c.plano_convex_lens(abs(radius()), float(rng.uniform(0.2, 0.5)), aperture=ap, material=glass)
-    elif kind == 3:
-        part = c.equilateral_prism(float(rng.uniform(0.6, 1.2)), float(rng.uniform(0.8, 1.5)), material=glass)
-    elif kind == 4:
-        part = c.plane_mirror(float(rng.uniform(0.05, 0.2)), aperture=ap).rotate_z(float(rng.uniform(100, 170)))
-    elif kind == 5:
-        part = c.spherical_mirror(abs(radius()) + 1.0, float(rng.uniform(0.1, 0.3)), aperture=ap).rotate_z(
-            float(rng.uniform(150, 180)))
-    elif kind == 6:
-        part = c.baffle((float(rng.uniform(0.3, 1.2)), float(rng.uniform(0.3, 1.2))))
-    else:
-        part = c.parabolic_mirror(float(rng.uniform(1.0, 3.0)), float(rng.uniform(0.1, 0.3)), aperture=ap).rotate_z(
-            float(rng.uniform(150, 180)))
-    if rng.random() < 0.5:  # a little tilt and decentre
-        part.rotate_y(float(rng.uniform(-4, 4))).rotate_z(float(rng.uniform(-4, 4)))
-        part.move(0.0, float(rng.uniform(-0.05, 0.05)), float(rng.uniform(-0.05, 0.05)))
-    return part
+random_part = scenes.random_part  # (shared with the fuzz-seed fixtures)
 
 
 @pytest.mark.parametrize("seed", _seeds())

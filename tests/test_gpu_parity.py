@@ -20,7 +20,7 @@ torch = pytest.importorskip("torch")
 SCENE_FIXTURES = ["config1", "config2", "config3", "config4", "config5", "two_mirrors",
                   "tutorial", "mirrors_and_stops", "stopped_lens",
                   # adversarial families (tests/scenes.py adv_*) and upstream's stale cull box
-                  "adv_lens", "adv_stop", "adv_prism", "adv_condenser", "adv_still", "adv_short_a", "adv_short_b", "adv_short_c", "stale_box"]
+                  "adv_lens", "adv_stop", "adv_prism", "adv_condenser", "adv_still", "adv_short_a", "adv_short_b", "adv_short_c", "adv_bench_a", "adv_bench_b", "adv_bench_c", "stale_box"]
 KINDS = ("sphere", "cylinder", "plane", "cube", "paraboloid")
 VARIANTS = ("identity", "moved", "rotated", "scaled")
 

@@ -18,7 +18,7 @@ SCENE_ARGS = {
     "config5": (2048,), "two_mirrors": (10,), "tutorial": (10,), "mirrors_and_stops": (4096,),
     "stopped_lens": (2048,),
     # rays on the engine's thresholds, and upstream's stale cull box of a right-nested tree
-    "adv_lens": (), "adv_stop": (), "adv_prism": (), "adv_condenser": (), "adv_still": (), "adv_short_a": (), "adv_short_b": (), "adv_short_c": (), "stale_box": (3000,),
+    "adv_lens": (), "adv_stop": (), "adv_prism": (), "adv_condenser": (), "adv_still": (), "adv_short_a": (), "adv_short_b": (), "adv_short_c": (), "adv_bench_a": (), "adv_bench_b": (), "adv_bench_c": (), "stale_box": (3000,),
 }
 
 
