@@ -54,6 +54,10 @@ def test_random_scene(seed):
     # (absolute thresholds) fire for short directions whether or not they are parallel to anything
     short = rng.choice(rays.shape[1] - 1000, size=600, replace=False) + 500
     rays[4:7, short] *= 10.0 ** rng.uniform(-9.0, 1.0, size=600)
+    # rays that start inside some medium (their index row is what Snell's law takes for n1), of any brightness
+    inside = rng.choice(18_000, size=1500, replace=False)
+    rays[11, inside] = rng.uniform(1.0, 2.0, 1500)
+    rays[9, inside[:300]] = 10.0 ** rng.uniform(-12.0, 3.0, 300)
     # ... nor does it insist on homogeneous coordinates being 1 / 0: the 4x4 transforms take whatever is there
     odd = rng.choice(400, size=40, replace=False) + 19_000
     rays[3, odd[:20]] = rng.uniform(0.3, 3.0, 20) * rng.choice([-1.0, 1.0], 20)
