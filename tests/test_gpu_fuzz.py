@@ -24,11 +24,9 @@ def _seeds():
     return range(first, first + int(os.environ.get("PRT_FUZZ_SEEDS", "24")))
 
 
-@pytest.mark.parametrize("seed", _seeds())
-def test_random_scene(seed):
-    from pyrayt_amd.engine import DeviceScene
+def build_random_scene(seed):
+    """(parts, rays, rng, short, odd) of fuzz seed `seed` (also used by tools/diag_fuzz.py)."""
     from pyrayt_amd.g3d.objects import CountedObject
-    from pyrayt_amd.scene import SceneSnapshot
 
     api = scenes.product_api()
     rng = np.random.default_rng(1000 + seed)
@@ -62,6 +60,15 @@ def test_random_scene(seed):
     odd = rng.choice(400, size=40, replace=False) + 19_000
     rays[3, odd[:20]] = rng.uniform(0.3, 3.0, 20) * rng.choice([-1.0, 1.0], 20)
     rays[7, odd[20:]] = 10.0 ** rng.uniform(-6.0, -1.0, 20) * rng.choice([-1.0, 1.0], 20)
+    return parts, rays, rng, short, odd
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_scene(seed):
+    from pyrayt_amd.engine import DeviceScene
+    from pyrayt_amd.scene import SceneSnapshot
+
+    parts, rays, rng, short, odd = build_random_scene(seed)
     snap = SceneSnapshot(parts)
     flat = helpers.flat_scene(snap)
     ds = DeviceScene(snap)

@@ -12,18 +12,7 @@ from pyrayt_amd.g3d.objects import CountedObject
 from pyrayt_amd.scene import SceneSnapshot
 
 seed = int(sys.argv[1])
-api = scenes.product_api()
-rng = np.random.default_rng(1000 + seed)
-CountedObject.reset_ids()
-parts = []
-for _ in range(rng.integers(1, 5)):
-    comp = fz.random_component(rng, api.cg, api.materials, depth=int(rng.integers(0, 4)))
-    comp.move(*rng.uniform(-2.0, 2.0, 3))
-    parts.append(comp)
-rays = scenes.random_rays(20_000, seed=5000 + seed, box=4.0, wavelength=0.55)
-rays[10] = rng.uniform(0.4, 0.8, rays.shape[1])
-short = rng.choice(rays.shape[1] - 1000, size=600, replace=False) + 500
-rays[4:7, short] *= 10.0 ** rng.uniform(-9.0, 1.0, size=600)
+parts, rays, rng, short, odd = fz.build_random_scene(seed)
 snap = SceneSnapshot(parts)
 flat = helpers.flat_scene(snap)
 want_t, want_surf = c_oracle.propagate(flat, rays)
