@@ -4,6 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+With --gpus N > 1 and no launcher (no WORLD_SIZE in the environment) the process that was started
+becomes a launcher itself: before anything touches the GPU it picks a free port and starts N rank
+processes of this same file (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), passes rank 0's JSON line
+through as its only stdout and exits non-zero if any rank fails (`spawn_ranks`).
+
 One *step* = one pass of the hot path (every generation: intersect + nearest hit + shade +
 compaction + record rows) over the job's rays, already resident in HBM.  The metric counts
 result rows (one row = one ray segment resolved to its nearest surface and shaded), aggregated
@@ -75,8 +80,63 @@ def parse_args():
     return ap.parse_args()
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def spawn_ranks(world, argv, worker=None, poll_s=0.05):
+    """Start `world` rank processes of this benchmark (one per GPU) and wait for them.
+
+    Runs in a parent that has not touched the GPU (and never will: no torch import, no library
+    load) -- a process that has initialised HIP must not be replaced or forked on this pool, so the
+    ranks are fresh interpreters.  Rank 0 inherits this process's stdout (its one JSON line is the
+    launcher's only stdout); the other ranks' stdout goes to stderr.  Returns the exit code: 0 when
+    every rank exited 0, otherwise the first non-zero code seen (the remaining ranks are stopped by
+    PID).  `worker` (tests): the command to run instead of [python, bench.py]."""
+    import subprocess
+
+    port = _free_port()
+    cmd = list(worker) if worker else [sys.executable, os.path.abspath(__file__)]
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ)
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=None if rank == 0 else sys.stderr))
+    code = 0
+    pending = list(procs)
+    while pending and code == 0:
+        for proc in list(pending):
+            rc = proc.poll()
+            if rc is None:
+                continue
+            pending.remove(proc)
+            if rc != 0:
+                code = rc
+                break
+        else:
+            time.sleep(poll_s)
+    for proc in pending:  # a rank failed: the others would wait for it in a barrier forever
+        proc.terminate()
+    for proc in pending:
+        try:
+            proc.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            proc.wait()
+    return code
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: become one (nothing above or in here touches the GPU)
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     import numpy as np
     import torch
 
@@ -90,18 +150,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    if args.gpus != world:
-        if rank == 0 and distributed:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-        if not distributed and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     n_devices = torch.cuda.device_count()
-    local_device = local_rank % max(1, n_devices)
-    torch.cuda.set_device(local_device)
-    device = torch.device("cuda", local_device)
     # collectives run over RCCL ("nccl") on device tensors; PRT_DIST_BACKEND=gloo (CPU tensors) only
     # exists so that the multi-rank code path can be exercised on a single-GPU box
     backend = os.environ.get("PRT_DIST_BACKEND", "nccl")
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if distributed and backend == "nccl" and n_devices < local_world:
+        raise SystemExit(f"{local_world} ranks on this node but {n_devices} GPU(s) visible: RCCL needs one device per "
+                         "rank (PRT_DIST_BACKEND=gloo lets several ranks share a GPU, for plumbing checks only)")
+    local_device = local_rank % max(1, n_devices)
+    torch.cuda.set_device(local_device)
+    device = torch.device("cuda", local_device)
     comm_device = device if backend == "nccl" else torch.device("cpu")
     if distributed:
         import torch.distributed as dist
@@ -278,6 +339,8 @@ def main():
                         f", generation_limit {limit}, rays resident in HBM",
             "rays_job": n_job * (1 if strong else world),
             "rays_per_gpu": n,
+            "devices_visible_per_rank_process": n_devices,
+            "dist_backend": backend if distributed else None,
             "rows_per_step_per_gpu": rows_per_step,
             "rows_per_generation": counts,
             # secondary metric of SURVEY.md section 8d: rays alive at generation entry x primitives

@@ -114,3 +114,107 @@ def test_placement_kernel_against_the_indexed_copy():
     want = pdist._place_with_torch(list(blocks.unbind(0)), matrix, total)
     got = pdist._place_on_device(blocks.to("cuda:0"), matrix, limit, total)
     assert torch.equal(got.cpu(), want)
+
+
+# ---- real multi-rank RCCL: switches itself on when the box shows two or more devices -----------------
+def _rccl_worker(rank, world, port, name, n, mode, result_dir):
+    """One rank per device, backend nccl (= RCCL): real HIP trace of the shard, then the library's own
+    exchange -- prt_allgather_counts + prt_allgather_rows over a communicator bootstrapped through the
+    torch.distributed group (LibraryComm.from_group)."""
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    device = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    try:
+        from pyrayt_amd import distributed as pdist
+        from pyrayt_amd import engine
+
+        snap, rays = _scene_and_rays(name, n)
+        group = pdist.resolve_group(None)
+        lo, hi = pdist.shard_bounds(rays.shape[1], group)
+        scene = engine.DeviceScene(snap)
+        shard = torch.from_numpy(np.ascontiguousarray(rays[:, lo:hi])).to(device)
+        rows, counts = scene.trace(shard, LIMIT)
+        comm = pdist.LibraryComm.from_group(group, device)
+        try:
+            for repeat in range(2):  # the second pass runs on the communicator's reused buffers
+                full, full_counts = pdist.assemble_rows(rows, counts, LIMIT, group, mode, comm=comm)
+            assert full.is_cuda and full.device == device
+            torch.cuda.synchronize(device)
+        finally:
+            comm.close()
+        np.save(os.path.join(result_dir, f"rows_{rank}.npy"), full.cpu().numpy())
+        np.save(os.path.join(result_dir, f"counts_{rank}.npy"), np.array(full_counts))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two or more GPUs (one RCCL rank per device)")
+@pytest.mark.parametrize("name,n,mode", [("config2", 20011, "all"), ("config3", 9001, "root"),
+                                         ("stopped_lens", 6007, "all")])
+def test_rccl_allgather_rows_across_real_devices(tmp_path, name, n, mode):
+    """The first execution of prt_allgather_rows with more than one rank: min(devices, 4) ranks, one
+    device each, assembled frame bit-identical to the single-rank frame on every rank ("all") or on
+    rank 0 ("root")."""
+    import torch.multiprocessing as mp
+
+    from pyrayt_amd import engine
+
+    world = min(torch.cuda.device_count(), 4)
+    mp.start_processes(_rccl_worker, args=(world, _free_port(), name, n, mode, str(tmp_path)), nprocs=world,
+                       join=True, start_method="spawn")
+    snap, rays = _scene_and_rays(name, n)
+    rows, counts = engine.DeviceScene(snap).trace(torch.from_numpy(rays).to("cuda:0"), LIMIT)
+    want = rows.cpu().numpy()
+    for rank in range(world):
+        got = np.load(tmp_path / f"rows_{rank}.npy")
+        assert np.load(tmp_path / f"counts_{rank}.npy").tolist() == counts
+        if mode == "all" or rank == 0:
+            assert got.shape == want.shape
+            assert np.array_equal(got, want, equal_nan=True)
+        else:
+            assert got.shape[1] == 0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two or more GPUs")
+def test_bench_launches_its_own_ranks_on_real_devices():
+    """`python bench.py --gpus 2` with no launcher in front of it: one JSON line, n_gpus 2, gather over RCCL."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    done = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                           "--rays", "100000", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [ln for ln in done.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, done.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert "ms" in line["gather"] and "RCCL" in line["gather"]["transport"], line["gather"]
+
+
+def test_bench_launches_its_own_ranks_sharing_one_gpu():
+    """The same without a second device: the ranks share GPU 0 and talk over gloo (plumbing check of the
+    launcher + sharded bench path; RCCL refuses two ranks per device)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PRT_DIST_BACKEND"] = "gloo"
+    done = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                           "--rays", "100000", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [ln for ln in done.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, done.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["rays_per_gpu"] == 50000
+    assert "ms" in line["gather"], line["gather"]
