@@ -77,6 +77,11 @@ def parse_args():
                     help="experiments only: the north-star workload uses 10")
     ap.add_argument("--cpu-rays", type=int, default=1_000_000,
                     help="rays of the same workload timed on the CPU oracle")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="time synchronous traces (prt_trace) instead of keeping one trace in flight "
+                         "(prt_trace_begin / prt_trace_end)")
+    ap.add_argument("--side-steps", type=int, default=40,
+                    help="steps of each untimed side measurement (synchronous / no hints / changing ray count)")
     return ap.parse_args()
 
 
@@ -196,39 +201,110 @@ def main():
     rays_dev = torch.from_numpy(rays).to(device)
 
     limit = args.generation_limit
-    # one record block, handed back to every step (what a design loop does once it has consumed the
-    # previous frame); n * limit columns always suffice
-    block = torch.empty((engine.RECORD_COLS, max(n, 1) * limit), dtype=torch.float64, device=device)
+    pipelined = not args.no_pipeline
+    # record blocks handed back to every step (what a design loop does once it has consumed the
+    # previous frame); n * limit columns always suffice.  Pipelined: the step in flight and the step
+    # being collected record into different blocks (prt_trace_begin / prt_trace_end, two tickets).
+    blocks = [torch.empty((engine.RECORD_COLS, max(n, 1) * limit), dtype=torch.float64, device=device)
+              for _ in range(2 if pipelined else 1)]
+    block = blocks[0]
 
-    def step():
-        return scene.trace(rays_dev, limit, flags=args.flags, out=block)
+    def step(flags=args.flags, rays_in=None):
+        return scene.trace(rays_dev if rays_in is None else rays_in, limit, flags=flags, out=block)
+
+    class Totals:
+        def __init__(self):
+            self.kernel_ms = self.launches = self.ray_generations = self.rows_recorded = self.rays_carried = 0.0
+
+        def add(self):
+            st = scene.trace_stats()
+            self.kernel_ms += st["kernel_ms"]
+            self.launches += st["kernel_launches"]
+            self.ray_generations += st["ray_generations"]
+            self.rows_recorded += st["rows"]
+            self.rays_carried += st["rays_carried"]
+
+    def run_steps(count, totals=None, flags=args.flags):
+        """`count` traces back to back; returns (rows, counts) of the last one.  Pipelined: trace k + 1 is
+        enqueued before the counts of trace k are collected, so the host's share of a step (launch
+        calls, the wait for the counts, Python) overlaps with the GPU's work on the next trace."""
+        rows = counts = None
+        if not pipelined:
+            for _ in range(count):
+                rows, counts = step(flags)
+                if totals is not None:
+                    totals.add()
+            return rows, counts
+        scene.trace_begin(0, rays_dev, limit, blocks[0], flags=flags)
+        for k in range(count):
+            if k + 1 < count:
+                scene.trace_begin((k + 1) & 1, rays_dev, limit, blocks[(k + 1) & 1], flags=flags)
+            rows, counts = scene.trace_end(k & 1)
+            if totals is not None:
+                totals.add()
+        return rows, counts
 
     spinup_steps = 0
     t_spin = time.perf_counter()
     while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
-        step()
-        spinup_steps += 1
-    for _ in range(args.warmup):
-        rows, counts = step()
+        run_steps(2)
+        spinup_steps += 2
+    rows, counts = run_steps(max(args.warmup, 1)) if args.warmup else step()
     torch.cuda.synchronize(device)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    kernel_ms = launches = ray_generations = rows_recorded = rays_carried = 0.0
-    for _ in range(args.steps):
-        rows, counts = step()
-        st = scene.trace_stats()
-        kernel_ms += st["kernel_ms"]
-        launches += st["kernel_launches"]
-        ray_generations += st["ray_generations"]
-        rows_recorded += st["rows"]
-        rays_carried += st["rays_carried"]
+    timed = Totals()
+    rows, counts = run_steps(args.steps, timed)
     torch.cuda.synchronize(device)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
+    kernel_ms, launches, ray_generations = timed.kernel_ms, timed.launches, timed.ray_generations
+    rows_recorded, rays_carried = timed.rows_recorded, timed.rays_carried
+
+    # side measurements (untimed region, every rank so that the ranks stay in step): the same step
+    # (a) synchronous: one trace at a time through prt_trace, host and GPU strictly alternating;
+    # (b) without the dense-mode hints of the previous trace (PRT_TRACE_NO_HINTS: what a first trace
+    #     or a trace whose rays die differently runs on);
+    # (c) with a ray count that changes from call to call (no hints, control words re-initialised):
+    #     what a design loop that resizes its ray set every iteration sees.
+    def side(label, fn, count):
+        if count <= 0:
+            return None
+        fn(3)
+        torch.cuda.synchronize(device)
+        tot = Totals()
+        s0 = time.perf_counter()
+        fn(count, tot)
+        torch.cuda.synchronize(device)
+        took = time.perf_counter() - s0
+        return {"ms_per_step": took / count * 1e3, "kernel_ms_per_step": tot.kernel_ms / count,
+                "avg_launch_ms": tot.kernel_ms / tot.launches if tot.launches else 0.0,
+                "launches_per_step": tot.launches / count, "rows_per_s_this_gpu": tot.rows_recorded / took,
+                "_bytes": (104.0 * tot.ray_generations + 120.0 * tot.rows_recorded + 104.0 * tot.rays_carried),
+                "_kernel_ms": tot.kernel_ms}
+
+    def sync_steps(count, totals=None, flags=args.flags):
+        for _ in range(count):
+            step(flags)
+            if totals is not None:
+                totals.add()
+
+    def resized_steps(count, totals=None):
+        shorter = rays_dev[:, : max(1, n - 256)]
+        for k in range(count):
+            step(args.flags, rays_dev if k % 2 == 0 else shorter)
+            if totals is not None:
+                totals.add()
+
+    side_sync = side("synchronous", sync_steps, args.side_steps)
+    side_no_hints = side("no hints", lambda c, t=None: run_steps(c, t, flags=args.flags | engine.TRACE_NO_HINTS),
+                         args.side_steps)
+    side_resized = side("changing ray count", resized_steps, args.side_steps)
+    rows, counts = run_steps(2)  # (leave the scene with the hints of the north-star trace for what follows)
 
     rows_per_step = int(rows.shape[1])
     if distributed:
@@ -304,15 +380,16 @@ def main():
     # 13 state rows (include/prt.h "compact state"), i.e. 80 B where the figure says 104 -- reported next
     # to it as `moved_bytes_per_launch`, which is what `traffic` (PMC) has to be compared with.
     algorithmic_bytes = 104.0 * ray_generations + 120.0 * rows_recorded + 104.0 * rays_carried
-    full_rows = scene.telemetry()["full_rows_fallbacks"] > 0 or os.environ.get("PRT_FULL_ROWS") is not None
+    full_rows = scene.telemetry()["full_rows_fallbacks"] > 0 or bool(args.flags & engine.TRACE_FULL_ROWS)
     state = STATE_BYTES_FULL if full_rows else STATE_BYTES
     first_generation = float(n) * args.steps
     moved_bytes = (STATE_BYTES_FULL * first_generation + state * (ray_generations - first_generation) +
                    ROW_BYTES * rows_recorded + state * rays_carried)
     achieved = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     traffic = None
-    traffic_file = os.path.join(ROOT, "profiles", "r2", "traffic.json")
-    if os.path.exists(traffic_file) and args.flags == 0 and n == RAYS_PER_GPU and args.workload == "config2":
+    traffic_file = next((f for f in (os.path.join(ROOT, "profiles", r, "traffic.json") for r in ("r3", "r2"))
+                         if os.path.exists(f)), None)
+    if traffic_file and args.flags == 0 and n == RAYS_PER_GPU and args.workload == "config2":
         with open(traffic_file) as fh:
             measured = json.load(fh)
         # per launch like `achieved`: a repeated trace launches exactly its working generations
@@ -336,7 +413,12 @@ def main():
             "workload": WORKLOADS[args.workload] +
                         (f": one {n_job}-ray job, contiguous id shards over {world} GPU(s)" if strong
                          else f": {n_job} rays per GPU (weak scaling)") +
-                        f", generation_limit {limit}, rays resident in HBM",
+                        f", generation_limit {limit}, rays resident in HBM; the timed step is a REPEATED "
+                        "IDENTICAL trace: dense-mode hints of the previous trace active, first batch sized by it" +
+                        (", one trace kept in flight while the previous one's counts are collected "
+                         "(prt_trace_begin / prt_trace_end)" if pipelined else ", synchronous (prt_trace)") +
+                        "; see value_synchronous / value_no_hints / value_changing_ray_count for the other kinds of step",
+            "pipelined": pipelined,
             "rays_job": n_job * (1 if strong else world),
             "rays_per_gpu": n,
             "devices_visible_per_rank_process": n_devices,
@@ -357,7 +439,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "frac_of_measured_copy": achieved / COPY_GBS,
             "traffic": traffic,
-            "traffic_source": "profiles/r2/traffic.json (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, "
+            "traffic_source": os.path.relpath(traffic_file, ROOT) + " (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, "
                               "calibrated; same command, separate passes)" if traffic else None,
             "kernel": "k_generation" if not (args.flags & 2) else "k_hit + k_scan + k_shade + k_advance",
             "algorithmic_bytes_per_launch": algorithmic_bytes / launches if launches else 0,
@@ -371,6 +453,30 @@ def main():
         },
         "end_to_end_trace": end_to_end,
     }
+
+    # the other kinds of step (this rank's GPU; untimed side runs of --side-steps traces each)
+    def publish(kind):
+        if kind is None:
+            return None
+        bytes_, ms_ = kind.pop("_bytes"), kind.pop("_kernel_ms")
+        gbs = bytes_ / (ms_ * 1e-3) / 1e9 if ms_ > 0 else 0.0
+        kind["frac"] = gbs / HBM_PEAK_GBS
+        return kind
+
+    side_sync, side_no_hints, side_resized = publish(side_sync), publish(side_no_hints), publish(side_resized)
+    if side_sync:
+        line["value_synchronous"] = side_sync["rows_per_s_this_gpu"] * (world if strong else world)
+        line["synchronous"] = side_sync
+    if side_no_hints:
+        line["value_no_hints"] = side_no_hints["rows_per_s_this_gpu"] * world
+        line["roofline"]["no_hints"] = {k: side_no_hints[k] for k in ("avg_launch_ms", "frac", "kernel_ms_per_step",
+                                                                      "launches_per_step", "ms_per_step")}
+    if side_resized:
+        # "first trace" in the sense that matters to a caller: nothing learnt from the previous trace applies
+        # (other ray count: no hints, control words re-initialised); the one-off costs of a scene's very
+        # first call (table upload, kernel load) are in end_to_end_trace.first_call_ms instead
+        line["value_first_trace"] = side_resized["rows_per_s_this_gpu"] * world
+        line["changing_ray_count"] = side_resized
     if gather:
         line["gather"] = gather
         if "ms" in gather:
@@ -395,6 +501,31 @@ def main():
                       f"workload, {frame.shape[0]} rows in {cpu_s:.1f} s, single process like "
                       f"the reference; host has {os.cpu_count()} logical CPUs",
         }
+        # the bar next to it: the C restatement on every host core (one process per core over contiguous
+        # id ranges of the same job; a child interpreter that never touches the GPU)
+        try:
+            import subprocess
+
+            procs = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+            repeat = max(1, round(procs * 1.3e6 * 1.5 / (3.0 * n)))  # ~1.5 s of work per core at ~1.3e6 rows/s/core
+            done = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", "--workload", args.workload, "--rays", str(n_job),
+                                   "--procs", str(procs), "--repeat", str(repeat), "--limit", str(limit)],
+                                  cwd=ROOT, capture_output=True, text=True, timeout=600)
+            res = json.loads(done.stdout.strip().splitlines()[-1])
+            model = ""
+            try:
+                with open("/proc/cpuinfo") as fh:
+                    model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "")
+            except OSError:
+                pass
+            line["cpu_baseline_all_cores"] = {
+                "value": res["rows_per_s"], "unit": "intersections/s", "cores": procs, "kind": "port-c",
+                "sample": f"C oracle (oracle/prt_oracle.c, gcc -O2) on the whole {n_job}-ray job, one process per "
+                          f"logical CPU over contiguous id ranges, each slice traced {repeat}x: {res['rows']} rows in "
+                          f"{res['seconds']:.2f} s; CPU: {model or 'unknown'} ({os.cpu_count()} logical CPUs)",
+            }
+        except Exception as exc:  # noqa: BLE001
+            line["cpu_baseline_all_cores"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()

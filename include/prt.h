@@ -117,12 +117,32 @@ const char* prt_last_error(void);
 /* number of visible HIP devices (0 if none / no driver) */
 int prt_device_count(void);
 
+/* How a scene is compiled and which kernels serve it.  Every field's zero is the default (and the
+ * product's choice); the others exist for A/B measurements and for the tests, which run the parity
+ * suites under each of them.  None of them changes a result.  No counterpart upstream.  The library
+ * reads nothing from the environment: these options and the PRT_TRACE_* flags are all there is. */
+typedef struct prt_scene_options {
+  int32_t struct_size;  /* sizeof(prt_scene_options) as the caller knows it */
+  int32_t no_chain;     /* 1: components run on the step interpreter, none as a register-only chain step */
+  int32_t no_cull;      /* 1: no component cull steps in the trace program */
+  int32_t cull_min;     /* components from which cull steps are compiled in (0 = the default, 3) */
+  int32_t no_groups;    /* 1: no hierarchy of cull steps over groups of components */
+  int32_t no_implied;   /* 1: every CSG node evaluates upstream's cull box (csg.py:126-128) exactly */
+  int32_t hit_lanes;    /* nearest-hit kernel of prt_propagate and of PRT_TRACE_UNFUSED: lanes per ray,
+                           0 / 1 = one ray per lane (default), 4 / 8 / 16 = surface-parallel with a
+                           wavefront shuffle (t, component order) min-reduce */
+  int32_t hit_staged;   /* 1: those kernels read the program from an LDS copy instead of the scalar cache */
+  int32_t list_order_groups; /* 1: the cull-step hierarchy groups components in list order only (the
+                           round-2 form); 0: by position in space when that is tighter */
+  int32_t reserved[7];
+} prt_scene_options;
+
 /* Build a scene from a snapshot.  roots[] lists the node index of every top-level component
  * in RayTracer._components order (pyrayt/_pyrayt.py:229-239); the surface look-up table of
- * _pyrayt.py:257-260 is the depth-first leaf order of those roots. */
+ * _pyrayt.py:257-260 is the depth-first leaf order of those roots.  options: NULL = defaults. */
 int prt_scene_create(const prt_prim* prims, int n_prims, const prt_node* nodes, int n_nodes,
                      const int32_t* roots, int n_roots, const prt_material* mats, int n_mats,
-                     prt_scene** out);
+                     const prt_scene_options* options, prt_scene** out);
 void prt_scene_destroy(prt_scene* scene);
 /* The same components with other numbers in them -- a part moved, a radius or a glass changed: what a
  * design loop does between two RayTracer.trace() calls (examples/lens_design.ipynb; upstream simply
@@ -130,9 +150,11 @@ void prt_scene_destroy(prt_scene* scene);
  * scene's tables in place: device buffers, pinned memory, events and what the scene learnt from its
  * previous trace stay.  Returns 0, or 1 -- scene untouched -- when the snapshot does not have the old
  * one's shape (a table or program would change size): build a new scene then.  Synchronises the
- * device (the previous trace may still be reading the tables). */
+ * device (the previous trace may still be reading the tables); refused while a trace is in flight.
+ * options: NULL = keep the scene's. */
 int prt_scene_update(prt_scene* scene, const prt_prim* prims, int n_prims, const prt_node* nodes, int n_nodes,
-                     const int32_t* roots, int n_roots, const prt_material* mats, int n_mats);
+                     const int32_t* roots, int n_roots, const prt_material* mats, int n_mats,
+                     const prt_scene_options* options);
 /* rows of the hit list component `root` returns from intersect(): 2 * (#leaves under it) */
 int prt_scene_component_rows(const prt_scene* scene, int root);
 /* what the scene compiled to (no counterpart upstream; host-only, needs no GPU):
@@ -225,16 +247,46 @@ int prt_generate_rays(int device, const prt_source* source, int64_t n_total, int
  *     there: do not hand the block to anything but prt_trace between two traces
  *   flags: PRT_TRACE_* bits
  * Returns the total number of rows (>= 0) or a negative error.  PRT_ERR_ROWS_CAP if rows_cap
- * is too small (n * generation_limit rows always suffices).  Synchronises the stream. */
+ * is too small (n * generation_limit rows always suffices).
+ * On return the COUNTS are on the host; the record rows and the workspace are only stream-ordered: the
+ * generation kernels publish their counts to host-mapped memory themselves, and the call returns as
+ * soon as it has seen them -- possibly while the last kernel is still storing rows.  Whatever consumes
+ * rows_out (or frees / reuses rows_out, rays or the workspace) must run on `stream` or synchronise with
+ * it first; PRT_TRACE_SYNC makes the call do that itself before it returns. */
 #define PRT_TRACE_KEEP_ABSORBED 1 /* carry zero-direction (absorbed) rays into the next
                                      generation exactly like _pyrayt.py:415-428 (Q3) instead of
                                      dropping them when they are absorbed; the rows are
                                      identical either way */
 #define PRT_TRACE_UNFUSED 2       /* run the generation as propagate + interact kernels */
+#define PRT_TRACE_NO_HINTS 4      /* do not use the dense-mode hints of the scene's previous trace
+                                     (every generation runs the general look-back path, as in a first trace) */
+#define PRT_TRACE_FULL_ROWS 8     /* carry all 13 state rows between generations (see "compact state") */
+#define PRT_TRACE_PUBLISH_KERNEL 16 /* counts reach the host through a one-block kernel behind each batch
+                                     instead of from inside the generation kernels (A/B, tests) */
+#define PRT_TRACE_TEST_STALL 32   /* test hook: one tile reports an expired look-back, so that the
+                                     fallback to the three-kernel path can be exercised */
+#define PRT_TRACE_SYNC 64         /* hipStreamSynchronize(stream) before returning */
+#define PRT_TRACE_COUNT_PATHS 128 /* count, in prt_trace_telemetry, the rays that are not well formed and
+                                     the CSG node evaluations that took an exact path (see there) */
 int64_t prt_trace_workspace_bytes(int64_t n);
 int64_t prt_trace(prt_scene* scene, int device, const double* rays, int64_t n, int64_t ld,
                   int generation_limit, double ray_offset, double* rows_out, int64_t rows_cap,
                   int64_t* rows_per_generation, void* workspace, int flags, void* stream);
+
+/* The same in two halves, so that host work and GPU work overlap (no counterpart upstream:
+ * pyrayt/_pyrayt.py:329-339 is a blocking loop).  prt_trace_begin enqueues the generations the scene's
+ * previous trace needed (a first trace: a batch of four) and returns at once; prt_trace_end waits for
+ * their counts, enqueues whatever the trace still needs (more generations; a repeat when a hint did
+ * not hold) and returns what prt_trace returns.  prt_trace is begin + end on ticket 0.
+ * A scene has PRT_TRACE_TICKETS tickets per device: traces of different tickets may be in flight
+ * together (they execute in stream order).  Every ticket in flight needs its own workspace and its own
+ * record block, and all of them the same stream; rays, rows_out and the workspace must stay valid
+ * until prt_trace_end.  Results are those of prt_trace, bit for bit. */
+#define PRT_TRACE_TICKETS 2
+int prt_trace_begin(prt_scene* scene, int device, int ticket, const double* rays, int64_t n, int64_t ld,
+                    int generation_limit, double ray_offset, double* rows_out, int64_t rows_cap,
+                    void* workspace, int flags, void* stream);
+int64_t prt_trace_end(prt_scene* scene, int device, int ticket, int64_t* rows_per_generation);
 
 /* ---- frame re-assembly across the GPUs of a node ----------------------------
  * No counterpart upstream (pyrayt/_pyrayt.py:329-339 is one Python thread).  Rank r traces the
@@ -293,7 +345,7 @@ int prt_frame_stats(int device, const double* rows, int64_t ld, int64_t n_rows, 
                     double generation, double rays_per_source, int n_groups, double* out, void* workspace,
                     void* stream);
 
-/* statistics of the last prt_trace on this scene (for bench.py's roofline):
+/* statistics of the trace of this scene that ended last (prt_trace / prt_trace_end; for bench.py's roofline):
  * out[0] = generations that found rays, out[1] = sum over generations of rays alive at entry,
  * out[2] = GPU milliseconds spent in generation kernels (hipEvent, on the trace stream),
  * out[3] = number of generation-kernel launches, out[4] = sum of rows recorded,
@@ -304,23 +356,26 @@ int prt_frame_stats(int device, const double* rows, int64_t ld, int64_t n_rows, 
 #define PRT_VARIANT_FUSED 1       /* one ray per lane, one fused kernel per generation */
 #define PRT_VARIANT_UNFUSED 2     /* propagate / scan / interact kernels per generation */
 #define PRT_VARIANT_KLANES 3      /* ... with the surface-parallel nearest-hit kernel (K lanes per ray,
-                                     shuffle min-reduce; environment PRT_HIT_VARIANT=lanes4|lanes8|lanes16) */
+                                     shuffle min-reduce; prt_scene_options.hit_lanes = 4 | 8 | 16) */
 int prt_trace_stats(const prt_scene* scene, double* out8);
-/* counters of this scene since it was created: out4 = { traces re-run on the three-kernel path after a
+/* counters of this scene since it was created: out8 = { traces re-run on the three-kernel path after a
  * look-back gave up, traces repeated because a dense-mode hint did not hold, generation launches made in
- * dense mode, traces repeated with all 13 state rows (see below; at most one per scene) }.  Dense mode: a generation in which the previous trace of the same scene and ray count
+ * dense mode, traces repeated with all 13 state rows (see below; at most one per scene),
+ * and from the traces run with PRT_TRACE_COUNT_PATHS: how many such traces, ray-generations whose ray was
+ * not well formed (see "shortcuts" in DESIGN.md: such a ray takes none), CSG node evaluations with
+ * survivors under an implied cull box, ... of which evaluated upstream's box test exactly }.  Dense mode: a generation in which the previous trace of the same scene and ray count
  * recorded every ray and carried all or none of them on is launched on the assumption that it will
  * again -- every tile then knows its output position without the look-back; each tile checks the
  * assumption on its own counts and a miss repeats the trace without assumptions (results are exact
- * either way; PRT_NO_HINTS=1 in the environment turns the hints off).
+ * either way; PRT_TRACE_NO_HINTS turns the hints off for a call).
  * Compact state: between the generations of a trace the ray state goes without its rows 3, 7 and 8
  * (origin w, direction w, generation): in a ray set that starts like RaySet's defaults
  * (pyrayt/_pyrayt.py:29-36: w = 1 / 0, generation 0) they hold 1, +0 and the generation's number in every
  * generation, bit for bit, so they are neither written nor read (24 of 104 B each way).  Generation 0
  * checks the caller's rows, every generation checks the rays it hands on; the first ray that differs
- * makes the library repeat the trace with all rows and keep doing so for this scene (PRT_FULL_ROWS=1
- * forces that form). */
-int prt_trace_telemetry(const prt_scene* scene, int64_t* out4);
+ * makes the library repeat the trace with all rows and keep doing so for this scene
+ * (PRT_TRACE_FULL_ROWS forces that form for a call). */
+int prt_trace_telemetry(const prt_scene* scene, int64_t* out8);
 
 /* ---- renderers (second consumer of the intersect path) ----------
  * tinygfx/g3d/renderers.py: an OrthographicCamera grid (world_objects.py:499-537) is pushed

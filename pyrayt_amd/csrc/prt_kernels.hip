@@ -476,6 +476,19 @@ static_assert(offsetof(HostMirror, gen) == 64, "mirror header");
 #define PRT_ERR_STALL (-100) /* internal: look-back gave up -> host falls back to the unfused path */
 #define PRT_ERR_FULL_ROWS (-102) /* internal: a ray set needs the rows the compact form leaves out -> host re-runs with all 13 */
 
+// Raising an error on the device.  The verdicts that make the host repeat the trace (SPECULATION, STALL,
+// FULL_ROWS) replace whatever is there and are WAITED FOR -- the returned value is consumed, so the
+// atomic has been performed at the memory side before anything this lane does next (publishing a tile
+// word, checking in, telling the host): a tile that consumes this tile's word afterwards and then reads
+// the error word sees the verdict.  ROWS_CAP and UNTRACABLE never replace another error: a dense-mode
+// generation measures the record block against its ASSUMED offsets, so after a missed hint a tile may
+// find the block too small although the real rows fit -- the miss is what the host has to hear about.
+__device__ __forceinline__ void raise_verdict(int32_t* error, int code) {
+  const int before = atomicExch(error, code);
+  asm volatile("" ::"v"(before) : "memory");
+}
+__device__ __forceinline__ void raise_error(int32_t* error, int code) { atomicCAS(error, 0, code); }
+
 // tile status word for the decoupled look-back: [63:62] status, [61:31] live, [30:0] carried.
 // One naturally aligned 8-byte word written by one agent-scope store: payload and flag cannot
 // be observed torn, so no fence is needed around it.
@@ -510,7 +523,7 @@ __device__ __forceinline__ unsigned long long tile_load(unsigned long long* p) {
 #endif
 __device__ __forceinline__ bool lookback(unsigned long long* state, int tile, unsigned agg_live,
                                          unsigned agg_carry, unsigned& excl_live,
-                                         unsigned& excl_carry) {
+                                         unsigned& excl_carry, int32_t* error) {
   // One poll fetches PRT_LOOKBACK_WINDOWS x 64 predecessor words (lane l: tiles base - l, base - 64 - l,
   // ...), all loads in flight together: a poll is a round trip to the fabric (~1 us under load, the
   // words are device-scope), and the nearest inclusive prefix is typically 40-130 tiles back
@@ -563,7 +576,12 @@ __device__ __forceinline__ bool lookback(unsigned long long* state, int tile, un
   }
   excl_live = sum_live;
   excl_carry = sum_carry;
-  if (lane == 0) tile_store(state + tile, tile_pack(TILE_PREFIX, sum_live + agg_live, sum_carry + agg_carry));
+  if (lane == 0) {
+    // (an expired spin leaves a partial prefix: the verdict goes out first, so that whoever consumes
+    // this word -- the last tile, which tells the host, included -- finds the error word set)
+    if (!ok) raise_verdict(error, PRT_ERR_STALL);
+    tile_store(state + tile, tile_pack(TILE_PREFIX, sum_live + agg_live, sum_carry + agg_carry));
+  }
   return ok;
 }
 
@@ -757,7 +775,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
         r.dw = row_load(tile_rays + 7 * ld, lane_bytes);
         const double generation = row_load(tile_rays + 8 * ld, lane_bytes);
         PARK(0) = generation;
-        if (!(w_is_trivial(r.ow, r.dw) && generation == 0.0)) atomicExch(&ctrl->error, PRT_ERR_FULL_ROWS);
+        if (!(w_is_trivial(r.ow, r.dw) && generation == 0.0)) raise_verdict(&ctrl->error, PRT_ERR_FULL_ROWS);
       }
     }
 #ifdef PRT_TIMING
@@ -806,11 +824,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     if (threadIdx.x == 0) {
       const int64_t mine = (n - (int64_t)tile * PRT_BLOCK) < PRT_BLOCK ? (n - (int64_t)tile * PRT_BLOCK) : PRT_BLOCK;
       const bool holds = (int64_t)agg_live == mine && (int64_t)agg_carry == (assume == 1 ? mine : 0);
-      if (!holds && !failed) {
-        // (the returned value is waited for: the verdict is in place before this tile checks in below)
-        const int before = atomicExch(&ctrl->error, PRT_ERR_SPECULATION);
-        asm volatile("" ::"v"(before) : "memory");
-      }
+      if (!holds && !failed) raise_verdict(&ctrl->error, PRT_ERR_SPECULATION);  // in place before this tile checks in below
       finisher = tile == 0;
       if (publish_here) {
         // Two levels (64 tiles to a counter, the last of each on to the root): thousands of increments of
@@ -860,10 +874,11 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     e_live = (unsigned)tile * PRT_BLOCK; e_carry = (unsigned)tile * PRT_BLOCK;
     if (lane == 0) tile_store(tiles_cur + tile, tile_pack(TILE_PREFIX, e_live + agg_live, e_carry + agg_carry));
 #else
-    bool ok = lookback(tiles_cur, tile, agg_live, agg_carry, e_live, e_carry);
+    bool ok = lookback(tiles_cur, tile, agg_live, agg_carry, e_live, e_carry, &ctrl->error);
 #endif
-    if (ctrl->pad == 1 && tile == 3) ok = false;  // test hook: pretend the spin expired
-    if (!ok && lane == 0) atomicExch(&ctrl->error, PRT_ERR_STALL);
+    // test hook: pretend the spin expired (such traces publish through k_fused_reinit behind the batch)
+    if (ctrl->pad == 1 && tile == 3 && lane == 0) raise_verdict(&ctrl->error, PRT_ERR_STALL);
+    (void)ok;
     if (lane == 0) { s_excl[0] = e_live; s_excl[1] = e_carry; }
   }
   __syncthreads();
@@ -906,7 +921,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     }
   }
   if (row_base + excl_live + agg_live > ld_rows) {  // uniform per workgroup (ld_rows == rows_cap)
-    if (threadIdx.x == 0) atomicExch(&ctrl->error, PRT_ERR_ROWS_CAP);
+    if (threadIdx.x == 0 && !failed) raise_error(&ctrl->error, PRT_ERR_ROWS_CAP);
     return;
   }
   if (!live) return;
@@ -931,9 +946,9 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   if (!interact_store_rows<COMPACT>(sh, r, carry, (unsigned)live_rank * 8u, (unsigned)carry_rank * 8u,
                                     next + uniform64(excl_carry), ld_next, rows + uniform64(row_base + excl_live),
                                     ld_rows, next_generation, relaunch, ray_offset))
-    atomicExch(&ctrl->error, PRT_ERR_FULL_ROWS);
+    raise_verdict(&ctrl->error, PRT_ERR_FULL_ROWS);
 #endif
-  if (!sh.ok) atomicExch(&ctrl->error, PRT_ERR_UNTRACABLE);
+  if (!sh.ok) raise_error(&ctrl->error, PRT_ERR_UNTRACABLE);
   STAMP(7);
 }
 
@@ -1104,23 +1119,18 @@ static SceneDev trace_scene_dev(const prt_scene* s, const DeviceCopy* c) {
 }
 
 // ---- nearest-hit kernel selection -----------------------------------------------------------------
-// PRT_HIT_VARIANT = "lanes4" | "lanes8" | "lanes16" (surface-parallel: K lanes per ray, shuffle
-// min-reduce) and/or "lds" (program staged in LDS), e.g. "lanes8,lds".  Read per call; applies to
-// prt_propagate and to the three-kernel trace (PRT_TRACE_UNFUSED).  Default: one ray per lane, steps
-// through the scalar cache -- the measured winner.
+// prt_scene_options.hit_lanes = 4 | 8 | 16 (surface-parallel: K lanes per ray, shuffle min-reduce)
+// and / or .hit_staged (program staged in LDS); applies to prt_propagate and to the three-kernel trace
+// (PRT_TRACE_UNFUSED).  Default: one ray per lane, steps through the scalar cache -- the measured
+// winner.
 struct HitVariant {
   int lanes = 1;
   bool staged = false;
 };
-static HitVariant hit_variant() {
+static HitVariant hit_variant(const prt_scene* s) {
   HitVariant v;
-  if (const char* env = getenv("PRT_HIT_VARIANT")) {
-    const std::string text(env);
-    if (text.find("lanes16") != std::string::npos) v.lanes = 16;
-    else if (text.find("lanes8") != std::string::npos) v.lanes = 8;
-    else if (text.find("lanes4") != std::string::npos) v.lanes = 4;
-    v.staged = text.find("lds") != std::string::npos;
-  }
+  v.lanes = s->options.hit_lanes > 1 ? s->options.hit_lanes : 1;
+  v.staged = s->options.hit_staged != 0;
   return v;
 }
 
@@ -1130,7 +1140,7 @@ static int launch_hit(const prt_scene* s, const DeviceCopy* c, const SceneDev& s
                       const double* rays, int64_t ld, const TraceCtrl* ctrl, int64_t n_fixed, int64_t n_bound,
                       double* hit_t, int32_t* hit_prim, int64_t* surf_out, int32_t* tile_counts,
                       int keep_absorbed) {
-  const HitVariant v = hit_variant();
+  const HitVariant v = hit_variant(s);
   size_t lds = lds_bytes(sd.lds_slots);
   if (v.staged) lds = align_up(lds, 16) + (size_t)sd.n_instr * sizeof(DevInstr) + 8 * PRT_BLOCK;
   if (lds > kMaxLdsBytes) return fail(PRT_ERR_SCENE, "program too large to stage in LDS");
@@ -1333,7 +1343,6 @@ extern "C" int prt_interact(prt_scene* s, int device, const double* rays_in, int
 //   ctrl | fused ctrl | generation slots | rows_per_generation (device) | tile words A | B
 //   | block counts | block offsets | hit_t (n f64) | hit_prim (n i32)      [unfused path only]
 //   | ray buffer A (13 n) | ray buffer B (13 n)
-static const int kMaxGenerationSlots = 1024;
 struct TraceLayout {
   size_t ctrl, fctrl, gen, gen_rows, tiles_a, tiles_b, counts, offsets, hit_t, hit_prim, rays_a,
       rays_b, total;
@@ -1374,10 +1383,9 @@ static int64_t trace_error(int error) {
   return fail(error, "device error during trace");
 }
 
-// three kernels per generation + a host round trip (kept for A/B runs and cross-checks)
-// Who traced last with a given workspace address: a scene skips re-initialising the control words only
-// if nobody else used the block since its own last trace (another scene, or the other trace path of
-// the same one, marks the block as theirs before touching it).
+// Who traced last with a given workspace address: a ticket skips re-initialising the control words only
+// if nobody else used the block since its own last trace (another scene, another ticket, or the other
+// trace path of the same one marks the block as theirs before touching it).
 static std::mutex g_workspace_mutex;
 static std::unordered_map<const void*, unsigned long long> g_workspace_user;
 static std::atomic<unsigned long long> g_next_user{1};
@@ -1389,10 +1397,12 @@ static bool workspace_taken_over(const void* w, unsigned long long user) {
   return !same;
 }
 
-static int64_t trace_unfused(prt_scene* s, DeviceCopy* c, const double* rays, int64_t n, int64_t ld,
-                             int generation_limit, double ray_offset, double* rows_out,
-                             int64_t rows_cap, int64_t* rows_per_generation, char* w, int flags,
-                             hipStream_t st) {
+// three kernels per generation + a host round trip (kept for A/B runs and cross-checks)
+static int64_t trace_unfused(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t* rows_per_generation) {
+  const int64_t n = t->n;
+  const int generation_limit = t->limit;
+  char* w = t->w;
+  hipStream_t st = t->st;
   const TraceLayout l = trace_layout(n);
   TraceCtrl* ctrl = (TraceCtrl*)(w + l.ctrl);
   int64_t* gen_rows = (int64_t*)(w + l.gen_rows);
@@ -1401,20 +1411,23 @@ static int64_t trace_unfused(prt_scene* s, DeviceCopy* c, const double* rays, in
   double* hit_t = (double*)(w + l.hit_t);
   int32_t* hit_prim = (int32_t*)(w + l.hit_prim);
   double* buf[2] = {(double*)(w + l.rays_a), (double*)(w + l.rays_b)};
-  const int keep_absorbed = (flags & PRT_TRACE_KEEP_ABSORBED) ? 1 : 0;
+  const int keep_absorbed = (t->flags & PRT_TRACE_KEEP_ABSORBED) ? 1 : 0;
+  if (t->user == 0) t->user = g_next_user.fetch_add(1);
+  (void)workspace_taken_over(w, t->user);  // the block is ours now: a fused trace behind this one re-initialises
+  t->ready_workspace = nullptr;
 
   SceneDev sd = trace_scene_dev(s, c);
-  hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, st, ctrl, n, rows_cap);
+  hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, st, ctrl, n, t->rows_cap);
 
-  const double* src = rays;
-  int64_t src_ld = ld;
+  const double* src = t->rays;
+  int64_t src_ld = t->ld;
   int64_t n_cur = n, total_rows = 0;
   int error = 0;
   for (int g = 0; g < generation_limit && n_cur > 0; ++g) {
     double* dst = buf[g & 1];
     const unsigned nb = blocks_for(n_cur);
     const int relaunch = (g + 1 != generation_limit) ? 1 : 0;
-    HIP_TRY(hipEventRecord(c->ev0, st));
+    HIP_TRY(hipEventRecord(t->ev0, st));
     {
       int rc_hit = launch_hit(s, c, sd, st, src, src_ld, (const TraceCtrl*)ctrl, (int64_t)0, n_cur, hit_t, hit_prim,
                               (int64_t*)nullptr, counts, keep_absorbed);
@@ -1424,27 +1437,27 @@ static int64_t trace_unfused(prt_scene* s, DeviceCopy* c, const double* rays, in
     hipLaunchKernelGGL(k_shade, dim3(nb), dim3(PRT_BLOCK), 0, st, sd, src, src_ld,
                        (const TraceCtrl*)ctrl, (int64_t)0, (const double*)hit_t,
                        (const int32_t*)hit_prim, (const int64_t*)nullptr, (const int64_t*)offsets,
-                       dst, n, rows_out, rows_cap, (int64_t)0, (double)(g + 1), relaunch,
-                       ray_offset, keep_absorbed, ctrl);
+                       dst, n, t->rows_out, t->rows_cap, (int64_t)0, (double)(g + 1), relaunch,
+                       t->ray_offset, keep_absorbed, ctrl);
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, st, ctrl, gen_rows, g);
-    HIP_TRY(hipEventRecord(c->ev1, st));
+    HIP_TRY(hipEventRecord(t->ev1, st));
     // the host needs the new ray count to size the next launch
-    HIP_TRY(hipMemcpyAsync(c->host_pinned, ctrl, sizeof(TraceCtrl), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(c->host_pinned + 6, gen_rows + g, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(t->host_pinned, ctrl, sizeof(TraceCtrl), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(t->host_pinned + 6, gen_rows + g, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    const TraceCtrl* h = (const TraceCtrl*)c->host_pinned;
-    s->stats[0] += 1;
-    s->stats[1] += (double)n_cur;
-    s->stats[2] += ms;
-    s->stats[3] += 4;
+    HIP_TRY(hipEventElapsedTime(&ms, t->ev0, t->ev1));
+    const TraceCtrl* h = (const TraceCtrl*)t->host_pinned;
+    t->stats[0] += 1;
+    t->stats[1] += (double)n_cur;
+    t->stats[2] += ms;
+    t->stats[3] += 4;
     if (h->error) { error = h->error; break; }
-    const int64_t live = c->host_pinned[6];
+    const int64_t live = t->host_pinned[6];
     rows_per_generation[g] = live;
     total_rows += live;
-    s->stats[4] += (double)live;
-    s->stats[5] += (double)h->n_cur;
+    t->stats[4] += (double)live;
+    t->stats[5] += (double)h->n_cur;
     n_cur = h->n_cur;
     src = dst;
     src_ld = n;
@@ -1457,26 +1470,26 @@ static int64_t trace_unfused(prt_scene* s, DeviceCopy* c, const double* rays, in
 // between (a generation whose predecessor left no rays exits in its prologue)
 static const int kGenerationBatch = 4;
 
-// add the HIP-event time of the last batch to the kernel-time statistic (waits for ev1 if need be:
-// by the time anybody asks, the batch has long finished)
-static int settle_timing(prt_scene* s, DeviceCopy* c) {
-  if (!c->timing_pending) return PRT_OK;
-  c->timing_pending = false;
-  HIP_TRY(hipEventSynchronize(c->ev1));
+// add the HIP-event time of the ticket's last batch to its kernel-time statistic (waits for ev1 if
+// need be: by the time anybody asks, the batch has long finished)
+static int settle_timing(TraceTicket* t) {
+  if (!t->timing_pending) return PRT_OK;
+  t->timing_pending = false;
+  HIP_TRY(hipEventSynchronize(t->ev1));
   float ms = 0;
-  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-  s->stats[2] += ms;
+  HIP_TRY(hipEventElapsedTime(&ms, t->ev0, t->ev1));
+  t->stats[2] += ms;
   return PRT_OK;
 }
 
 // spin on the epoch word of the host mirror; gives up after ~2 s of polling and lets the stream
 // synchronisation report whatever went wrong
-static int await_epoch(DeviceCopy* c, unsigned long long epoch, hipStream_t st) {
-  volatile unsigned long long* word = &c->mirror->epoch;
+static int await_epoch(TraceTicket* t, unsigned long long epoch) {
+  volatile unsigned long long* word = &t->mirror->epoch;
   for (long spins = 0; __atomic_load_n(word, __ATOMIC_ACQUIRE) != epoch; ++spins) {
     __builtin_ia32_pause();
     if (spins > (1l << 28)) {
-      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(hipStreamSynchronize(t->st));
       if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != epoch) return fail(PRT_ERR_HIP, "trace batch never published its counts");
       break;
     }
@@ -1495,226 +1508,285 @@ extern "C" void prt_debug_host_profile(double* out9) { for (int k = 0; k < 8; ++
 #define HP(k)
 #endif
 
-static int64_t trace_fused(prt_scene* s, DeviceCopy* c, const double* rays, int64_t n, int64_t ld,
-                           int generation_limit, double ray_offset, double* rows_out,
-                           int64_t rows_cap, int64_t* rows_per_generation, char* w, int flags,
-                           hipStream_t st, bool allow_hints, bool compact) {
+// enqueue generations [t->g, t->g + t->batch) of the ticket's trace (one launch each, no host round trip
+// in between) and whatever has to run behind them; they publish t->epoch to the ticket's mirror
+static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
+  const int64_t n = t->n;
   const TraceLayout l = trace_layout(n);
+  char* w = t->w;
   FusedCtrl* ctrl = (FusedCtrl*)(w + l.fctrl);
   GenCtrl* gen = (GenCtrl*)(w + l.gen);
-  unsigned long long* tiles[2] = {(unsigned long long*)(w + l.tiles_a),
-                                  (unsigned long long*)(w + l.tiles_b)};
+  unsigned long long* tiles[2] = {(unsigned long long*)(w + l.tiles_a), (unsigned long long*)(w + l.tiles_b)};
   double* buf[2] = {(double*)(w + l.rays_a), (double*)(w + l.rays_b)};
-  const int keep_absorbed = (flags & PRT_TRACE_KEEP_ABSORBED) ? 1 : 0;
-  SceneDev sd = trace_scene_dev(s, c);
+  const int keep_absorbed = (t->flags & PRT_TRACE_KEEP_ABSORBED) ? 1 : 0;
+  const SceneDev sd = trace_scene_dev(s, c);
   // (shading from an LDS copy of the primitive table was tried in two forms -- per lane without the
   // waterfall, and inside the waterfall -- and measured 2-17 % slower than the batched L1 reads)
-  const size_t lds = lds_bytes_fused(sd.lds_slots);
-  const int n_slots = generation_limit + 1;
-  // PRT_TEST_STALL=1 makes one tile report an expired look-back so that the tests can exercise
-  // the fallback to the three-kernel path.
-  const char* stall_env = getenv("PRT_TEST_STALL");
-  const int test_stall = (stall_env && stall_env[0] == '1') ? 1 : 0;
-  int rc;
+  size_t lds = lds_bytes_fused(sd.lds_slots);
+#ifdef PRT_LDS_PAD  // experiment build: extra dynamic LDS lowers the occupancy without touching the code
+  lds += PRT_LDS_PAD;
+#endif
+  hipStream_t st = t->st;
+  int rc = settle_timing(t);
+  if (rc) return rc;
+  HP(2);
+  const unsigned long long epoch = ++t->epoch;
+  HIP_TRY(hipEventRecord(t->ev0, st));
+  HP(3);
+  const bool culls = s->has_cull_steps;
+  auto kernel = t->compact ? (culls ? k_generation<true, true> : k_generation<false, true>)
+                           : (culls ? k_generation<true, false> : k_generation<false, false>);
+  for (int b = 0; b < t->batch; ++b) {
+    const int gg = t->g + b;
+    const double* src = (gg == 0) ? t->rays : buf[(gg - 1) & 1];
+    const int64_t src_ld = (gg == 0) ? t->ld : n;
+    // dense-mode hint of the previous trace for this generation (the kernel reads the generation's
+    // ray count on the device and checks the assumption tile by tile)
+    int assume = 0;
+    if (t->use_hints && gg < (int)s->hint_mode.size()) assume = s->hint_mode[gg];
+    s->dense_launches += assume ? 1 : 0;
+    // launches, not generations, alternate between the two status buffers, across traces too: every
+    // launch works on the one the launch before it left clean and cleans the other (k_generation)
+    hipLaunchKernelGGL(kernel, dim3(blocks_for(n)), dim3(PRT_BLOCK), lds, st, sd, src, src_ld, buf[gg & 1], n,
+                       t->rows_out, t->rows_cap, ctrl, gen, gg, tiles[t->flip], tiles[t->flip ^ 1], (double)(gg + 1),
+                       t->limit, t->ray_offset, keep_absorbed,
+                       t->publish_in_kernel ? t->mirror_dev : (HostMirror*)nullptr, epoch, b,
+                       b + 1 == t->batch ? 1 : 0, assume);
+    t->flip ^= 1;
+    if (b == 0) HP(4);
+  }
+  HIP_TRY(hipEventRecord(t->ev1, st));
+  t->timing_pending = true;
+  // Behind the batch, only when the generation kernels did not tell the host themselves: a one-block
+  // kernel that does (and re-arms the control words if the batch turns out to end the trace).  In
+  // the usual case nothing runs behind the batch: the status buffers recycle each other, a
+  // generation slot is always written by the launch before the one that reads it, and the error
+  // word of a trace that succeeded is still zero.
+  if (!t->publish_in_kernel) {
+    hipLaunchKernelGGL(k_fused_reinit, dim3(1), dim3(1024), 0, st, ctrl, gen, t->limit + 1, t->g + t->batch,
+                       t->limit, tiles[0], (int64_t)blocks_for(n), n, t->test_stall, t->mirror_dev, epoch,
+                       t->g, t->batch + 1);
+  }
+  HIP_TRY(hipGetLastError());
+  HP(5);
+  t->launched = true;
+  return PRT_OK;
+}
+
+// start an attempt of the ticket's trace on the fused path: control words, hints, first batch
+static int fused_start(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
+  const int64_t n = t->n;
+  const TraceLayout l = trace_layout(n);
+  char* w = t->w;
+  const int n_slots = t->limit + 1;
+  const int keep_absorbed = (t->flags & PRT_TRACE_KEEP_ABSORBED) ? 1 : 0;
+  t->test_stall = (t->flags & PRT_TRACE_TEST_STALL) ? 1 : 0;
   // A trace leaves the control words (generation slots, tile status buffers, error word) as the next
   // trace of the same shape needs them (see the launch loop); only a first trace, one with another
   // workspace / ray count / limit, or one behind a trace that failed clears them here.
-  if (c->user == 0) c->user = g_next_user.fetch_add(1);
-  const bool others = workspace_taken_over(w, c->user);
-  if (others || !(c->ready_workspace == w && c->ready_n == n && c->ready_slots == n_slots && c->ready_stall == test_stall)) {
-    hipLaunchKernelGGL(k_fused_init, dim3(64), dim3(256), 0, st, ctrl, gen, n_slots, tiles[0],
-                       (int64_t)blocks_for(n), n, test_stall);
-    c->flip = 0;
+  if (t->user == 0) t->user = g_next_user.fetch_add(1);
+  const bool others = workspace_taken_over(w, t->user);
+  if (others || !(t->ready_workspace == w && t->ready_n == n && t->ready_slots == n_slots &&
+                  t->ready_stall == t->test_stall)) {
+    hipLaunchKernelGGL(k_fused_init, dim3(64), dim3(256), 0, t->st, (FusedCtrl*)(w + l.fctrl), (GenCtrl*)(w + l.gen),
+                       n_slots, (unsigned long long*)(w + l.tiles_a), (int64_t)blocks_for(n), n, t->test_stall);
+    t->flip = 0;
   }
-  c->ready_workspace = nullptr;
-
-  size_t lds_pad = 0;  // experiment: PRT_LDS_PAD=<bytes> lowers occupancy without touching the code
-  if (const char* pad_env = getenv("PRT_LDS_PAD")) lds_pad = (size_t)atol(pad_env);
-  const bool culls = count_steps(s->trace_program.code, I_BOX) > 0;
+  t->ready_workspace = nullptr;
   // the generation kernels tell the host themselves unless an error can still be raised after the
   // last tile has its totals (only PRT_ERR_UNTRACABLE, at store time) or an experiment kernel runs
   // (the stall test hook raises its fake error from a tile that no successor waits for: same path)
-  const bool publish_in_kernel = !s->has_untracable && !test_stall && getenv("PRT_PUBLISH_KERNEL") == nullptr;
-  // Hints from the previous trace of this scene with this many rays (PRT_NO_HINTS=1 turns them off).
+  t->publish_in_kernel = !s->has_untracable && !t->test_stall && !(t->flags & PRT_TRACE_PUBLISH_KERNEL);
+  // Hints from the previous trace of this scene with this many rays (PRT_TRACE_NO_HINTS turns them off).
   // After a miss the hints rest for 2, 4, 8 ... 64 traces (a caller that alternates between ray sets of
   // different shapes must not pay a repeat every time).
+  bool allow_hints = t->allow_hints;
   if (allow_hints && s->hint_holdoff > 0) {
     s->hint_holdoff -= 1;
     allow_hints = false;
   }
-  const bool use_hints = allow_hints && s->hint_n == n && s->hint_keep_absorbed == keep_absorbed &&
-                         getenv("PRT_NO_HINTS") == nullptr && !test_stall;
-  int64_t bound = n, total_rows = 0;
-  int g = 0, error = 0;
-  bool done = false;
-  std::vector<char> seen_mode;
-  while (g < generation_limit && !done) {
-    // Generations are launched blind, a batch at a time, and the host looks at the counts once per
-    // batch.  A scene traced before most likely runs as many generations as last time: launching
-    // exactly that many first means neither a launch that finds no rays nor a second round trip.
-    int want = kGenerationBatch;
-    if (g == 0 && s->last_generations > 0) want = std::min(s->last_generations, kMaxBatch);
-    const int batch = std::min(want, generation_limit - g);
-    HP(1);
-    rc = settle_timing(s, c);
-    if (rc) return rc;
-    HP(2);
-    const unsigned long long epoch = ++c->epoch;
-    bool in_kernel_publish = publish_in_kernel;
-    HIP_TRY(hipEventRecord(c->ev0, st));
-    HP(3);
-    for (int b = 0; b < batch; ++b) {
-      const int gg = g + b;
-      const double* src = (gg == 0) ? rays : buf[(gg - 1) & 1];
-      const int64_t src_ld = (gg == 0) ? ld : n;
-      // dense-mode hint of the previous trace for this generation (the kernel reads the generation's
-      // ray count on the device and checks the assumption tile by tile)
-      int assume = 0;
-      if (use_hints && gg < (int)s->hint_mode.size()) assume = s->hint_mode[gg];
-      s->dense_launches += assume ? 1 : 0;
-      auto kernel = compact ? (culls ? k_generation<true, true> : k_generation<false, true>)
-                            : (culls ? k_generation<true, false> : k_generation<false, false>);
-      // launches, not generations, alternate between the two status buffers, across traces too: every
-      // launch works on the one the launch before it left clean and cleans the other (k_generation)
-      hipLaunchKernelGGL(kernel, dim3(blocks_for(n)), dim3(PRT_BLOCK), lds + lds_pad, st, sd, src,
-                         src_ld, buf[gg & 1], n, rows_out, rows_cap, ctrl, gen, gg, tiles[c->flip],
-                         tiles[c->flip ^ 1], (double)(gg + 1), generation_limit, ray_offset, keep_absorbed,
-                         in_kernel_publish ? c->mirror_dev : (HostMirror*)nullptr, epoch, b,
-                         b + 1 == batch ? 1 : 0, assume);
-      c->flip ^= 1;
-      if (b == 0) HP(4);
-    }
-    HIP_TRY(hipEventRecord(c->ev1, st));
-    c->timing_pending = true;
-    // Behind the batch, only when the generation kernels did not tell the host themselves: a one-block
-    // kernel that does (and re-arms the control words if the batch turns out to end the trace).  In
-    // the usual case nothing runs behind the batch: the status buffers recycle each other, a
-    // generation slot is always written by the launch before the one that reads it, and the error
-    // word of a trace that succeeded is still zero.
-    if (!in_kernel_publish) {
-      hipLaunchKernelGGL(k_fused_reinit, dim3(1), dim3(1024), 0, st, ctrl, gen, n_slots, g + batch,
-                         generation_limit, tiles[0], (int64_t)blocks_for(n), n, test_stall, c->mirror_dev, epoch,
-                         g, batch + 1);
-    }
-    HIP_TRY(hipGetLastError());
-    HP(5);
-    rc = await_epoch(c, epoch, st);
-    if (rc) return rc;
-    HP(6);
-    const GenCtrl* host_gen = c->mirror->gen;
-    s->stats[3] += batch;
-    error = c->mirror->error;
-    if (error) break;
-    for (int b = 0; b < batch; ++b) {
-      if (host_gen[b].n_in == 0) { done = true; break; }
-      s->stats[0] += 1;
-      s->stats[1] += (double)host_gen[b].n_in;
-      s->stats[4] += (double)host_gen[b].n_live;
-      s->stats[5] += (double)host_gen[b].n_carry;
-      rows_per_generation[g + b] = host_gen[b].n_live;
-      total_rows += host_gen[b].n_live;
-      const bool all_live = host_gen[b].n_live == host_gen[b].n_in;
-      seen_mode.push_back(all_live && host_gen[b].n_carry == host_gen[b].n_in ? 1
-                          : all_live && host_gen[b].n_carry == 0 ? 2 : 0);
-    }
-    if (!done) bound = host_gen[batch].n_in;
-    if (bound == 0) done = true;
-    g += batch;
-  }
-#ifdef PRT_TIMING
-  if (const char* path = getenv("PRT_TIMING_FILE")) {
-    std::vector<long long> host(16384 * 4 * 8);
-    if (hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(g_stamps), host.size() * sizeof(long long)) == hipSuccess) {
-      if (FILE* f = fopen(path, "wb")) { fwrite(host.data(), sizeof(long long), host.size(), f); fclose(f); }
-    }
-  }
-#endif
-  if (error == PRT_ERR_SPECULATION || error == PRT_ERR_FULL_ROWS) return error;
-  if (error) return trace_error(error);
-  if (!publish_in_kernel) c->flip = 0;  // (k_fused_reinit cleared buffer 0; the next launch cleans buffer 1)
-  s->last_generations = (int)s->stats[0];
-  s->hint_n = n;
-  s->hint_keep_absorbed = keep_absorbed;
-  s->hint_mode = seen_mode;
-  if (use_hints) s->hint_misses_in_a_row = 0;
-  // the control words are as a next trace of this shape needs them (see the launch loop)
-  c->ready_workspace = w;
-  c->ready_n = n;
-  c->ready_slots = n_slots;
-  c->ready_stall = test_stall;
-  return total_rows;
+  t->use_hints = allow_hints && s->hint_n == n && s->hint_keep_absorbed == keep_absorbed && !t->test_stall;
+  t->g = 0;
+  t->n_seen = 0;
+  t->total_rows = 0;
+  // Generations are launched blind, a batch at a time, and the host looks at the counts once per
+  // batch.  A scene traced before most likely runs as many generations as last time: launching
+  // exactly that many first means neither a launch that finds no rays nor a second round trip.
+  int want = kGenerationBatch;
+  if (s->last_generations > 0) want = std::min(s->last_generations, kMaxBatch);
+  t->batch = std::min(want, t->limit);
+  HP(1);
+  return fused_launch_batch(s, c, t);
 }
 
-extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64_t n, int64_t ld,
-                             int generation_limit, double ray_offset, double* rows_out,
-                             int64_t rows_cap, int64_t* rows_per_generation, void* workspace,
-                             int flags, void* stream) {
+// wait for the attempt's batch, look at its counts, enqueue further batches until the trace is over.
+// Returns the number of rows, or an error (the internal ones included: the caller repeats the attempt).
+static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t* rows_per_generation) {
+  const int keep_absorbed = (t->flags & PRT_TRACE_KEEP_ABSORBED) ? 1 : 0;
+  int error = 0;
+  bool done = false;
+  while (true) {
+    int rc = await_epoch(t, t->epoch);
+    if (rc) return rc;
+    HP(6);
+    const GenCtrl* host_gen = t->mirror->gen;
+    t->stats[3] += t->batch;
+    error = t->mirror->error;
+    if (error) break;
+    for (int b = 0; b < t->batch; ++b) {
+      if (host_gen[b].n_in == 0) { done = true; break; }
+      t->stats[0] += 1;
+      t->stats[1] += (double)host_gen[b].n_in;
+      t->stats[4] += (double)host_gen[b].n_live;
+      t->stats[5] += (double)host_gen[b].n_carry;
+      rows_per_generation[t->g + b] = host_gen[b].n_live;
+      t->total_rows += host_gen[b].n_live;
+      const bool all_live = host_gen[b].n_live == host_gen[b].n_in;
+      t->seen_mode[t->n_seen++] = all_live && host_gen[b].n_carry == host_gen[b].n_in ? 1
+                                  : all_live && host_gen[b].n_carry == 0 ? 2 : 0;
+    }
+    if (!done && host_gen[t->batch].n_in == 0) done = true;
+    t->g += t->batch;
+    if (done || t->g >= t->limit) break;
+    t->batch = std::min(kGenerationBatch, t->limit - t->g);
+    rc = fused_launch_batch(s, c, t);
+    if (rc) return rc;
+  }
+  t->launched = false;
+  if (error == PRT_ERR_SPECULATION || error == PRT_ERR_FULL_ROWS) return error;
+  // a record block that looked too small to a generation launched on a hint may only have been too small
+  // for the hint: the caller repeats without hints before it reports it
+  if (error == PRT_ERR_ROWS_CAP && t->use_hints) return PRT_ERR_SPECULATION;
+  if (error == PRT_ERR_STALL) return PRT_ERR_STALL;
+  if (error) return trace_error(error);
+  if (!t->publish_in_kernel) t->flip = 0;  // (k_fused_reinit cleared buffer 0; the next launch cleans buffer 1)
+  s->last_generations = (int)t->stats[0];
+  s->hint_n = t->n;
+  s->hint_keep_absorbed = keep_absorbed;
+  s->hint_mode.assign(t->seen_mode, t->seen_mode + t->n_seen);
+  if (t->use_hints) s->hint_misses_in_a_row = 0;
+  // the control words are as a next trace of this shape needs them (see the launch loop)
+  t->ready_workspace = t->w;
+  t->ready_n = t->n;
+  t->ready_slots = t->limit + 1;
+  t->ready_stall = t->test_stall;
+  return t->total_rows;
+}
+
+static void reset_stats(prt_scene* s, TraceTicket* t, int variant) {
+  for (double& v : t->stats) v = 0;
+  t->stats[6] = (double)s->lookback_fallbacks;
+  t->stats[7] = variant;
+}
+
+extern "C" int prt_trace_begin(prt_scene* s, int device, int ticket, const double* rays, int64_t n, int64_t ld,
+                               int generation_limit, double ray_offset, double* rows_out, int64_t rows_cap,
+                               void* workspace, int flags, void* stream) {
   HP(0);
   DeviceCopy* c;
   int rc = on_device(s, device, &c);
   if (rc) return rc;
+  if (ticket < 0 || ticket >= PRT_TRACE_TICKETS) return fail(PRT_ERR_ARG, "ticket out of range");
+  TraceTicket* t = &c->ticket[ticket];
+  if (t->active) return fail(PRT_ERR_ARG, "this ticket has a trace in flight (prt_trace_end it first)");
   if (n < 0 || ld < n || generation_limit < 0 || generation_limit > kMaxGenerationSlots ||
-      rows_cap < 0 || !rows_per_generation || !workspace || (n && !rays) || (rows_cap && !rows_out))
+      rows_cap < 0 || !workspace || (n && !rays) || (rows_cap && !rows_out))
     return fail(PRT_ERR_ARG, "bad buffers (generation_limit must be <= 1024)");
   if (n >= (1ll << 31)) return fail(PRT_ERR_ARG, "at most 2^31-1 rays per call");
-  for (int g = 0; g < generation_limit; ++g) rows_per_generation[g] = 0;
-  rc = settle_timing(s, c);  // events of the previous trace, before its statistics are dropped
+  for (int k = 0; k < PRT_TRACE_TICKETS; ++k)
+    if (k != ticket && c->ticket[k].active && n && c->ticket[k].n &&
+        (c->ticket[k].w == (char*)workspace || c->ticket[k].rows_out == rows_out || c->ticket[k].st != (hipStream_t)stream))
+      return fail(PRT_ERR_ARG, "traces in flight together need their own workspace and record block, and one stream");
+  rc = settle_timing(t);  // events of the ticket's previous trace, before they are recorded again
   if (rc) return rc;
-  for (double& v : s->stats) v = 0;
-  if (n == 0 || generation_limit == 0) return 0;
-  s->stats[6] = (double)s->lookback_fallbacks;
-  if (flags & PRT_TRACE_UNFUSED) {
-    s->stats[7] = hit_variant().lanes > 1 ? PRT_VARIANT_KLANES : PRT_VARIANT_UNFUSED;
-    return trace_unfused(s, c, rays, n, ld, generation_limit, ray_offset, rows_out, rows_cap,
-                         rows_per_generation, (char*)workspace, flags, (hipStream_t)stream);
+  t->rays = rays; t->n = n; t->ld = ld; t->limit = generation_limit; t->ray_offset = ray_offset;
+  t->rows_out = rows_out; t->rows_cap = rows_cap; t->w = (char*)workspace; t->flags = flags;
+  t->st = (hipStream_t)stream;
+  t->launched = false;
+  t->allow_hints = !(flags & PRT_TRACE_NO_HINTS);
+  t->compact = !s->full_rows && !(flags & PRT_TRACE_FULL_ROWS);
+  t->active = true;
+  if (n == 0 || generation_limit == 0) { reset_stats(s, t, PRT_VARIANT_FUSED); return PRT_OK; }
+  if (flags & PRT_TRACE_UNFUSED) {  // host round trip per generation: everything happens in prt_trace_end
+    reset_stats(s, t, s->options.hit_lanes > 1 ? PRT_VARIANT_KLANES : PRT_VARIANT_UNFUSED);
+    return PRT_OK;
   }
-  s->stats[7] = PRT_VARIANT_FUSED;
+  reset_stats(s, t, PRT_VARIANT_FUSED);
+  rc = fused_start(s, c, t);
+  if (rc) t->active = false;
+  return rc;
+}
+
+extern "C" int64_t prt_trace_end(prt_scene* s, int device, int ticket, int64_t* rows_per_generation) {
+  DeviceCopy* c;
+  int rc = on_device(s, device, &c);
+  if (rc) return rc;
+  if (ticket < 0 || ticket >= PRT_TRACE_TICKETS || !rows_per_generation)
+    return fail(PRT_ERR_ARG, "bad ticket / null rows_per_generation");
+  TraceTicket* t = &c->ticket[ticket];
+  if (!t->active) return fail(PRT_ERR_ARG, "no trace in flight on this ticket");
+  t->active = false;
+  s->stats_device = device;
+  s->stats_ticket = ticket;
+  for (int g = 0; g < t->limit; ++g) rows_per_generation[g] = 0;
+  if (t->n == 0 || t->limit == 0) return 0;
   int64_t rc64 = 0;
-  bool allow_hints = true;
-  for (int attempt = 0; attempt < 4; ++attempt) {
-    rc64 = trace_fused(s, c, rays, n, ld, generation_limit, ray_offset, rows_out, rows_cap, rows_per_generation,
-                       (char*)workspace, flags, (hipStream_t)stream, allow_hints,
-                       !s->full_rows && getenv("PRT_FULL_ROWS") == nullptr);
-    if (rc64 != PRT_ERR_SPECULATION && rc64 != PRT_ERR_FULL_ROWS) break;
-    if (rc64 == PRT_ERR_SPECULATION) {
-      // a generation assumed dense was not (the rays or the scene changed since the hints were taken):
-      // nothing of this attempt is kept; run again without assumptions, which also renews the hints
-      s->speculation_misses += 1;
-      s->hint_misses_in_a_row = std::min(s->hint_misses_in_a_row + 1, 6);
-      s->hint_holdoff = 1 << s->hint_misses_in_a_row;
-      s->hint_n = -1;
-      allow_hints = false;
-    } else {
-      // a ray needs the state rows the compact form leaves out (homogeneous w other than 1 / +0, or a
-      // ray set that does not start at generation 0): this scene traces with all 13 rows from now on
-      s->full_rows = true;
-      s->full_rows_fallbacks += 1;
+  if (t->flags & PRT_TRACE_UNFUSED) {
+    rc64 = trace_unfused(s, c, t, rows_per_generation);
+  } else {
+    for (int attempt = 0;; ++attempt) {
+      rc64 = fused_finish(s, c, t, rows_per_generation);
+      if ((rc64 != PRT_ERR_SPECULATION && rc64 != PRT_ERR_FULL_ROWS) || attempt == 3) break;
+      if (rc64 == PRT_ERR_SPECULATION) {
+        // a generation assumed dense was not (the rays or the scene changed since the hints were taken):
+        // nothing of this attempt is kept; run again without assumptions, which also renews the hints
+        s->speculation_misses += 1;
+        s->hint_misses_in_a_row = std::min(s->hint_misses_in_a_row + 1, 6);
+        s->hint_holdoff = 1 << s->hint_misses_in_a_row;
+        s->hint_n = -1;
+        t->allow_hints = false;
+      } else {
+        // a ray needs the state rows the compact form leaves out (homogeneous w other than 1 / +0, or a
+        // ray set that does not start at generation 0): this scene traces with all 13 rows from now on
+        s->full_rows = true;
+        s->full_rows_fallbacks += 1;
+        t->compact = false;
+      }
+      for (int g = 0; g < t->limit; ++g) rows_per_generation[g] = 0;
+      rc = settle_timing(t);
+      if (rc) return rc;
+      reset_stats(s, t, PRT_VARIANT_FUSED);
+      rc = fused_start(s, c, t);
+      if (rc) return rc;
     }
-    for (int g = 0; g < generation_limit; ++g) rows_per_generation[g] = 0;
-    rc = settle_timing(s, c);
-    if (rc) return rc;
-    const double fallbacks = s->stats[6];
-    for (double& v : s->stats) v = 0;
-    s->stats[6] = fallbacks;
-    s->stats[7] = PRT_VARIANT_FUSED;
+    if (rc64 == PRT_ERR_SPECULATION || rc64 == PRT_ERR_FULL_ROWS) rc64 = fail(PRT_ERR_HIP, "trace kept failing its own assumptions");
+    if (rc64 == PRT_ERR_STALL) {  // never observed outside the test hook; see lookback()
+      for (int g = 0; g < t->limit; ++g) rows_per_generation[g] = 0;
+      rc = settle_timing(t);
+      if (rc) return rc;
+      s->lookback_fallbacks += 1;  // telemetry: a box that falls back silently would just look 2x slow
+      reset_stats(s, t, PRT_VARIANT_UNFUSED);
+      rc64 = trace_unfused(s, c, t, rows_per_generation);
+    }
   }
-  if (rc64 == PRT_ERR_STALL) {  // never observed outside the test hook; see lookback()
-    for (int g = 0; g < generation_limit; ++g) rows_per_generation[g] = 0;
-    rc = settle_timing(s, c);
-    if (rc) return rc;
-    for (double& v : s->stats) v = 0;
-    s->lookback_fallbacks += 1;  // telemetry: a box that falls back silently would just look 2x slow
-    s->stats[6] = (double)s->lookback_fallbacks;
-    s->stats[7] = PRT_VARIANT_UNFUSED;
-    rc64 = trace_unfused(s, c, rays, n, ld, generation_limit, ray_offset, rows_out, rows_cap,
-                         rows_per_generation, (char*)workspace, flags, (hipStream_t)stream);
-  }
+  if (rc64 >= 0 && (t->flags & PRT_TRACE_SYNC)) HIP_TRY(hipStreamSynchronize(t->st));
 #ifdef PRT_HOST_PROFILE
   HP(7);
   for (int k = 1; k < 8; ++k) g_hp[k] += g_hp_t[k] - g_hp_t[0];
   g_hp_n += 1;
 #endif
   return rc64;
+}
+
+extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64_t n, int64_t ld,
+                             int generation_limit, double ray_offset, double* rows_out,
+                             int64_t rows_cap, int64_t* rows_per_generation, void* workspace,
+                             int flags, void* stream) {
+  if (!rows_per_generation) return fail(PRT_ERR_ARG, "rows_per_generation is null");
+  const int rc = prt_trace_begin(s, device, 0, rays, n, ld, generation_limit, ray_offset, rows_out, rows_cap,
+                                 workspace, flags, stream);
+  if (rc) return rc;
+  return prt_trace_end(s, device, 0, rows_per_generation);
 }
 
 #ifdef PRT_COUNT_SLOW
@@ -1728,25 +1800,38 @@ extern "C" int prt_debug_slow_counters(unsigned long long* out4, int reset) {
 }
 #endif
 
-extern "C" int prt_trace_telemetry(const prt_scene* s, int64_t* out4) {
-  if (!s || !out4) return fail(PRT_ERR_ARG, "null argument");
-  out4[0] = s->lookback_fallbacks;
-  out4[1] = s->speculation_misses;
-  out4[2] = s->dense_launches;
-  out4[3] = s->full_rows_fallbacks;
+extern "C" int prt_trace_telemetry(const prt_scene* s, int64_t* out8) {
+  if (!s || !out8) return fail(PRT_ERR_ARG, "null argument");
+  out8[0] = s->lookback_fallbacks;
+  out8[1] = s->speculation_misses;
+  out8[2] = s->dense_launches;
+  out8[3] = s->full_rows_fallbacks;
+  for (int k = 0; k < 4; ++k) out8[4 + k] = s->path_counts[k];
   return PRT_OK;
 }
 
 extern "C" int prt_trace_stats(const prt_scene* s, double* out8) {
   if (!s || !out8) return fail(PRT_ERR_ARG, "null argument");
-  prt_scene* scene = const_cast<prt_scene*>(s);
-  for (DeviceCopy& c : scene->per_device) {  // the last batch's event time is collected on demand
-    int rc = settle_timing(scene, &c);
+  for (int k = 0; k < 8; ++k) out8[k] = 0;
+  if (s->stats_device < 0 || s->stats_device >= (int)s->per_device.size()) return PRT_OK;  // nothing traced yet
+  TraceTicket* t = &const_cast<prt_scene*>(s)->per_device[s->stats_device].ticket[s->stats_ticket];
+  if (!t->active) {  // (begun again already: its events belong to the new trace; the time stays out)
+    HIP_TRY(hipSetDevice(s->stats_device));
+    int rc = settle_timing(t);  // the last batch's event time is collected on demand
     if (rc) return rc;
   }
-  for (int k = 0; k < 8; ++k) out8[k] = s->stats[k];
+  for (int k = 0; k < 8; ++k) out8[k] = t->stats[k];
   return PRT_OK;
 }
+
+#ifdef PRT_TIMING
+// experiment build: the s_memtime stamps of generation 0's waves (tools/lookback_analysis.py)
+extern "C" int prt_debug_wave_stamps(long long* out, int64_t count) {
+  if (!out || count < 0 || count > 16384 * 4 * 8) return PRT_ERR_ARG;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), (size_t)count * sizeof(long long)) != hipSuccess) return PRT_ERR_HIP;
+  return PRT_OK;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // renderers

@@ -38,27 +38,54 @@ struct Program {
   std::vector<int32_t> component_first;  // per component: first and one-past-last step slot (its own cull step included)
 };
 
+// One trace in flight (prt_trace_begin ... prt_trace_end).  A scene has PRT_TRACE_TICKETS of them per
+// device, each with its own host mirror, events and record of the control words it left in its
+// workspace, so that the host can enqueue the next trace while the GPU still runs the previous one.
+static const int kMaxGenerationSlots = 1024;
+struct TraceTicket {
+  bool active = false;       // begun, not ended yet
+  // the call's arguments
+  const double* rays = nullptr;
+  int64_t n = 0, ld = 0;
+  int limit = 0;
+  double ray_offset = 0;
+  double* rows_out = nullptr;
+  int64_t rows_cap = 0;
+  char* w = nullptr;
+  int flags = 0;
+  hipStream_t st = nullptr;
+  // the attempt in flight (fused path): generations [g, g + batch) are enqueued and publish `epoch`
+  bool launched = false, allow_hints = true, use_hints = false, compact = true, publish_in_kernel = true;
+  int g = 0, batch = 0, test_stall = 0, n_seen = 0;
+  int64_t total_rows = 0;
+  char seen_mode[kMaxGenerationSlots];
+  double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // include/prt.h prt_trace_stats
+  // resources of the ticket
+  int64_t* host_pinned = nullptr;               // 8 x int64 pinned staging (three-kernel path)
+  struct HostMirror* mirror = nullptr;          // host-mapped: the device publishes a batch's counts here
+  struct HostMirror* mirror_dev = nullptr;      // the same memory as the device addresses it
+  unsigned long long epoch = 0;                 // number of batches published so far
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timing_pending = false;                  // ev0..ev1 of the last batch not yet added to stats[2]
+  // control words already initialised on the stream for a next trace of this shape (see fused_start)
+  const void* ready_workspace = nullptr;
+  int64_t ready_n = -1;
+  int ready_slots = 0, ready_stall = 0;
+  int flip = 0;  // which of the two tile-status buffers the next generation launch works on
+  unsigned long long user = 0;  // identity of this ticket in the workspace registry (0: not drawn yet)
+};
+
 struct DeviceCopy {
   DevPrim* prims = nullptr;
   DevInstr* trace_code = nullptr;               // all components, each reduced to its candidate hit
   int32_t* trace_component_first = nullptr;     // [2 * components] step ranges of trace_code (k-lanes kernels)
   DevInstr* render_code = nullptr;              // same with the renderers' selection rule
   std::vector<DevInstr*> component_code;        // one program per component, no I_ROOT
-  int64_t* host_pinned = nullptr;               // 8 x int64 pinned staging
-  struct HostMirror* mirror = nullptr;          // host-mapped: the device publishes a batch's counts here
-  struct HostMirror* mirror_dev = nullptr;      // the same memory as the device addresses it
-  unsigned long long epoch = 0;                 // number of batches published so far
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool timing_pending = false;                  // ev0..ev1 of the last batch not yet added to stats[2]
-  // control words already initialised on the stream for a next trace of this shape (see trace_fused)
-  const void* ready_workspace = nullptr;
-  int64_t ready_n = -1;
-  int ready_slots = 0, ready_stall = 0;
-  int flip = 0;  // which of the two tile-status buffers the next generation launch works on
-  unsigned long long user = 0;  // identity of this copy in the workspace registry (0: not drawn yet)
+  TraceTicket ticket[PRT_TRACE_TICKETS];
 };
 
 struct prt_scene {
+  prt_scene_options options;                    // as given to prt_scene_create / prt_scene_update (zeros = defaults)
   std::vector<prt_prim> prims;
   std::vector<prt_node> nodes;
   std::vector<int32_t> roots;
@@ -70,7 +97,8 @@ struct prt_scene {
   std::vector<Operand> component_result;        // where each component program leaves its list
   std::vector<DeviceCopy> per_device;
   bool has_untracable = false;
-  double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool has_cull_steps = false;                  // the trace program carries I_BOX steps (k_generation<CULL>)
+  int stats_device = -1, stats_ticket = 0;      // whose statistics prt_trace_stats reports: the trace ended last
   int last_generations = 0;  // working generations of the previous trace: sizes the first batch
   long lookback_fallbacks = 0;  // traces of this scene that fell back to the three-kernel path
   // what the previous trace's generations looked like (dense-mode hints for the next one, see k_generation)
@@ -81,6 +109,9 @@ struct prt_scene {
   bool full_rows = false;       // a ray set of this scene needed the state rows the compact form leaves out
   long full_rows_fallbacks = 0; // traces that had to be repeated for that reason (at most one per scene)
   long dense_launches = 0;      // generation launches made in dense mode so far
+  // PRT_TRACE_COUNT_PATHS: traces counted, rays that were not well formed, CSG node evaluations under an
+  // implied cull box that had survivors, ... of which took upstream's exact box test
+  long long path_counts[4] = {0, 0, 0, 0};
   int hint_holdoff = 0;         // traces still to run without hints after a miss (doubles with every miss in a row)
   int hint_misses_in_a_row = 0;
 };
@@ -143,7 +174,7 @@ struct Compiler {
   // 500-seed fuzz tier: a stale, empty box culls every ray upstream).
   bool box_contains_solid(int node) const {
     const prt_node& n = s->nodes[node];
-    if (std::getenv("PRT_NO_IMPLIED") != nullptr) return false;  // test knob: every node tests its cull box exactly
+    if (s->options.no_implied) return false;  // test knob: every node tests its cull box exactly
     if (n.op == PRT_NODE_LEAF) return true;
     // the argument needs every leaf to see directions of length >= 0.1 in object space as long as
     // the world direction has |d|^2 >= kImpliedMinLen2 (csg_keep sends shorter ones to the exact test)
@@ -370,7 +401,7 @@ static int count_steps(const std::vector<DevInstr>& code, int kind) {
 // Is component `root_node` a left-deep chain of two or three leaves whose primitive types have a
 // compiled chain body?  Fills the record if so.
 static bool chain_record(const prt_scene* s, int root_node, const Compiler& c, DevChain* out) {
-  if (std::getenv("PRT_NO_CHAIN") != nullptr) return false;  // A/B and test knob: the step interpreter instead
+  if (s->options.no_chain) return false;  // A/B and test knob: the step interpreter instead
   const prt_node& top = s->nodes[root_node];
   if (top.op == PRT_NODE_LEAF || s->nodes[top.right].op != PRT_NODE_LEAF) return false;
   int leaves[3], n_leaves, nodes[2];
@@ -426,8 +457,8 @@ static Operand compile_component(const prt_scene* s, int root_node, std::vector<
   // a scene of several components gets a cull step in front of each: most rays can reach only one
   // or two of them (see may_reach); with one or two components the test would cost more than it saves
   size_t box_at = (size_t)-1;
-  const bool cull_off = std::getenv("PRT_NO_CULL") != nullptr;  // A/B and test knobs, read per scene
-  const int cull_min = std::getenv("PRT_CULL_MIN") ? std::atoi(std::getenv("PRT_CULL_MIN")) : 3;
+  const bool cull_off = s->options.no_cull != 0;  // A/B and test knobs (prt_scene_options)
+  const int cull_min = s->options.cull_min > 0 ? s->options.cull_min : 3;
   if (root_rule == ROOT_TRACE && (int)s->roots.size() >= cull_min && !cull_off) {
     DevInstr in = Compiler::blank(I_BOX);
     double* box = in.data;
@@ -540,15 +571,36 @@ static int validate_tree(const prt_scene* s, int node, int depth, std::vector<ch
 
 static const size_t kMaxLdsBytes = 150 * 1024;  // one workgroup per CU at the very most (160 KiB LDS)
 
+// options as the library keeps them: the caller's struct may be shorter (older header) or longer
+static int read_options(const prt_scene_options* given, prt_scene_options* out) {
+  std::memset(out, 0, sizeof(*out));
+  if (given) {
+    if (given->struct_size < (int32_t)(2 * sizeof(int32_t)))
+      return fail(PRT_ERR_ARG, "prt_scene_options.struct_size is not set");
+    std::memcpy(out, given, std::min((size_t)given->struct_size, sizeof(*out)));
+  }
+  out->struct_size = (int32_t)sizeof(*out);
+  const int lanes = out->hit_lanes;
+  if (!(lanes == 0 || lanes == 1 || lanes == 4 || lanes == 8 || lanes == 16))
+    return fail(PRT_ERR_ARG, "prt_scene_options.hit_lanes must be 0, 1, 4, 8 or 16");
+  if (out->cull_min < 0) return fail(PRT_ERR_ARG, "prt_scene_options.cull_min is negative");
+  return PRT_OK;
+}
+
 extern "C" int prt_scene_create(const prt_prim* prims, int n_prims, const prt_node* nodes,
                                 int n_nodes, const int32_t* roots, int n_roots,
-                                const prt_material* mats, int n_mats, prt_scene** out) {
+                                const prt_material* mats, int n_mats, const prt_scene_options* options,
+                                prt_scene** out) {
   if (!out) return fail(PRT_ERR_ARG, "out is null");
   *out = nullptr;
   if (n_prims < 0 || n_nodes < 0 || n_roots < 0 || n_mats < 0 ||
       (n_prims && !prims) || (n_nodes && !nodes) || (n_roots && !roots) || (n_mats && !mats))
     return fail(PRT_ERR_ARG, "null array with non-zero count");
+  prt_scene_options opts;
+  int rc_opts = read_options(options, &opts);
+  if (rc_opts) return rc_opts;
   prt_scene* s = new prt_scene();
+  s->options = opts;
   s->prims.assign(prims, prims + n_prims);
   s->nodes.assign(nodes, nodes + n_nodes);
   s->roots.assign(roots, roots + n_roots);
@@ -584,9 +636,10 @@ extern "C" int prt_scene_create(const prt_prim* prims, int n_prims, const prt_no
     s->dev_prims.push_back(d);
   }
   {
-    const bool cull_off = std::getenv("PRT_NO_CULL") != nullptr || std::getenv("PRT_NO_GROUPS") != nullptr;
+    const bool cull_off = s->options.no_cull != 0 || s->options.no_groups != 0;
     const bool grouped = (int)s->roots.size() >= kGroupMinComponents && !cull_off;
     if (!s->roots.empty()) compile_trace_run(s, 0, (int)s->roots.size(), grouped);
+    s->has_cull_steps = count_steps(s->trace_program.code, I_BOX) > 0;
   }
   for (int r : s->roots) {
     compile_component(s, r, s->render_program.code, ROOT_RENDER, &s->render_program.lds_slots);
@@ -615,10 +668,12 @@ extern "C" void prt_scene_destroy(prt_scene* s) {
     (void)hipFree(c.trace_component_first);
     (void)hipFree(c.render_code);
     for (DevInstr* p : c.component_code) (void)hipFree(p);
-    if (c.host_pinned) (void)hipHostFree(c.host_pinned);
-    if (c.mirror) (void)hipHostFree(c.mirror);
-    if (c.ev0) (void)hipEventDestroy(c.ev0);
-    if (c.ev1) (void)hipEventDestroy(c.ev1);
+    for (TraceTicket& t : c.ticket) {
+      if (t.host_pinned) (void)hipHostFree(t.host_pinned);
+      if (t.mirror) (void)hipHostFree(t.mirror);
+      if (t.ev0) (void)hipEventDestroy(t.ev0);
+      if (t.ev1) (void)hipEventDestroy(t.ev1);
+    }
   }
   delete s;
 }
@@ -630,10 +685,14 @@ extern "C" void prt_scene_destroy(prt_scene* s) {
 // would change size: the caller then builds a new scene.
 extern "C" int prt_scene_update(prt_scene* s, const prt_prim* prims, int n_prims, const prt_node* nodes,
                                 int n_nodes, const int32_t* roots, int n_roots, const prt_material* mats,
-                                int n_mats) {
+                                int n_mats, const prt_scene_options* options) {
   if (!s) return fail(PRT_ERR_ARG, "scene is null");
+  for (const DeviceCopy& c : s->per_device)
+    for (const TraceTicket& tk : c.ticket)
+      if (tk.active) return fail(PRT_ERR_ARG, "a trace of this scene is in flight (prt_trace_end it first)");
   prt_scene* t = nullptr;
-  const int rc = prt_scene_create(prims, n_prims, nodes, n_nodes, roots, n_roots, mats, n_mats, &t);
+  const int rc = prt_scene_create(prims, n_prims, nodes, n_nodes, roots, n_roots, mats, n_mats,
+                                  options ? options : &s->options, &t);
   if (rc) return rc;
   auto same_program = [](const Program& a, const Program& b) {
     return a.code.size() == b.code.size() && a.lds_slots == b.lds_slots &&
@@ -673,6 +732,8 @@ extern "C" int prt_scene_update(prt_scene* s, const prt_prim* prims, int n_prims
   s->dev_prims.swap(t->dev_prims);
   std::swap(s->trace_program, t->trace_program);
   std::swap(s->render_program, t->render_program);
+  s->options = t->options;
+  s->has_cull_steps = t->has_cull_steps;
   s->component_programs.swap(t->component_programs);
   s->component_result.swap(t->component_result);
   prt_scene_destroy(t);  // (never reached a device: host memory only)
@@ -733,14 +794,16 @@ static int on_device(prt_scene* s, int device, DeviceCopy** out) {
       if (rc) return rc;
       c.component_code.push_back(code);
     }
-    HIP_TRY(hipHostMalloc((void**)&c.host_pinned, 8 * sizeof(int64_t), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void**)&c.mirror, 64 + (kMaxBatch + 4) * 64, hipHostMallocMapped | hipHostMallocCoherent));  // header + GenCtrl slots of 64 B
-    std::memset((void*)c.mirror, 0, 64 + (kMaxBatch + 4) * 64);
-    HIP_TRY(hipHostGetDevicePointer((void**)&c.mirror_dev, (void*)c.mirror, 0));
+    for (TraceTicket& t : c.ticket) {
+      HIP_TRY(hipHostMalloc((void**)&t.host_pinned, 8 * sizeof(int64_t), hipHostMallocDefault));
+      HIP_TRY(hipHostMalloc((void**)&t.mirror, 64 + (kMaxBatch + 4) * 64, hipHostMallocMapped | hipHostMallocCoherent));  // header + GenCtrl slots of 64 B
+      std::memset((void*)t.mirror, 0, 64 + (kMaxBatch + 4) * 64);
+      HIP_TRY(hipHostGetDevicePointer((void**)&t.mirror_dev, (void*)t.mirror, 0));
+      HIP_TRY(hipEventCreate(&t.ev0));
+      HIP_TRY(hipEventCreate(&t.ev1));
+    }
     int rc_lds = raise_lds_limits();
     if (rc_lds) return rc_lds;
-    HIP_TRY(hipEventCreate(&c.ev0));
-    HIP_TRY(hipEventCreate(&c.ev1));
   }
   *out = &c;
   return PRT_OK;

@@ -20,6 +20,39 @@ DEFAULT_RAY_OFFSET = 1e-6
 
 TRACE_KEEP_ABSORBED = 1
 TRACE_UNFUSED = 2
+TRACE_NO_HINTS = 4
+TRACE_FULL_ROWS = 8
+TRACE_PUBLISH_KERNEL = 16
+TRACE_TEST_STALL = 32
+TRACE_SYNC = 64
+TRACE_COUNT_PATHS = 128
+TRACE_TICKETS = 2
+
+# prt_scene_options (include/prt.h): how a scene is compiled / which nearest-hit kernel serves
+# prt_propagate.  Zeros are the defaults; the rest are A/B and test knobs.  DEFAULT_OPTIONS and
+# DEFAULT_TRACE_FLAGS are what a DeviceScene uses when its caller says nothing (the test matrix sets
+# them, tests/conftest.py); the library itself reads nothing from the environment.
+OPTIONS_DTYPE = np.dtype(
+    [("struct_size", "<i4"), ("no_chain", "<i4"), ("no_cull", "<i4"), ("cull_min", "<i4"), ("no_groups", "<i4"),
+     ("no_implied", "<i4"), ("hit_lanes", "<i4"), ("hit_staged", "<i4"), ("list_order_groups", "<i4"),
+     ("reserved", "<i4", (7,))])
+assert OPTIONS_DTYPE.itemsize == 64
+OPTION_NAMES = tuple(name for name in OPTIONS_DTYPE.names if name not in ("struct_size", "reserved"))
+DEFAULT_OPTIONS = {}
+DEFAULT_TRACE_FLAGS = 0
+
+
+def options_record(options=None):
+    """The prt_scene_options struct for DEFAULT_OPTIONS overlaid with `options` (a dict or None)."""
+    merged = dict(DEFAULT_OPTIONS)
+    merged.update(options or {})
+    rec = np.zeros(1, dtype=OPTIONS_DTYPE)
+    rec["struct_size"] = OPTIONS_DTYPE.itemsize
+    for key, value in merged.items():
+        if key not in OPTION_NAMES:
+            raise ValueError(f"unknown scene option {key!r} (known: {', '.join(OPTION_NAMES)})")
+        rec[key] = int(value)
+    return rec
 
 ERR_ROWS_CAP = -4
 ERR_UNTRACABLE = -5
@@ -37,9 +70,9 @@ def _declare(lib):
         "prt_version": (c_int, []),
         "prt_last_error": (ctypes.c_char_p, []),
         "prt_device_count": (c_int, []),
-        "prt_scene_create": (c_int, [c_p, c_int, c_p, c_int, c_p, c_int, c_p, c_int, ctypes.POINTER(c_p)]),
+        "prt_scene_create": (c_int, [c_p, c_int, c_p, c_int, c_p, c_int, c_p, c_int, c_p, ctypes.POINTER(c_p)]),
         "prt_scene_destroy": (None, [c_p]),
-        "prt_scene_update": (c_int, [c_p, c_p, c_int, c_p, c_int, c_p, c_int, c_p, c_int]),
+        "prt_scene_update": (c_int, [c_p, c_p, c_int, c_p, c_int, c_p, c_int, c_p, c_int, c_p]),
         "prt_scene_component_rows": (c_int, [c_p, c_int]),
         "prt_scene_info": (c_int, [c_p, c_p]),
         "prt_intersect": (c_int, [c_p, c_int, c_int, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
@@ -52,6 +85,8 @@ def _declare(lib):
         "prt_trace_workspace_bytes": (c_i64, [c_i64]),
         "prt_trace": (c_i64, [c_p, c_int, c_p, c_i64, c_i64, c_int, c_d, c_p, c_i64, c_p, c_p,
                               c_int, c_p]),
+        "prt_trace_begin": (c_int, [c_p, c_int, c_int, c_p, c_i64, c_i64, c_int, c_d, c_p, c_i64, c_p, c_int, c_p]),
+        "prt_trace_end": (c_i64, [c_p, c_int, c_int, c_p]),
         "prt_trace_stats": (c_int, [c_p, c_p]),
         "prt_trace_telemetry": (c_int, [c_p, c_p]),
         "prt_generate_rays": (c_int, [c_int, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p]),
@@ -93,7 +128,7 @@ EXPORTED_SYMBOLS = (
     "prt_version", "prt_last_error", "prt_device_count", "prt_scene_create", "prt_scene_destroy", "prt_scene_update",
     "prt_scene_component_rows", "prt_scene_info", "prt_intersect", "prt_propagate", "prt_world_normals",
     "prt_material_trace", "prt_interact_workspace_bytes", "prt_interact",
-    "prt_trace_workspace_bytes", "prt_trace", "prt_trace_stats", "prt_trace_telemetry", "prt_generate_rays",
+    "prt_trace_workspace_bytes", "prt_trace", "prt_trace_begin", "prt_trace_end", "prt_trace_stats", "prt_trace_telemetry", "prt_generate_rays",
     "prt_camera_rays", "prt_render_hits", "prt_gooch_shade", "prt_gooch_mix", "prt_render",
     "prt_edge_workspace_bytes", "prt_edge_canvas", "prt_reflect", "prt_refract", "prt_binomial_root",
     "prt_smallest_positive_root", "prt_dot", "prt_array_csg", "prt_primitive_intersect",
@@ -168,18 +203,23 @@ def _stream_ptr(torch, device):
 class DeviceScene:
     """Owns a ``prt_scene*`` built from a SceneSnapshot."""
 
-    def __init__(self, snapshot):
+    def __init__(self, snapshot, options=None, trace_flags=None):
+        """options: dict of prt_scene_options fields (see OPTION_NAMES) on top of DEFAULT_OPTIONS;
+        trace_flags: PRT_TRACE_* bits or'ed into every trace of this scene (default DEFAULT_TRACE_FLAGS)."""
         lib = library()
         self.snapshot = snapshot
         self._handle = ctypes.c_void_p()
+        self._pending = [None] * TRACE_TICKETS
+        self.trace_flags = DEFAULT_TRACE_FLAGS if trace_flags is None else int(trace_flags)
         prims = np.ascontiguousarray(snapshot.prims)
         nodes = np.ascontiguousarray(snapshot.nodes)
         roots = np.ascontiguousarray(snapshot.roots)
         mats = np.ascontiguousarray(snapshot.materials)
+        opts = options_record(options)
         _check(
             lib.prt_scene_create(
                 prims.ctypes.data, len(prims), nodes.ctypes.data, len(nodes), roots.ctypes.data,
-                len(roots), mats.ctypes.data, len(mats), ctypes.byref(self._handle),
+                len(roots), mats.ctypes.data, len(mats), opts.ctypes.data, ctypes.byref(self._handle),
             )
         )
 
@@ -192,7 +232,7 @@ class DeviceScene:
         roots = np.ascontiguousarray(snapshot.roots)
         mats = np.ascontiguousarray(snapshot.materials)
         rc = library().prt_scene_update(self.handle, prims.ctypes.data, len(prims), nodes.ctypes.data, len(nodes),
-                                        roots.ctypes.data, len(roots), mats.ctypes.data, len(mats))
+                                        roots.ctypes.data, len(roots), mats.ctypes.data, len(mats), None)
         if rc == 1:
             return False
         _check(rc)
@@ -200,8 +240,8 @@ class DeviceScene:
         return True
 
     @classmethod
-    def from_components(cls, components):
-        return cls(_scene.SceneSnapshot(components))
+    def from_components(cls, components, options=None):
+        return cls(_scene.SceneSnapshot(components), options=options)
 
     @property
     def handle(self):
@@ -222,6 +262,7 @@ class DeviceScene:
 
     def close(self):
         self._view_of = self._view = None
+        self._pending = [None] * TRACE_TICKETS
         if self._handle:
             library().prt_scene_destroy(self._handle)
             self._handle = ctypes.c_void_p()
@@ -261,7 +302,7 @@ class DeviceScene:
             rows = out if out is not None else torch.empty((RECORD_COLS, cap), dtype=torch.float64, device=dev)
             total = lib.prt_trace(
                 self.handle, dev.index or 0, rays.data_ptr(), n, rays.stride(0), limit,
-                float(ray_offset), rows.data_ptr(), cap, counts, work.data_ptr(), int(flags),
+                float(ray_offset), rows.data_ptr(), cap, counts, work.data_ptr(), int(flags) | self.trace_flags,
                 _stream_ptr(torch, dev),
             )
             if total == ERR_ROWS_CAP and cap < n * limit and out is None:
@@ -280,6 +321,43 @@ class DeviceScene:
         if getattr(self, "_view_of", None) is not out or self._view_total != total:
             self._view_of, self._view_total, self._view = out, total, out[:, :total]
         return self._view, per_generation
+
+    # --- the hot loop in two halves: enqueue now, collect the counts later -----------------------------
+    def trace_begin(self, ticket, rays, generation_limit, out, ray_offset=DEFAULT_RAY_OFFSET, flags=0):
+        """Enqueue a trace on ticket 0 or 1 and return at once (``prt_trace_begin``).  `out`: the (15, cap)
+        CUDA float64 record block of this ticket -- tickets in flight together record into different
+        blocks (and get their own workspace here).  Collect with ``trace_end(ticket)``."""
+        torch = _torch()
+        assert rays.is_cuda and rays.dtype == torch.float64 and rays.dim() == 2
+        assert rays.shape[0] == RAY_ROWS and rays.stride(1) == 1
+        assert out.is_cuda and out.dtype == torch.float64 and out.dim() == 2 and out.device == rays.device
+        assert out.shape[0] == RECORD_COLS and out.is_contiguous()
+        n, dev, limit = rays.shape[1], rays.device, int(generation_limit)
+        works = getattr(self, "_ticket_work", None)
+        if works is None:
+            works = self._ticket_work = [None] * TRACE_TICKETS
+        work = works[ticket]
+        need = int(library().prt_trace_workspace_bytes(n))
+        if work is None or work.device != dev or work.numel() < need:
+            work = works[ticket] = torch.empty(need, dtype=torch.uint8, device=dev)
+        _check(library().prt_trace_begin(self.handle, dev.index or 0, int(ticket), rays.data_ptr(), n, rays.stride(0),
+                                         limit, float(ray_offset), out.data_ptr(), out.shape[1], work.data_ptr(),
+                                         int(flags) | self.trace_flags, _stream_ptr(torch, dev)))
+        counts = self._pending[ticket]
+        if counts is None or len(counts[0]) != limit:
+            counts = ((ctypes.c_int64 * max(limit, 1))(), None, None)
+        self._pending[ticket] = (counts[0], rays, out)  # (keeps rays and the block alive while in flight)
+
+    def trace_end(self, ticket):
+        """Wait for the counts of the trace begun on `ticket` (``prt_trace_end``): (rows view, counts)."""
+        counts, rays, out = self._pending[ticket]
+        assert out is not None, "no trace in flight on this ticket"
+        self._pending[ticket] = (counts, None, None)
+        total = _check(library().prt_trace_end(self.handle, out.device.index or 0, int(ticket), counts))
+        per_generation = counts[:]
+        while per_generation and per_generation[-1] == 0:
+            per_generation.pop()
+        return out[:, :total], per_generation
 
     def _rows_cap(self, torch, n, limit, dev):
         """Columns of the record block.  n * limit always suffices (one row per ray and generation)
@@ -316,10 +394,11 @@ class DeviceScene:
 
     def telemetry(self):
         """Counters since the scene was created (``prt_trace_telemetry``)."""
-        out = (ctypes.c_int64 * 4)()
+        out = (ctypes.c_int64 * 8)()
         _check(library().prt_trace_telemetry(self.handle, out))
-        return {"lookback_fallbacks": int(out[0]), "speculation_misses": int(out[1]),
-                "dense_launches": int(out[2]), "full_rows_fallbacks": int(out[3])}
+        keys = ("lookback_fallbacks", "speculation_misses", "dense_launches", "full_rows_fallbacks",
+                "counted_traces", "rays_not_well_formed", "implied_box_nodes", "exact_box_tests")
+        return dict(zip(keys, (int(v) for v in out)))
 
     # --- per-state entry points -----------------------------------------------------------------
     def propagate(self, rays):

@@ -17,17 +17,19 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-def check(parts, rays, limit, expect_culls=True):
+def check(parts, rays, limit, expect_culls=True, options=None):
+    from pyrayt_amd import engine
     from pyrayt_amd.engine import DeviceScene
     from pyrayt_amd.scene import SceneSnapshot
 
     snap = SceneSnapshot(parts)
     flat = helpers.flat_scene(snap)
-    ds = DeviceScene(snap)
+    ds = DeviceScene(snap, options=options)
     info = ds.info()
-    if expect_culls and "PRT_NO_CULL" not in os.environ:  # (tools/run_matrix.sh runs the suite with the steps compiled out)
-        # one cull step per component, plus the steps over runs of components from eight components on
-        grouped = len(parts) >= 8 and "PRT_NO_GROUPS" not in os.environ
+    in_force = dict(engine.DEFAULT_OPTIONS, **(options or {}))  # (tools/run_matrix.sh runs the suite with the steps compiled out)
+    if expect_culls and not in_force.get("no_cull"):
+        # one cull step per component, plus the steps over groups of components from eight components on
+        grouped = len(parts) >= 8 and not in_force.get("no_groups")
         assert info["cull_steps"] >= len(parts) and (info["cull_steps"] > len(parts)) == grouped, info
     elif not expect_culls:
         assert info["cull_steps"] == 0, info
@@ -66,11 +68,10 @@ def test_lens_train_both_directions(api):
 
 
 @pytest.mark.parametrize("groups", [True, False])
-def test_long_lens_train_with_run_cull_steps(api, groups, monkeypatch):
-    """33 components: the hierarchy of cull steps over runs of consecutive components (and the flat
-    form, PRT_NO_GROUPS) against the C oracle, rays entering from both ends and from the side."""
-    if not groups:
-        monkeypatch.setenv("PRT_NO_GROUPS", "1")
+def test_long_lens_train_with_run_cull_steps(api, groups):
+    """33 components: the hierarchy of cull steps over groups of components (and the flat form,
+    options.no_groups) against the C oracle, rays entering from both ends and from the side."""
+    options = None if groups else {"no_groups": 1}
     c = api.components
     parts = [c.biconvex_lens(4, 4, 0.25, aperture=1).move_x(1.0 * k) for k in range(32)]
     parts.append(c.baffle((2, 2)).move_x(33.0))
@@ -79,7 +80,7 @@ def test_long_lens_train_with_run_cull_steps(api, groups, monkeypatch):
                       scenes.random_rays(4288, 43, box=20.0, degenerate=True)))
     rays[4, 5000:6500] *= -1.0  # part of the mid-train cone runs backwards
     rays[12] = np.arange(rays.shape[1])
-    counts = check(parts, rays, 70)
+    counts = check(parts, rays, 70, options=options)
     assert len(counts) > 60
 
 

@@ -21,7 +21,7 @@ def _seeds():
     import os
 
     first = int(os.environ.get("PRT_FUZZ_FIRST", "0"))
-    return range(first, first + int(os.environ.get("PRT_FUZZ_SEEDS", "24")))
+    return range(first, first + int(os.environ.get("PRT_FUZZ_SEEDS", "200")))
 
 
 def build_random_scene(seed):

@@ -6,12 +6,15 @@ plus size-independent properties at the north-star size.
 Bar (BASELINE.json north_star): intersected-surface index bit-exact; hit point / direction /
 refractive index within 1e-6 abs in float64.  helpers.ATOL = 1e-6.
 """
+import ctypes
+
 import numpy as np
 import pytest
 
 import helpers
 import scenes
 from oracle import prt_oracle as orc
+from pyrayt_amd import engine
 
 pytestmark = pytest.mark.gpu
 
@@ -49,10 +52,10 @@ class FixtureSnapshot:
         self.roots = scene["roots"].astype(np.int32)
 
 
-def device_scene(scene_dict):
+def device_scene(scene_dict, options=None):
     from pyrayt_amd.engine import DeviceScene
 
-    return DeviceScene(FixtureSnapshot(scene_dict))
+    return DeviceScene(FixtureSnapshot(scene_dict), options=options)
 
 
 def test_library_loads_on_gpu():
@@ -78,17 +81,17 @@ def test_trace_matches_reference(name, flags):
 
 
 @pytest.mark.parametrize("name", SCENE_FIXTURES)
-@pytest.mark.parametrize("knob", ["PRT_NO_CHAIN", "PRT_NO_CULL", "PRT_CULL_MIN"])
-def test_trace_matches_reference_on_every_program_form(name, knob, monkeypatch):
-    """The same goldens with the scene compiled to the other program forms: the step interpreter
-    instead of chain steps, no component cull steps, cull steps from two components on."""
-    monkeypatch.setenv(knob, "2" if knob == "PRT_CULL_MIN" else "1")
+@pytest.mark.parametrize("knob", ["no_chain", "no_cull", "cull_min", "no_implied", "list_order_groups"])
+def test_trace_matches_reference_on_every_program_form(name, knob):
+    """The same goldens with the scene compiled to the other program forms (prt_scene_options): the step
+    interpreter instead of chain steps, no component cull steps, cull steps from two components on, every
+    cull box tested exactly, the cull hierarchy in list order."""
     fx = helpers.load(f"scene_{name}.npz")
-    ds = device_scene(helpers.scene_of(fx))
+    ds = device_scene(helpers.scene_of(fx), options={knob: 2 if knob == "cull_min" else 1})
     info = ds.info()
-    if knob == "PRT_NO_CHAIN":
+    if knob == "no_chain":
         assert info["chain_steps"] == 0
-    if knob == "PRT_NO_CULL":
+    if knob == "no_cull":
         assert info["cull_steps"] == 0
     rows, counts = ds.trace(dev(fx["rays0"]), int(fx["generation_limit"]))
     helpers.assert_frames_match(rows.cpu().numpy().T, fx["frame"], what=f"{name} {knob}")
@@ -99,13 +102,14 @@ def test_trace_matches_reference_on_every_program_form(name, knob, monkeypatch):
 
 @pytest.mark.parametrize("name", SCENE_FIXTURES)
 @pytest.mark.parametrize("variant", ["lanes4", "lanes8,lds", "lanes16", "lds"])
-def test_surface_parallel_variants_match_reference(name, variant, monkeypatch):
+def test_surface_parallel_variants_match_reference(name, variant):
     """The k-lanes-per-ray nearest-hit kernels (K lanes of a wave share a ray, each takes components
     j, j+K, ..., shuffle min-reduce over (t, component order)) and the LDS-staged program fetch give
     the reference's surfaces and frames exactly like the lane-per-ray kernel."""
-    monkeypatch.setenv("PRT_HIT_VARIANT", variant)
+    lanes = [int(part[5:]) for part in variant.split(",") if part.startswith("lanes")]
     fx = helpers.load(f"scene_{name}.npz")
-    ds = device_scene(helpers.scene_of(fx))
+    ds = device_scene(helpers.scene_of(fx), options={"hit_lanes": lanes[0] if lanes else 0,
+                                                     "hit_staged": int("lds" in variant)})
     t, surf = ds.propagate(dev(fx["rays0"]))
     assert np.array_equal(surf.cpu().numpy(), fx["surf_0"]), f"{name} {variant}: surfaces"
     assert np.allclose(t.cpu().numpy(), fx["t_0"], rtol=0, atol=helpers.ATOL), f"{name} {variant}: t"
@@ -360,7 +364,7 @@ def test_config2_one_million_rays():
     ds.close()
 
 
-def test_lookback_stall_falls_back_to_three_kernel_path(monkeypatch):
+def test_lookback_stall_falls_back_to_three_kernel_path():
     """If the decoupled look-back ever gave up (it relies on in-order workgroup dispatch, which
     is observed but not promised), prt_trace must transparently redo the loop on the path with
     no inter-workgroup dependency and return the same frame."""
@@ -371,8 +375,7 @@ def test_lookback_stall_falls_back_to_three_kernel_path(monkeypatch):
     ds = DeviceScene(SceneSnapshot(parts))
     want, want_counts = ds.trace(dev(rays), 10)
     assert ds.trace_stats()["kernel_launches"] == 4  # one fused launch per generation (+1 empty)
-    monkeypatch.setenv("PRT_TEST_STALL", "1")
-    got, counts = ds.trace(dev(rays), 10)
+    got, counts = ds.trace(dev(rays), 10, flags=engine.TRACE_TEST_STALL)
     assert ds.trace_stats()["kernel_launches"] == 12  # 3 generations x 4 kernels
     assert counts == want_counts and torch.equal(got, want)
     ds.close()
@@ -686,7 +689,7 @@ def test_ray_sets_that_need_all_state_rows(kind):
     ds.close()
 
 
-def test_compact_and_full_state_rows_give_the_same_frame(monkeypatch):
+def test_compact_and_full_state_rows_give_the_same_frame():
     from pyrayt_amd.engine import DeviceScene
 
     for name in ("scene_config2.npz", "scene_config3.npz", "scene_config5.npz", "scene_mirrors_and_stops.npz"):
@@ -694,9 +697,7 @@ def test_compact_and_full_state_rows_give_the_same_frame(monkeypatch):
         rays, limit = dev(fx["rays0"]), int(fx["generation_limit"])
         ds = device_scene(helpers.scene_of(fx))
         compact, counts = ds.trace(rays, limit)
-        monkeypatch.setenv("PRT_FULL_ROWS", "1")
-        full, full_counts = ds.trace(rays, limit)
-        monkeypatch.delenv("PRT_FULL_ROWS")
+        full, full_counts = ds.trace(rays, limit, flags=engine.TRACE_FULL_ROWS)
         assert counts == full_counts and np.array_equal(compact.cpu().numpy(), full.cpu().numpy(), equal_nan=True)
         helpers.assert_frames_match(compact.cpu().numpy().T, fx["frame"], what=name)
         ds.close()
@@ -706,7 +707,7 @@ def test_compact_and_full_state_rows_give_the_same_frame(monkeypatch):
 # dense-mode hints: a repeated trace launches the generations that were dense last time without the
 # look-back; a hint that does not hold must cost a repeat, never a wrong frame
 # ---------------------------------------------------------------------------------------------
-def test_dense_mode_hints_repeat_and_miss(monkeypatch):
+def test_dense_mode_hints_repeat_and_miss():
     from pyrayt_amd.engine import DeviceScene
     from pyrayt_amd.g3d.objects import CountedObject
     from pyrayt_amd.scene import SceneSnapshot
@@ -740,9 +741,8 @@ def test_dense_mode_hints_repeat_and_miss(monkeypatch):
         assert counts3 == want2_counts and np.array_equal(got3.cpu().numpy(), got2.cpu().numpy())
     tele = ds.telemetry()                                 # ... then they are back, renewed from the repeats
     assert tele["speculation_misses"] == 1 and tele["dense_launches"] > before
-    monkeypatch.setenv("PRT_NO_HINTS", "1")
     before = ds.telemetry()["dense_launches"]
-    got4, _ = ds.trace(dev(other), 10)
+    got4, _ = ds.trace(dev(other), 10, flags=engine.TRACE_NO_HINTS)
     assert ds.telemetry()["dense_launches"] == before and np.array_equal(got4.cpu().numpy(), got2.cpu().numpy())
     ds.close()
 
@@ -811,3 +811,127 @@ def test_dense_mode_hints_across_limits_flags_and_sizes():
     rows2, _ = ds.trace(half, 10)
     assert np.array_equal(rows.cpu().numpy(), rows2.cpu().numpy())
     ds.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# prt_trace_begin / prt_trace_end: traces in flight together give the frames prt_trace gives
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["config2", "config3", "config5", "mirrors_and_stops", "adv_lens"])
+def test_traces_in_flight_equal_synchronous_traces(name):
+    fx = helpers.load(f"scene_{name}.npz")
+    limit = int(fx["generation_limit"])
+    ds = device_scene(helpers.scene_of(fx))
+    rays = dev(fx["rays0"])
+    n = rays.shape[1]
+    want, want_counts = ds.trace(rays, limit)
+    want = want.cpu().numpy().copy()
+    helpers.assert_frames_match(want.T, fx["frame"], what=name)
+    blocks = [torch.full((15, n * limit), float("nan"), dtype=torch.float64, device="cuda:0") for _ in range(2)]
+    steps = 7
+    ds.trace_begin(0, rays, limit, blocks[0])
+    for k in range(steps):                       # first trace unhinted, then hinted, one always in flight
+        if k + 1 < steps:
+            ds.trace_begin((k + 1) & 1, rays, limit, blocks[(k + 1) & 1])
+        rows, counts = ds.trace_end(k & 1)
+        assert counts == want_counts, (k, counts)
+        torch.cuda.synchronize()
+        assert np.array_equal(rows.cpu().numpy(), want, equal_nan=True), k
+        st = ds.trace_stats()
+        assert st["variant"] == 1 and st["rows"] == want.shape[1] and st["kernel_ms"] > 0
+        blocks[k & 1].fill_(float("nan"))
+    ds.close()
+
+
+def test_tickets_reject_misuse_and_every_flag_goes_through_them():
+    from pyrayt_amd import engine as eng
+
+    fx = helpers.load("scene_config3.npz")
+    limit = int(fx["generation_limit"])
+    ds = device_scene(helpers.scene_of(fx))
+    rays = dev(fx["rays0"])
+    n = rays.shape[1]
+    a, b = (torch.empty((15, n * limit), dtype=torch.float64, device="cuda:0") for _ in range(2))
+    ds.trace_begin(0, rays, limit, a)
+    with pytest.raises(ValueError, match="in flight"):
+        ds.trace_begin(0, rays, limit, b)                      # the ticket is taken
+    with pytest.raises(ValueError, match="own workspace and record block"):
+        ds.trace_begin(1, rays, limit, a)                      # same record block as the trace in flight
+    rows, counts = ds.trace_end(0)
+    helpers.assert_frames_match(rows.cpu().numpy().T, fx["frame"], what="ticket 0")
+    with pytest.raises(ValueError, match="no trace in flight"):
+        eng._check(eng.library().prt_trace_end(ds.handle, 0, 0, (ctypes.c_int64 * limit)()))
+    # keep-absorbed, the three-kernel path, no hints, all state rows, kernel publish, the stall fallback, sync
+    for flags in (1, 2, 3, eng.TRACE_NO_HINTS, eng.TRACE_FULL_ROWS, eng.TRACE_PUBLISH_KERNEL, eng.TRACE_TEST_STALL,
+                  eng.TRACE_SYNC, eng.TRACE_NO_HINTS | eng.TRACE_PUBLISH_KERNEL):
+        for _ in range(2):
+            ds.trace_begin(1, rays, limit, b, flags=flags)
+            ds.trace_begin(0, rays, limit, a, flags=flags)
+            for ticket, block in ((1, b), (0, a)):
+                rows, counts = ds.trace_end(ticket)
+                helpers.assert_frames_match(rows.cpu().numpy().T, fx["frame"], what=f"flags {flags} ticket {ticket}")
+    assert ds.telemetry()["lookback_fallbacks"] == 4
+    # a record block one column short is reported by prt_trace_end
+    short = torch.empty((15, fx["frame"].shape[0] - 1), dtype=torch.float64, device="cuda:0")
+    ds.trace_begin(0, rays, limit, short)
+    with pytest.raises(RuntimeError, match="rows_cap"):
+        ds.trace_end(0)
+    ds.close()
+
+
+def test_a_missed_hint_in_flight_repeats_only_that_trace():
+    from pyrayt_amd.engine import DeviceScene
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    CountedObject.reset_ids()
+    n, limit = 40_000, 10
+    parts, rays = scenes.config2(scenes.product_api(), n)
+    snap = SceneSnapshot(parts)
+    flat = helpers.flat_scene(snap)
+    other = rays.copy()
+    other[5, ::3] = 5.0
+    other[4:7] /= np.linalg.norm(other[4:7], axis=0)
+    want_a, counts_a = orc.trace(flat, rays, limit)
+    want_b, counts_b = orc.trace(flat, other, limit)
+    ds = DeviceScene(snap)
+    rays_a, rays_b = dev(rays), dev(other)
+    blocks = [torch.empty((15, n * limit), dtype=torch.float64, device="cuda:0") for _ in range(2)]
+    for _ in range(2):
+        ds.trace(rays_a, limit)                                 # the hints now describe ray set A
+    ds.trace_begin(0, rays_b, limit, blocks[0])                 # launched on A's hints: misses
+    ds.trace_begin(1, rays_a, limit, blocks[1])                 # launched on A's hints: holds
+    rows_b, got_b = ds.trace_end(0)
+    rows_a, got_a = ds.trace_end(1)
+    assert got_b == counts_b and got_a == counts_a
+    helpers.assert_frames_match(rows_b.cpu().numpy().T, want_b, what="missed hint in flight")
+    helpers.assert_frames_match(rows_a.cpu().numpy().T, want_a, what="the trace queued behind it")
+    assert ds.telemetry()["speculation_misses"] == 1
+    ds.close()
+
+
+def test_a_missed_hint_with_an_exact_fit_record_block_is_repeated_not_reported():
+    """A generation launched on a dense-mode hint measures the record block against the ASSUMED offsets;
+    when the hint does not hold those are too large, and an exact-fit block must not turn the miss into
+    a 'rows_cap too small' (ADVICE round 2): the trace is repeated without hints and fits."""
+    from pyrayt_amd.engine import DeviceScene
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    CountedObject.reset_ids()
+    n, limit = 30_000, 10
+    parts, rays = scenes.config2(scenes.product_api(), n)
+    snap = SceneSnapshot(parts)
+    flat = helpers.flat_scene(snap)
+    for stride, first in ((3, 0), (7, 5), (n, n - 1)):           # many misses, few, a single ray of the last tile
+        other = rays.copy()
+        other[4:7, first::stride] = np.array([[0.0], [1.0], [0.0]])
+        want, want_counts = orc.trace(flat, other, limit)
+        assert sum(want_counts) < 3 * n - 2
+        ds = DeviceScene(snap)
+        for _ in range(2):
+            ds.trace(dev(rays), limit)                          # hints: every generation dense
+        block = torch.empty((15, sum(want_counts)), dtype=torch.float64, device="cuda:0")  # fits `other` exactly
+        rows, counts = ds.trace(dev(other), limit, out=block)
+        assert counts == want_counts and ds.telemetry()["speculation_misses"] == 1
+        helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"exact fit after a miss, stride {stride}")
+        ds.close()

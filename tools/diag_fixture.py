@@ -13,11 +13,8 @@ fx = helpers.load(sys.argv[1])
 want = fx["frame"]
 rays = fx["rays0"]
 limit = int(fx["generation_limit"])
-for env in ({}, {"PRT_NO_CULL": "1"}, {"PRT_NO_CHAIN": "1"}, {"PRT_NO_CULL": "1", "PRT_NO_CHAIN": "1"}):
-    for k in ("PRT_NO_CULL", "PRT_NO_CHAIN"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
-    ds = DeviceScene(FixtureSnapshot(helpers.scene_of(fx)))
+for env in ({}, {"no_cull": 1}, {"no_chain": 1}, {"no_cull": 1, "no_chain": 1}):
+    ds = DeviceScene(FixtureSnapshot(helpers.scene_of(fx)), options=env)
     rows, counts = ds.trace(torch.from_numpy(rays).cuda(), limit)
     got = rows.cpu().numpy().T
     key = lambda f: {(int(r[0]), int(r[4])): r for r in f}

@@ -18,11 +18,8 @@ flat = helpers.flat_scene(snap)
 want_t, want_surf = c_oracle.propagate(flat, rays)
 np_t, np_surf = prt_oracle.propagate(flat, rays)
 print("numpy oracle == C oracle:", np.array_equal(np_surf, want_surf))
-for env in ({}, {"PRT_NO_CULL": "1"}, {"PRT_NO_IMPLIED": "1"}, {"PRT_NO_CULL": "1", "PRT_NO_CHAIN": "1", "PRT_NO_IMPLIED": "1"}):
-    for k in ("PRT_NO_CULL", "PRT_NO_CHAIN", "PRT_NO_IMPLIED"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
-    ds = DeviceScene(snap)
+for env in ({}, {"no_cull": 1}, {"no_implied": 1}, {"no_cull": 1, "no_chain": 1, "no_implied": 1}):
+    ds = DeviceScene(snap, options=env)
     t, surf = ds.propagate(torch.from_numpy(rays).cuda())
     surf, t = surf.cpu().numpy(), t.cpu().numpy()
     bad = np.nonzero(surf != want_surf)[0]
@@ -37,8 +34,6 @@ for i in np.nonzero(surf != want_surf)[0][:3]:
 bad = np.nonzero(surf != want_surf)[0]
 if len(bad):
     i = int(bad[0])
-    for k in ("PRT_NO_CULL", "PRT_NO_CHAIN", "PRT_NO_IMPLIED"):
-        os.environ.pop(k, None)
     ds = DeviceScene(snap)
     one = np.ascontiguousarray(rays[:, i:i + 1])
     for root in range(len(flat["roots"])):

@@ -15,11 +15,15 @@ for name, n in jobs:
     CountedObject.reset_ids()
     comps, rays = scenes.SCENES[name](scenes.product_api(), n)
     dev = torch.from_numpy(np.ascontiguousarray(rays)).cuda()
-    ds = engine.DeviceScene.from_components(comps)
     base = None
+    scene_of = {}
+    for v in variants:  # one compiled scene per kernel variant (prt_scene_options.hit_lanes / hit_staged)
+        lanes = [int(part[5:]) for part in v.split(",") if part.startswith("lanes")]
+        scene_of[v] = engine.DeviceScene.from_components(comps, options={"hit_lanes": lanes[0] if lanes else 0,
+                                                                         "hit_staged": int("lds" in v)})
     for rep in range(2):
         for v in variants:
-            os.environ["PRT_HIT_VARIANT"] = v
+            ds = scene_of[v]
             for _ in range(3):
                 t, surf = ds.propagate(dev)
             torch.cuda.synchronize()
@@ -34,4 +38,5 @@ for name, n in jobs:
                 base = surf.clone()
             same = bool(torch.equal(surf, base))
             print(f"{name:8s} {n:8d} rays  variant {v or 'lane-per-ray (scalar steps)':28s} {us:9.1f} us per propagate  ids equal: {same}", flush=True)
-    ds.close()
+    for ds in scene_of.values():
+        ds.close()
