@@ -101,8 +101,19 @@ def spawn_ranks(world, argv, worker=None, poll_s=0.05):
     ranks are fresh interpreters.  Rank 0 inherits this process's stdout (its one JSON line is the
     launcher's only stdout); the other ranks' stdout goes to stderr.  Returns the exit code: 0 when
     every rank exited 0, otherwise the first non-zero code seen (the remaining ranks are stopped by
-    PID).  `worker` (tests): the command to run instead of [python, bench.py]."""
+    PID).  `worker` (tests): the command to run instead of [python, bench.py].
+    Libraries write to stdout too (gloo announces its connections there): of rank 0's stdout only the
+    lines that are a JSON object are passed on, the rest goes to stderr with everything else."""
     import subprocess
+    import threading
+
+    def forward(pipe):
+        for raw in iter(pipe.readline, b""):
+            text = raw.decode("utf-8", "replace")
+            target = sys.stdout if text.lstrip().startswith("{") else sys.stderr
+            target.write(text)
+            target.flush()
+        pipe.close()
 
     port = _free_port()
     cmd = list(worker) if worker else [sys.executable, os.path.abspath(__file__)]
@@ -112,7 +123,9 @@ def spawn_ranks(world, argv, worker=None, poll_s=0.05):
         env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=None if rank == 0 else sys.stderr))
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if rank == 0 else sys.stderr))
+    reader = threading.Thread(target=forward, args=(procs[0].stdout,), daemon=True)
+    reader.start()
     code = 0
     pending = list(procs)
     while pending and code == 0:
@@ -134,6 +147,7 @@ def spawn_ranks(world, argv, worker=None, poll_s=0.05):
         except subprocess.TimeoutExpired:
             proc.kill()
             proc.wait()
+    reader.join(timeout=10)
     return code
 
 

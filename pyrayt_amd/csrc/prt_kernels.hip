@@ -775,7 +775,9 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
         r.dw = row_load(tile_rays + 7 * ld, lane_bytes);
         const double generation = row_load(tile_rays + 8 * ld, lane_bytes);
         PARK(0) = generation;
-        if (!(w_is_trivial(r.ow, r.dw) && generation == 0.0)) raise_verdict(&ctrl->error, PRT_ERR_FULL_ROWS);
+        // (raised with a plain exchange: waiting for it here costs the kernel its register allocation -- 100 B
+        // of scratch per lane; the tile publishes long after this point, behind the whole hit phase)
+        if (!(w_is_trivial(r.ow, r.dw) && generation == 0.0)) atomicExch(&ctrl->error, PRT_ERR_FULL_ROWS);
       }
     }
 #ifdef PRT_TIMING
@@ -946,7 +948,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   if (!interact_store_rows<COMPACT>(sh, r, carry, (unsigned)live_rank * 8u, (unsigned)carry_rank * 8u,
                                     next + uniform64(excl_carry), ld_next, rows + uniform64(row_base + excl_live),
                                     ld_rows, next_generation, relaunch, ray_offset))
-    raise_verdict(&ctrl->error, PRT_ERR_FULL_ROWS);
+    atomicExch(&ctrl->error, PRT_ERR_FULL_ROWS);
 #endif
   if (!sh.ok) raise_error(&ctrl->error, PRT_ERR_UNTRACABLE);
   STAMP(7);

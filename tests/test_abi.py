@@ -88,3 +88,21 @@ def test_no_cpu_fallback():
             if name.endswith((".py", ".hip", ".hpp", ".cpp", "Makefile")):
                 text = open(os.path.join(dirpath, name)).read()
                 assert not pattern.search(text), f"{name} references the oracle"
+
+
+def test_generation_kernel_keeps_its_register_allocation(lib_path):
+    """k_generation is tuned to 96 VGPRs without scratch (5 waves per SIMD).  A source change that looks
+    harmless can cost it that (a waited-for atomic in the store path once did: 100 B of scratch per
+    lane, 58 -> 73 us per launch), and nothing but the clock would notice: read it off the code object."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(mod.READELF):
+        pytest.skip("llvm-readelf not available")
+    kernels = {name: res for name, res in mod.kernel_resources(lib_path).items() if "k_generation" in name}
+    assert len(kernels) == 4, sorted(kernels)
+    for name, res in kernels.items():
+        assert res["private_segment_fixed_size"] == 0, (name, res)
+        assert res["vgpr_spill_count"] == 0 and res["vgpr_count"] <= 96, (name, res)

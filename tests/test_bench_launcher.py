@@ -21,6 +21,7 @@ STUB = textwrap.dedent("""
         sys.exit(7)
     if mode == "fail":
         time.sleep(60)   # "waiting in a barrier" for the rank that died
+    print(f"[Gloo] chatter from rank {rank}")   # libraries write to stdout too
     print(json.dumps({"rank": rank, "n_gpus": world, "argv": sys.argv[1:]}) if rank == 0 else f"noise from rank {rank}")
 """)
 
@@ -45,6 +46,7 @@ def test_launcher_passes_rank_zero_line_through(tmp_path, world):
     assert line == {"rank": 0, "n_gpus": world, "argv": ["ok", "--steps", "3"]}
     for rank in range(1, world):  # the other ranks' stdout ends up on stderr
         assert f"noise from rank {rank}" in done.stderr
+    assert "[Gloo] chatter from rank 0" in done.stderr
 
 
 def test_launcher_reports_a_failed_rank_and_stops_the_others(tmp_path):
