@@ -74,3 +74,86 @@ __device__ __forceinline__ void prt_div3(double n0, double n1, double n2, double
     q2 = n2 / d;
   }
 }
+
+// ---- experiment switches of the round-3 "VALU diet" (all on by default; -DPRT_OPT=<mask> builds A/B partners) ----
+//   1  square roots without the scaling wrapper when no lane of the wave needs it (prt_sqrt*)
+//   2  the reference's isclose / NaN selects only in waves that hold such a lane (prt_device.hpp)
+//   4  root / slab pairs on one refined reciprocal when v_div_scale gives both quotients the same denominator
+#ifndef PRT_OPT
+#define PRT_OPT 7
+#endif
+
+// ---- square root ---------------------------------------------------------------------------------
+// hipcc expands sqrt(double) into
+//     scale = x < 2^-767;  xs = ldexp(x, scale ? 256 : 0)
+//     y = v_rsq(xs);  g = xs * y;  h = y * 0.5;  r = fma(-h, g, 0.5);  g = fma(g, r, g);  d = fma(-g, g, xs)
+//     h = fma(h, r, h);  g = fma(d, h, g);  d = fma(-g, g, xs);  g = fma(d, h, g)
+//     res = ldexp(g, scale ? -128 : 0);  res = class(xs, +-0 | +inf) ? xs : res
+// -- twenty instructions of which ten are the iteration.  For 2^-767 <= x < +inf the first ldexp moves
+// nothing, the last one neither, and the class test fails: the ten instructions in the middle on x itself
+// ARE the result, bit for bit (prt_sqrt_core; checked against sqrt() on 2^32 operands per launch by
+// tools/ubench/sqrt_fast.hip).  A wave in which any lane holds another operand takes the ordinary sqrt.
+__device__ __forceinline__ double prt_sqrt_core(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  double d = __builtin_fma(-g, g, x);
+  h = __builtin_fma(h, r, h);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return g;
+}
+// sqrt(x)
+__device__ __forceinline__ double prt_sqrt(double x) {
+#if PRT_OPT & 1
+  // high word in [0x10000000, 0x7ff00000)  <=>  2^-767 <= x < +inf  (negative, zero, tiny, inf, NaN: the rest)
+  const unsigned u = (unsigned)__double2hiint(x) - 0x10000000u;
+  if (__ballot(u >= 0x6ff00000u) == 0ull) return prt_sqrt_core(x);
+#endif
+  return sqrt(x);
+}
+// sqrt(max(0, x)) for the lanes with x >= 0; a lane with x < 0 (or NaN) gets some finite value -- every
+// caller overrides what it derives from it (the `!(disc >= 0)` rule of the quadratics, the total-reflection
+// branch of refract).  max(0, x) is never -0 here: x is a difference of products, b*b - 4ac resp. 1 - ...
+__device__ __forceinline__ double prt_sqrt_clamped(double x) {
+#if PRT_OPT & 1
+  const unsigned hi = (unsigned)__double2hiint(x);
+  // lanes that need the general sequence: 0 <= x < 2^-767 (zero included), +inf, +NaN
+  const bool special = hi < 0x10000000u || (hi - 0x7ff00000u) < 0x00100000u;
+  if (__ballot(special) == 0ull) return prt_sqrt_core(fmax(x, 0x1p-767));
+#endif
+  return sqrt(0.0 > x ? 0.0 : x);
+}
+
+// ---- two quotients of one denominator ----------------------------------------------------------------
+// The compiler's n / d scales d against the numerator first (ds = v_div_scale(d, d, n)) and refines the
+// reciprocal of THAT.  When both numerators give the same ds -- bit for bit, which is what is compared --
+// the refined reciprocal is the same value in both divisions, so it is computed once; everything else is
+// the compiler's own sequence on the same operands (v_div_scale of the numerator, its VCC into v_div_fmas,
+// v_div_fixup): bit-identical quotients by construction, with no assumption about the operands.
+__device__ __forceinline__ void prt_div2_same_scale(double n0, double n1, double d, double& q0, double& q1) {
+#if PRT_OPT & 4
+  bool f0, f1, g0, g1;
+  const double ds0 = __builtin_amdgcn_div_scale(n0, d, false, &f0);   // (numerator, denominator, scale the numerator?, &vcc)
+  const double ds1 = __builtin_amdgcn_div_scale(n1, d, false, &f1);
+  if (__ballot(__double_as_longlong(ds0) != __double_as_longlong(ds1)) == 0ull) {
+    const double ns0 = __builtin_amdgcn_div_scale(n0, d, true, &g0);
+    const double ns1 = __builtin_amdgcn_div_scale(n1, d, true, &g1);
+    double r = __builtin_amdgcn_rcp(ds0);
+    double e = __builtin_fma(-ds0, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-ds0, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double m0 = ns0 * r, m1 = ns1 * r;
+    const double e0 = __builtin_fma(-ds0, m0, ns0), e1 = __builtin_fma(-ds0, m1, ns1);
+    q0 = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(e0, r, m0, g0), d, n0);
+    q1 = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(e1, r, m1, g1), d, n1);
+    return;
+  }
+#endif
+  q0 = n0 / d;
+  q1 = n1 / d;
+}
