@@ -136,21 +136,19 @@ __device__ __forceinline__ double col_dot(M m, int r, double x, double y, double
 }
 
 __device__ __forceinline__ double norm4(double x, double y, double z, double w) {
-  return sqrt(((x * x + y * y) + z * z) + w * w);
+  return prt_sqrt(((x * x + y * y) + z * z) + w * w);
 }
 __device__ __forceinline__ double norm3(double x, double y, double z) {
-  return sqrt((x * x + y * y) + z * z);
+  return prt_sqrt((x * x + y * y) + z * z);
 }
 
 // Quotients that share a denominator: one refined reciprocal for all of them (prt_math.hpp), the
 // same bits as separate `/`.  Used for the three-component normalisations; -DPRT_PLAIN_DIV3 builds
 // the A/B partner.
 __device__ __forceinline__ void div2(double n0, double n1, double d, double& q0, double& q1) {
-#ifndef PRT_SHARED_DIV2  // measured: for pairs the operand checks cost what the shared reciprocal saves
-  q0 = n0 / d; q1 = n1 / d;
-#else
-  prt_div2(n0, n1, d, q0, q1);
-#endif
+  // (operand-window checks cost a pair what the shared reciprocal saves -- prt_div2, round 2; comparing the
+  // two scaled denominators is one instruction and needs no window)
+  prt_div2_same_scale(n0, n1, d, q0, q1);
 }
 __device__ __forceinline__ void div3(double n0, double n1, double n2, double d, double& q0, double& q1,
                                      double& q2) {
@@ -162,10 +160,27 @@ __device__ __forceinline__ void div3(double n0, double n1, double n2, double d, 
 }
 
 // ---- quadratic with the reference's degenerate branches (operations.py:28-63) ----------------
+// (PRT_OPT & 2: the `isclose` branches of the reference are evaluated for every lane of every wave, yet
+// in an optical trace almost no wave holds a lane they apply to.  Where a branch only *replaces* values
+// -- `x + (flag ? 1 : 0)`, `if (flag) v = ...` -- a wave without such a lane runs a body without it:
+// x + 0.0 is x for every x the flag leaves alone (it is set for +-0), the replacement is not taken.)
+__device__ __forceinline__ bool no_lane(bool flag) {
+#if PRT_OPT & 2
+  return __ballot(flag) == 0ull;
+#else
+  (void)flag;
+  return false;
+#endif
+}
 __device__ __forceinline__ void binomial_root(double a, double b, double c, double& p0, double& p1) {
   const double disc = b * b - 4 * a * c;
   const bool lin = near0(a);
-  const double s = sqrt(dmax(0.0, disc));
+  const double s = prt_sqrt_clamped(disc);
+  if (no_lane(lin)) {  // the quadratic proper
+    div2(-b + s, -b - s, 2 * a, p0, p1);
+    if (!(disc >= 0)) { p0 = PRT_INF; p1 = PRT_INF; }
+    return;
+  }
   const double den = 2 * a + (lin ? 1.0 : 0.0);
   div2(-b + s, -b - s, den, p0, p1);
   if (!(disc >= 0)) { p0 = PRT_INF; p1 = PRT_INF; }
@@ -183,6 +198,10 @@ __device__ __forceinline__ void binomial_root(double a, double b, double c, doub
 __device__ __forceinline__ void z_slab(double oz, double dz, double lo, double hi, double& c0,
                                        double& c1) {
   const bool par = near0(dz);
+  if (no_lane(par)) {
+    div2(lo - oz, hi - oz, dz, c0, c1);
+    return;
+  }
   const double den = dz + (par ? 1.0 : 0.0);
   div2(lo - oz, hi - oz, den, c0, c1);
   if (par) {
@@ -202,15 +221,20 @@ __device__ __forceinline__ void overlap(double a0, double a1, double b0, double 
 }
 
 // one axis of the cube / plane-patch slab test (primitives.py:531-565 / :454-469)
+// (`inside` is only looked at for a lane whose direction has no component along the axis)
 __device__ __forceinline__ void axis_slab(double o, double d, double lo, double hi, bool inside,
                                           double& s_lo, double& s_hi) {
   const bool z = near0(d);
-  const double den = d + (z ? 1.0 : 0.0);
   double first, second;
-  div2(-(o - lo), -(o - hi), den, first, second);
-  if (z) {
-    first = inside ? -PRT_INF : PRT_INF;
-    second = PRT_INF;
+  if (no_lane(z)) {
+    div2(-(o - lo), -(o - hi), d, first, second);
+  } else {
+    const double den = d + (z ? 1.0 : 0.0);
+    div2(-(o - lo), -(o - hi), den, first, second);
+    if (z) {
+      first = inside ? -PRT_INF : PRT_INF;
+      second = PRT_INF;
+    }
   }
   s_lo = dmin(first, second);
   s_hi = dmax(first, second);
@@ -252,7 +276,7 @@ __device__ __forceinline__ void primitive_pair(int type, const double* __restric
       const double b = 2 * ((dx * ox + dy * oy) + dz * oz);
       const double c = ((ox * ox + oy * oy) + oz * oz) - q[0] * q[0];
       const double disc = b * b - 4 * a * c;
-      const double s = sqrt(dmax(0.0, disc));
+      const double s = prt_sqrt_clamped(disc);
       const double den = 2 * a;
       div2(-b + s, -b - s, den, h0, h1);
       if (!(disc >= 0)) { h0 = PRT_INF; h1 = PRT_INF; }
@@ -273,8 +297,13 @@ __device__ __forceinline__ void primitive_pair(int type, const double* __restric
       axis_slab(oy, dy, hl, -hl, fabs(oy) <= hl, ly, hy);
       const double enter = dmax(lx, ly), leave = dmin(hx, hy);
       const bool skew = near0(dz);
-      double t = -oz / (dz + (skew ? 1.0 : 0.0));
-      if (skew) t = PRT_INF;
+      double t;
+      if (no_lane(skew)) {
+        t = -oz / dz;
+      } else {
+        t = -oz / (dz + (skew ? 1.0 : 0.0));
+        if (skew) t = PRT_INF;
+      }
       if (!(t >= enter && t <= leave)) t = PRT_INF;
       h0 = t; h1 = t;
     } break;
@@ -288,14 +317,19 @@ __device__ __forceinline__ void primitive_pair(int type, const double* __restric
       const double c = (ox * ox + oy * oy) - f4 * oz;
       const double disc = b * b - 4 * a * c;
       const bool lin = near0(a);
-      const double s = sqrt(dmax(0.0, disc));
-      const double den = 2 * a + (lin ? 1.0 : 0.0);
+      const double s = prt_sqrt_clamped(disc);
       double p0, p1;
-      div2(-b + s, -b - s, den, p0, p1);
-      if (!(disc >= 0)) { p0 = PRT_INF; p1 = PRT_INF; }
-      if (lin) {
-        p0 = -c / (b + (near0(b) ? 1.0 : 0.0));
-        p1 = (dz >= 0) ? PRT_INF : -PRT_INF;
+      if (no_lane(lin)) {
+        div2(-b + s, -b - s, 2 * a, p0, p1);
+        if (!(disc >= 0)) { p0 = PRT_INF; p1 = PRT_INF; }
+      } else {
+        const double den = 2 * a + (lin ? 1.0 : 0.0);
+        div2(-b + s, -b - s, den, p0, p1);
+        if (!(disc >= 0)) { p0 = PRT_INF; p1 = PRT_INF; }
+        if (lin) {
+          p0 = -c / (b + (near0(b) ? 1.0 : 0.0));
+          p1 = (dz >= 0) ? PRT_INF : -PRT_INF;
+        }
       }
       double c0, c1;
       z_slab(oz, dz, 0.0, q[1], c0, c1);
@@ -317,8 +351,10 @@ __device__ __forceinline__ void surface_pair(int type, const double* __restrict_
   const double dz = row_dot(m, 2, r.dx, r.dy, r.dz, r.dw);
   double h0, h1;
   primitive_pair(type, q, ox, oy, oz, dx, dy, dz, h0, h1);
-  h0 = nan_to_inf(h0);
-  h1 = nan_to_inf(h1);
+  if (!no_lane(__builtin_isunordered(h0, h1))) {  // (0 / 0 of a zero direction: one compare for the pair)
+    h0 = nan_to_inf(h0);
+    h1 = nan_to_inf(h1);
+  }
   t0 = fmin(h0, h1);  // NaN-free here: v_min / v_max order the pair like np.sort (signed zeros compare equal)
   t1 = fmax(h0, h1);
 }
@@ -421,8 +457,8 @@ __device__ __forceinline__ double glass_index(PrimPtr p, double wavelength) {
   if (p->mat_kind == MAT_CONST) return p->coef[0];  // materials.py:112-118
   const auto k = p->coef;                             // materials.py:136-145
   const double w2 = wavelength * wavelength;
-  return sqrt(((1 + (k[0] * w2) / (w2 - k[3])) + (k[1] * w2) / (w2 - k[4])) +
-              (k[2] * w2) / (w2 - k[5]));
+  return prt_sqrt(((1 + (k[0] * w2) / (w2 - k[3])) + (k[1] * w2) / (w2 - k[4])) +
+                  (k[2] * w2) / (w2 - k[5]));
 }
 
 // operations.reflect (operations.py:104-107): v - (2 n) (v.n), in place
@@ -452,7 +488,7 @@ __device__ __forceinline__ void refract4(double vx, double vy, double vz, double
   const double r = n1 / n2;
   const double cos1 = leaving ? cos_p : cos_n;
   const double radicand = 1 - (r * r) * (1 - cos1 * cos1);
-  const double cos2 = sqrt(dmax(0.0, radicand));
+  const double cos2 = prt_sqrt_clamped(radicand);  // (only looked at when radicand > 0)
   double ux, uy, uz, uw;
   if (radicand > 0) {
     const double k = r * cos1 - cos2;
@@ -888,14 +924,17 @@ __device__ __forceinline__ bool may_reach(const double* __restrict__ box, const 
 // values at every level, so ties resolve as in csg_node.  When no lane of the wave holds a positive
 // survivor after the first node, the third leaf is not evaluated (an INTERSECT / DIFFERENCE result
 // lies inside its left operand: the same argument as the interpreter's right-leaf skip).
-template <int T0, int T1, int T2>
+template <int T0, int T1, int T2, bool FIXED = false>
 __device__ __forceinline__ void chain_candidate(const DevChain* __restrict__ ch, const Ray8& ray,
                                                 double& best_t, int& best_prim) {
   double lv[2], rv[2];
   surface_pair(T0, ch->leaf[0], ch->leaf[0] + 6, ray, lv[0], lv[1]);
   surface_pair(T1, ch->leaf[1], ch->leaf[1] + 6, ray, rv[0], rv[1]);
   bool keep_l[2], keep_r[2], c1[2][2];
-  csg_keep<2, 2>(ch->op1, lv, rv, ch->box1, ray, ch->implied1 != 0, keep_l, keep_r, c1);
+  // (FIXED: experiment -- both operations INTERSECT and both boxes implied, known at compile time)
+  const int op1 = FIXED ? (int)CSG_INTERSECT : ch->op1, op2 = FIXED ? (int)CSG_INTERSECT : ch->op2;
+  const bool implied1 = FIXED ? true : ch->implied1 != 0, implied2 = FIXED ? true : ch->implied2 != 0;
+  csg_keep<2, 2>(op1, lv, rv, ch->box1, ray, implied1, keep_l, keep_r, c1);
   const int id0 = ch->prim[0], id1 = ch->prim[1];
   double t;
   int prim;
@@ -915,11 +954,11 @@ __device__ __forceinline__ void chain_candidate(const DevChain* __restrict__ ch,
       behind += l4[k] <= 0 ? 1 : 0;
     }
     positive = positive || (behind & 1);
-    if (ch->op2 != CSG_UNION && __ballot(positive) == 0ull) return;
+    if (op2 != CSG_UNION && __ballot(positive) == 0ull) return;
     double r2[2];
     surface_pair(T2 < 0 ? 0 : T2, ch->leaf[2], ch->leaf[2] + 6, ray, r2[0], r2[1]);
     bool keep4[4], keep2[2], c2[4][2];
-    csg_keep<4, 2>(ch->op2, l4, r2, ch->box2, ray, ch->implied2 != 0, keep4, keep2, c2);
+    csg_keep<4, 2>(op2, l4, r2, ch->box2, ray, implied2, keep4, keep2, c2);
     const int id2 = ch->prim[2];
     const int lid[4] = {id0, id0, id1, id1}, rid[2] = {id2, id2};
     csg_root_pick<4, 2>(l4, lid, keep4, r2, rid, keep2, t, prim);
@@ -933,7 +972,16 @@ __device__ __forceinline__ void chain_candidate(const DevChain* __restrict__ ch,
 __device__ __forceinline__ void chain_step(const DevChain* __restrict__ ch, int shape, const Ray8& ray,
                                            double& best_t, int& best_prim) {
   switch (shape) {  // wave-uniform
+#ifdef PRT_FIXED_SSC  // experiment: the INTERSECT / INTERSECT / implied form of the lens chain as its own body
+    case CHAIN_SSC:
+      if (ch->op1 == CSG_INTERSECT && ch->op2 == CSG_INTERSECT && ch->implied1 && ch->implied2)
+        chain_candidate<PRIM_SPHERE, PRIM_SPHERE, PRIM_CYLINDER, true>(ch, ray, best_t, best_prim);
+      else
+        chain_candidate<PRIM_SPHERE, PRIM_SPHERE, PRIM_CYLINDER>(ch, ray, best_t, best_prim);
+      break;
+#else
     case CHAIN_SSC: chain_candidate<PRIM_SPHERE, PRIM_SPHERE, PRIM_CYLINDER>(ch, ray, best_t, best_prim); break;
+#endif
     case CHAIN_SSQ: chain_candidate<PRIM_SPHERE, PRIM_SPHERE, PRIM_CUBE>(ch, ray, best_t, best_prim); break;
     case CHAIN_CSS: chain_candidate<PRIM_CYLINDER, PRIM_SPHERE, PRIM_SPHERE>(ch, ray, best_t, best_prim); break;
     case CHAIN_QSS: chain_candidate<PRIM_CUBE, PRIM_SPHERE, PRIM_SPHERE>(ch, ray, best_t, best_prim); break;
@@ -1062,6 +1110,21 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
     ra[k] = Pair{PRT_INF, PRT_INF, -1};
     rb[k] = Pair{PRT_INF, PRT_INF, -1};
   }
+#ifdef PRT_SPECIAL_C2
+  // EXPERIMENT (timing of a fully specialised program, results valid for BASELINE config 2 only): the
+  // program [chain S,S,C with INTERSECT nodes and implied boxes][bare plane] as straight-line code
+  if (!RENDER && R == 1 && !CULL) {
+    const DevChain* ch = reinterpret_cast<const DevChain*>(code);
+    const DevInstr* leaf = code + CHAIN_SLOTS;
+    double p0, p1;
+    surface_pair(PRIM_PLANE, leaf->data, leaf->data + 6, ray[0], p0, p1);
+    chain_candidate<PRIM_SPHERE, PRIM_SPHERE, PRIM_CYLINDER, true>(ch, ray[0], best_t[0], best_prim[0]);
+    const bool pos0 = p0 > 0 && p0 < PRT_INF, pos1 = p1 > 0 && p1 < PRT_INF;
+    const double t = pos0 ? p0 : (pos1 ? p1 : PRT_INF);
+    if ((pos0 || pos1) && t < best_t[0]) { best_t[0] = t; best_prim[0] = leaf->a0; }
+    return;
+  }
+#endif
   for (int pc = 0; pc < n_instr; ++pc) {
     if (!RENDER && R == 1) {  // trace programs: a whole component may be one chain record
       const int kind = code[pc].kind, shape = code[pc].a0;

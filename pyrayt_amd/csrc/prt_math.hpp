@@ -75,12 +75,18 @@ __device__ __forceinline__ void prt_div3(double n0, double n1, double n2, double
   }
 }
 
-// ---- experiment switches of the round-3 "VALU diet" (all on by default; -DPRT_OPT=<mask> builds A/B partners) ----
+// ---- experiment switches of the round-3 "VALU diet" (-DPRT_OPT=<mask>; all OFF in the product) -----------
 //   1  square roots without the scaling wrapper when no lane of the wave needs it (prt_sqrt*)
 //   2  the reference's isclose / NaN selects only in waves that hold such a lane (prt_device.hpp)
 //   4  root / slab pairs on one refined reciprocal when v_div_scale gives both quotients the same denominator
+// Each is bit-identical to the plain form and each was measured on config 2 (profiles/r3/valu_diet.txt):
+// 1 + 2 take 5.4 % of the VALU instructions out of k_generation (1 217 -> 1 152 per wave) and put 24
+// wave-uniform branches per wave in (96 -> 119): the launch time does not move (174.4 vs 174.1 us per
+// trace) -- a uniform branch costs this kernel what about three VALU instructions cost it, so a shortcut
+// has to save well over that to pay, and none of these does.  4 costs the register allocation (48 B of
+// scratch per lane) and 3.5 %.
 #ifndef PRT_OPT
-#define PRT_OPT 7
+#define PRT_OPT 0
 #endif
 
 // ---- square root ---------------------------------------------------------------------------------
