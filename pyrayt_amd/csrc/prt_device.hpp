@@ -96,7 +96,48 @@ enum {
 
 struct Ray8 {
   double ox, oy, oz, ow, dx, dy, dz, dw;
+  // (set by nearest_hit(); a ray built from its eight numbers alone has gated == false: no shortcut)
+  bool gated;                 // the ray may take shortcuts if well_formed() says so
+  bool any_w;                 // its w components are not known to be 1 / 0 (well_formed() looks at them)
+  unsigned long long* paths;  // PRT_TRACE_COUNT_PATHS counters, or null
 };
+
+// ---- the one gate of every shortcut ----------------------------------------------------------------
+// The kernels replace four of the reference's predicates by cheaper ones: the CSG cull box implied by a
+// node's survivors (csg_keep), the component cull steps (may_reach), the right-leaf skip of the
+// interpreter and the third-leaf skip of the chain steps.  Each is argued geometrically -- "a finite
+// positive entry of a hit list is a point of the surface, hence of its box" -- and the argument holds
+// for a ray that is what a RaySet holds (pyrayt/_pyrayt.py:29-36, sources and materials keep it so):
+//   * homogeneous coordinates w = 1 (origin) and 0 (direction): the object-space ray is then the image
+//     M^-1 of the world ray (world_objects.py:367-369 multiplies the translation by w);
+//   * a direction of unit length, here |d|^2 in [0.81, 1.21]: upstream's `isclose(.., 0)` branches use
+//     absolute 1e-8 thresholds on object-space quantities and fire for any SHORT direction, parallel
+//     or not, and what they then report is not a point of the surface; the scene compiler allows a
+//     shortcut only where |d|^2 >= 0.81 keeps every leaf's |d_obj|^2 >= 1e-3 (short_direction_bound);
+//   * a finite origin.
+// Any other ray takes none of them: every component, every upstream cull box exactly, every leaf.
+// One predicate for all of them; DESIGN.md section 4 has the argument per shortcut.  (It is a pure function
+// of the ray and is written out at every site: holding its value across the hit phase instead costs the
+// generation kernel its register allocation -- the lane mask lives in SGPRs, of which the kernel has none
+// to spare -- while the compiler is free to share it between neighbouring sites as it is.)
+#define kWellFormedLen2Lo 0.81
+#define kWellFormedLen2Hi 1.21
+__device__ __forceinline__ bool well_formed(const Ray8& r) {
+  if (!r.gated) return false;
+  const double len2 = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;
+  bool ok = len2 >= kWellFormedLen2Lo && len2 <= kWellFormedLen2Hi;  // (NaN and infinite directions fail)
+  ok = ok && fabs(r.ox) < PRT_INF && fabs(r.oy) < PRT_INF && fabs(r.oz) < PRT_INF;
+  if (r.any_w) ok = ok && r.ow == 1.0 && r.dw == 0.0;
+  return ok;
+}
+// PRT_TRACE_COUNT_PATHS: one atomic per wave and site; `paths` is null (a compile-time constant in the
+// fused kernel, which carries none of this) unless the trace asked for the counts
+__device__ __forceinline__ void count_paths(unsigned long long* paths, int k, bool flag) {
+  if (paths == nullptr) return;
+  const unsigned long long m = __ballot(flag);
+  if (m != 0ull && (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1)
+    atomicAdd(&paths[k], (unsigned long long)__popcll(m));
+}
 
 // a sorted pair of hit parameters with the primitive that produced it
 struct Pair {
@@ -676,18 +717,11 @@ __device__ __forceinline__ void first_positive_else_first(const Operand& o, cons
 // no survivor gets the all-inf list either way.  Only rays whose survivors are (nearly)
 // coincident -- tangent rays, a Plane's double hit (t,t) -- take the exact six-division test.
 // UNION nodes always take it (their upstream box can be smaller than the solid).
-#ifdef PRT_COUNT_SLOW  // experiment build: how often the shortcuts fall through to their exact paths
-__device__ unsigned long long g_slow[4];  // [0] implied nodes with survivors, [1] ... that took the exact box test, [2] cull tests, [3] ... that skipped
-#define PRT_COUNT(k, flag) do { const unsigned long long m_ = __ballot(flag); if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(true)) - 1) && m_) atomicAdd(&g_slow[k], (unsigned long long)__popcll(m_)); } while (0)
-#else
-#define PRT_COUNT(k, flag) do {} while (0)
-#endif
 
 // keep flags of one node (the part of csg_node below that needs no list storage): c(i,j), the
 // parities, the keep rule per operation and the (lazily evaluated) cull box.  Neither list has to
 // be sorted or compacted for this: every quantity is a count of entries of the *other* list that
 // sort before an entry, and a dropped entry left in place as +inf sorts before nothing finite.
-#define kImpliedMinLen2 1e-2 /* see csg_keep and prt_scene.hpp box_contains_solid */
 template <int ML, int MR>
 __device__ __forceinline__ void csg_keep(int op, const double (&lv)[ML], const double (&rv)[MR],
                                          const double* __restrict__ aabb, const Ray8& ray,
@@ -738,17 +772,13 @@ __device__ __forceinline__ void csg_keep(int op, const double (&lv)[ML], const d
       hi = fmax(hi, keep_r[j] ? rv[j] : -PRT_INF);
     }
     const bool any = hi >= lo;  // false when nothing survived (lo = +inf, hi = -inf)
-    // (a short direction -- |d|^2 < 1e-2; the scene compiler implies the box only for nodes whose leaves
-    // keep unit directions at |d_obj|^2 >= 0.1 -- may send a leaf into one of upstream's degenerate
-    // branches without being parallel to anything, and what survives then need not lie in the solid:
-    // the exact test decides, like for a thin chord.  Found by the short-direction fuzz family.)
-    // (likewise a ray with homogeneous w components other than 1 / 0: its object-space image is
-    // M^-1 (o, w), not the image of the world ray the box was tested against)
-    const bool short_d = (ray.dx * ray.dx + ray.dy * ray.dy) + ray.dz * ray.dz < kImpliedMinLen2 ||
-                         ray.ow != 1.0 || ray.dw != 0.0;
-    const bool robust = any && !short_d && lo > -PRT_INF && (hi - lo) > 1e-6 * ((1.0 + fabs(lo)) + fabs(hi));
-    PRT_COUNT(0, any);
-    PRT_COUNT(1, any && !robust);
+    // (a ray that is not well formed -- a short direction may send a leaf into one of upstream's degenerate
+    // branches without being parallel to anything, and what survives then need not lie in the solid; with
+    // w other than 1 / 0 the object-space ray is not the image of the world ray the box was tested
+    // against -- gets the exact test, like a thin chord.  Found by the short-direction and odd-w fuzz families.)
+    const bool robust = any && well_formed(ray) && lo > -PRT_INF && (hi - lo) > 1e-6 * ((1.0 + fabs(lo)) + fabs(hi));
+    count_paths(ray.paths, 2, any);
+    count_paths(ray.paths, 3, any && !robust);
     if (any && !robust) touched = box_touched(aabb, ray);
     // The chord argument covers the axes the ray really moves along: with |d| >= 1e-4 a slab crossing
     // is off by at most ~1e-12 / |d| <= 1e-8 (rounding, and the 1e-12 by which the compiler lets the
@@ -770,6 +800,7 @@ __device__ __forceinline__ void csg_keep(int op, const double (&lv)[ML], const d
       touched = touched && !outside && !(px && py && pz);
       const bool grazing = (!px && ax < 1e-4) || (!py && ay < 1e-4) || (!pz && az < 1e-4);
       if (__ballot(grazing && any && robust) != 0ull) {
+        count_paths(ray.paths, 3, grazing && any && robust);
         if (grazing && any && robust) touched = touched && box_touched(aabb, ray);
       }
     }
@@ -900,10 +931,9 @@ __device__ __forceinline__ bool may_reach(const double* __restrict__ box, const 
   double t_in = 0.0, t_out = best_t;
   bool never = false;
   const double o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
-  // a direction so short that a leaf of the component may take one of upstream's degenerate branches
-  // without being parallel to anything (box[6], see short_direction_bound): the hit such a branch
-  // reports need not lie on the surface, so the box says nothing about it
-  if ((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2] < box[6]) return true;
+  // (asked only for well-formed rays: with a direction so short that a leaf of the component may take one
+  // of upstream's degenerate branches without being parallel to anything, the hit such a branch reports
+  // need not lie on the surface, and the box says nothing about it -- see well_formed)
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const double inv = __builtin_amdgcn_rcp(d[k]);
@@ -953,7 +983,7 @@ __device__ __forceinline__ void chain_candidate(const DevChain* __restrict__ ch,
       positive = positive || (l4[k] > 0 && l4[k] < PRT_INF);
       behind += l4[k] <= 0 ? 1 : 0;
     }
-    positive = positive || (behind & 1);
+    positive = positive || (behind & 1) || !well_formed(ray);
     if (op2 != CSG_UNION && __ballot(positive) == 0ull) return;
     double r2[2];
     surface_pair(T2 < 0 ? 0 : T2, ch->leaf[2], ch->leaf[2] + 6, ray, r2[0], r2[1]);
@@ -1029,6 +1059,7 @@ __device__ __forceinline__ void run_step(const DevInstr* in, const Ray8& ray, co
         has_positive = (ra.t0 > 0 && ra.t0 < PRT_INF) || (ra.t1 > 0 && ra.t1 < PRT_INF) ||
                        ((ra.t0 <= 0) != (ra.t1 <= 0));
       }
+      has_positive = has_positive || !well_formed(ray);
       if (__ballot(has_positive) == 0ull) {
         rb.t0 = PRT_INF; rb.t1 = PRT_INF; rb.prim = p;
         return;
@@ -1096,8 +1127,7 @@ __device__ __forceinline__ void run_step(const DevInstr* in, const Ray8& ray, co
 // CULL: the program may contain I_BOX steps (compiled out of the kernels that never see one).
 // ANY_W: the rays may carry homogeneous w components other than 1 / 0 (the object-space ray is then
 // M^-1 (o, w_o), M^-1 (d, w_d), not the image of the world ray: world_objects.py:360-383 multiplies the
-// translation by w), which the cull steps' world-space argument does not cover: such a ray takes
-// every component.
+// translation by w): well_formed() then looks at them (the compact kernels know they are 1 / 0).
 template <int R, bool RENDER = false, bool CULL = true, bool ANY_W = true>
 __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code, int n_instr,
                                               const Ray8 (&ray)[R], int slots, double (&best_t)[R],
@@ -1109,6 +1139,7 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
     best_prim[k] = -1;
     ra[k] = Pair{PRT_INF, PRT_INF, -1};
     rb[k] = Pair{PRT_INF, PRT_INF, -1};
+    if (ray[k].paths != nullptr) count_paths(ray[k].paths, 1, !well_formed(ray[k]));
   }
 #ifdef PRT_SPECIAL_C2
   // EXPERIMENT (timing of a fully specialised program, results valid for BASELINE config 2 only): the
@@ -1139,9 +1170,7 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
       bool wanted = false;
 #pragma unroll
       for (int k = 0; k < R; ++k)
-        wanted = wanted || may_reach(step.data, ray[k], best_t[k]) || (ANY_W && (ray[k].ow != 1.0 || ray[k].dw != 0.0));
-      PRT_COUNT(2, true);
-      PRT_COUNT(3, !wanted);
+        wanted = wanted || !well_formed(ray[k]) || may_reach(step.data, ray[k], best_t[k]);
       if (__ballot(wanted) == 0ull) pc += step.a0;  // no lane of the wave needs this component
       continue;
     }
@@ -1160,6 +1189,7 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
 // (ballots over the active lanes) stay valid: each only ever skips work when *no* active lane needs it.
 __device__ __forceinline__ void component_candidate(const DevInstr* code, int first, int last, const Ray8& ray,
                                                     const LaneLists& lists, double& t, int& prim) {
+  // (`ray` is gated by the caller: well_formed() decides about the shortcuts in here too)
   Pair ra = {PRT_INF, PRT_INF, -1}, rb = {PRT_INF, PRT_INF, -1};
   t = PRT_INF;
   prim = -1;
@@ -1170,7 +1200,7 @@ __device__ __forceinline__ void component_candidate(const DevInstr* code, int fi
       chain_step(reinterpret_cast<const DevChain*>(in), in->a0, ray, t, prim);
       pc += CHAIN_SLOTS - 1;
     } else if (kind == I_BOX) {
-      if (ray.ow == 1.0 && ray.dw == 0.0 && !may_reach(in->data, ray, PRT_INF)) return;  // the cull step leads its component
+      if (well_formed(ray) && !may_reach(in->data, ray, PRT_INF)) return;  // the cull step leads its component
     } else {
       run_step<false>(in, ray, lists, ra, rb, t, prim);
     }
@@ -1183,7 +1213,12 @@ __device__ __forceinline__ void nearest_hit(const DevPrim* __restrict__ prims,
                                             const Ray8& ray, const LaneLists& lists, double& best_t,
                                             int& best_prim) {
   (void)prims;
-  const Ray8 rays1[1] = {ray};
+  // from here on well_formed() is the one gate of every shortcut.  (The gate is opened on this copy and
+  // not on one made inside nearest_hit_n: that form cost the generation kernel 12 B of scratch per lane.)
+  Ray8 gated_ray = ray;
+  gated_ray.gated = true;
+  gated_ray.any_w = ANY_W;
+  const Ray8 rays1[1] = {gated_ray};
   double t1[1];
   int p1[1];
   nearest_hit_n<1, RENDER, CULL, ANY_W>(code, n_instr, rays1, lists.total, t1, p1);

@@ -45,6 +45,9 @@ __device__ __forceinline__ Ray8 load_ray8(const double* __restrict__ rays, int64
   Ray8 r;
   r.ox = rays[0 * ld + i]; r.oy = rays[1 * ld + i]; r.oz = rays[2 * ld + i]; r.ow = rays[3 * ld + i];
   r.dx = rays[4 * ld + i]; r.dy = rays[5 * ld + i]; r.dz = rays[6 * ld + i]; r.dw = rays[7 * ld + i];
+  r.gated = false;    // (nearest_hit() opens the gate; a ray that never meets it takes no shortcut)
+  r.any_w = true;
+  r.paths = nullptr;
   return r;
 }
 
@@ -57,6 +60,7 @@ struct TraceCtrl {
   int64_t rows_cap;
   int32_t error;      // PRT_ERR_* raised on the device
   int32_t pad;
+  unsigned long long paths[4];  // PRT_TRACE_COUNT_PATHS: [1] rays not well formed, [2] implied-box nodes with survivors, [3] ... tested exactly
 };
 
 // dead-ray rule of _pyrayt.py:415-420: absorbed (|d| ~ 0 before the interaction) or no hit;
@@ -85,7 +89,8 @@ template <bool STAGED>
 __global__ void __launch_bounds__(PRT_BLOCK)
 k_hit(SceneDev scene, const double* __restrict__ rays, int64_t ld, const TraceCtrl* __restrict__ ctrl,
       int64_t n_fixed, double* __restrict__ hit_t, int32_t* __restrict__ hit_prim,
-      int64_t* __restrict__ surf_out, int32_t* __restrict__ block_counts, int keep_absorbed) {
+      int64_t* __restrict__ surf_out, int32_t* __restrict__ block_counts, int keep_absorbed,
+      unsigned long long* __restrict__ paths) {
   const int64_t n = ctrl ? ctrl->n_cur : n_fixed;
   const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
   const LaneLists lists = lane_lists(scene.lds_slots);
@@ -100,7 +105,8 @@ k_hit(SceneDev scene, const double* __restrict__ rays, int64_t ld, const TraceCt
   }
   bool live = false, carry = false;
   if (i < n) {
-    const Ray8 r = load_ray8(rays, ld, i);
+    Ray8 r = load_ray8(rays, ld, i);
+    r.paths = paths;  // PRT_TRACE_COUNT_PATHS (null otherwise)
     double t;
     int prim;
     nearest_hit(scene.prims, code, scene.n_instr, r, lists, t, prim);
@@ -158,7 +164,8 @@ k_hit_lanes(SceneDev scene, const int32_t* __restrict__ comp_first, int n_comp,
   }
   bool live = false, carry = false;
   if (i < n) {
-    const Ray8 r = load_ray8(rays, ld, i);
+    Ray8 r = load_ray8(rays, ld, i);
+    r.gated = true;  // well_formed() is the one gate of every shortcut (prt_device.hpp)
     double best_t = PRT_INF;
     int best_prim = -1, best_comp = 0x7fffffff;
     for (int c = sub; c < n_comp; c += K) {
@@ -1141,7 +1148,7 @@ static HitVariant hit_variant(const prt_scene* s) {
 static int launch_hit(const prt_scene* s, const DeviceCopy* c, const SceneDev& sd, hipStream_t st,
                       const double* rays, int64_t ld, const TraceCtrl* ctrl, int64_t n_fixed, int64_t n_bound,
                       double* hit_t, int32_t* hit_prim, int64_t* surf_out, int32_t* tile_counts,
-                      int keep_absorbed) {
+                      int keep_absorbed, unsigned long long* paths = nullptr) {
   const HitVariant v = hit_variant(s);
   size_t lds = lds_bytes(sd.lds_slots);
   if (v.staged) lds = align_up(lds, 16) + (size_t)sd.n_instr * sizeof(DevInstr) + 8 * PRT_BLOCK;
@@ -1149,7 +1156,7 @@ static int launch_hit(const prt_scene* s, const DeviceCopy* c, const SceneDev& s
   if (v.lanes == 1) {
     auto kernel = v.staged ? k_hit<true> : k_hit<false>;
     hipLaunchKernelGGL(kernel, dim3(blocks_for(n_bound)), dim3(PRT_BLOCK), lds, st, sd, rays, ld, ctrl, n_fixed,
-                       hit_t, hit_prim, surf_out, tile_counts, keep_absorbed);
+                       hit_t, hit_prim, surf_out, tile_counts, keep_absorbed, paths);
   } else {
     if (tile_counts) HIP_TRY(hipMemsetAsync(tile_counts, 0, (size_t)blocks_for(n_bound) * 2 * sizeof(int32_t), st));
     const int n_comp = (int)s->roots.size();
@@ -1299,6 +1306,7 @@ __global__ void k_ctrl_init(TraceCtrl* ctrl, int64_t n, int64_t rows_cap) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     ctrl->n_cur = n; ctrl->n_live = 0; ctrl->n_carry = 0; ctrl->row_base = 0;
     ctrl->rows_cap = rows_cap; ctrl->error = 0; ctrl->pad = 0;
+    for (int k = 0; k < 4; ++k) ctrl->paths[k] = 0;
   }
 }
 
@@ -1414,6 +1422,9 @@ static int64_t trace_unfused(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_
   int32_t* hit_prim = (int32_t*)(w + l.hit_prim);
   double* buf[2] = {(double*)(w + l.rays_a), (double*)(w + l.rays_b)};
   const int keep_absorbed = (t->flags & PRT_TRACE_KEEP_ABSORBED) ? 1 : 0;
+  // PRT_TRACE_COUNT_PATHS: the nearest-hit kernel of this path counts (one ray per lane only: the k-lanes
+  // kernels evaluate components per lane and would count a ray once per lane group member)
+  const bool count_paths = (t->flags & PRT_TRACE_COUNT_PATHS) != 0 && s->options.hit_lanes <= 1;
   if (t->user == 0) t->user = g_next_user.fetch_add(1);
   (void)workspace_taken_over(w, t->user);  // the block is ours now: a fused trace behind this one re-initialises
   t->ready_workspace = nullptr;
@@ -1432,7 +1443,7 @@ static int64_t trace_unfused(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_
     HIP_TRY(hipEventRecord(t->ev0, st));
     {
       int rc_hit = launch_hit(s, c, sd, st, src, src_ld, (const TraceCtrl*)ctrl, (int64_t)0, n_cur, hit_t, hit_prim,
-                              (int64_t*)nullptr, counts, keep_absorbed);
+                              (int64_t*)nullptr, counts, keep_absorbed, count_paths ? ctrl->paths : nullptr);
       if (rc_hit) return rc_hit;
     }
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, (const int32_t*)counts, offsets, ctrl);
@@ -1445,7 +1456,7 @@ static int64_t trace_unfused(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_
     HIP_TRY(hipEventRecord(t->ev1, st));
     // the host needs the new ray count to size the next launch
     HIP_TRY(hipMemcpyAsync(t->host_pinned, ctrl, sizeof(TraceCtrl), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(t->host_pinned + 6, gen_rows + g, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(t->host_pinned + 12, gen_rows + g, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, t->ev0, t->ev1));
@@ -1455,7 +1466,7 @@ static int64_t trace_unfused(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_
     t->stats[2] += ms;
     t->stats[3] += 4;
     if (h->error) { error = h->error; break; }
-    const int64_t live = t->host_pinned[6];
+    const int64_t live = t->host_pinned[12];
     rows_per_generation[g] = live;
     total_rows += live;
     t->stats[4] += (double)live;
@@ -1465,6 +1476,11 @@ static int64_t trace_unfused(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_
     src_ld = n;
   }
   if (error) return trace_error(error);
+  if (count_paths) {  // (the control block of the last generation is on the host: the counters are cumulative)
+    const TraceCtrl* h = (const TraceCtrl*)t->host_pinned;
+    s->path_counts[0] += 1;
+    for (int k = 1; k < 4; ++k) s->path_counts[k] += (long long)h->paths[k];
+  }
   return total_rows;
 }
 
@@ -1709,7 +1725,8 @@ extern "C" int prt_trace_begin(prt_scene* s, int device, int ticket, const doubl
   t->compact = !s->full_rows && !(flags & PRT_TRACE_FULL_ROWS);
   t->active = true;
   if (n == 0 || generation_limit == 0) { reset_stats(s, t, PRT_VARIANT_FUSED); return PRT_OK; }
-  if (flags & PRT_TRACE_UNFUSED) {  // host round trip per generation: everything happens in prt_trace_end
+  if (flags & PRT_TRACE_COUNT_PATHS) t->flags |= PRT_TRACE_UNFUSED;  // the counting nearest-hit kernel lives on that path
+  if (t->flags & PRT_TRACE_UNFUSED) {  // host round trip per generation: everything happens in prt_trace_end
     reset_stats(s, t, s->options.hit_lanes > 1 ? PRT_VARIANT_KLANES : PRT_VARIANT_UNFUSED);
     return PRT_OK;
   }
@@ -1791,16 +1808,6 @@ extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64
   return prt_trace_end(s, device, 0, rows_per_generation);
 }
 
-#ifdef PRT_COUNT_SLOW
-extern "C" int prt_debug_slow_counters(unsigned long long* out4, int reset) {
-  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_slow), 4 * sizeof(unsigned long long)) != hipSuccess) return PRT_ERR_HIP;
-  if (reset) {
-    const unsigned long long zero[4] = {0, 0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_slow), zero, sizeof(zero)) != hipSuccess) return PRT_ERR_HIP;
-  }
-  return PRT_OK;
-}
-#endif
 
 extern "C" int prt_trace_telemetry(const prt_scene* s, int64_t* out8) {
   if (!s || !out8) return fail(PRT_ERR_ARG, "null argument");

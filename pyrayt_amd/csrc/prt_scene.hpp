@@ -61,7 +61,7 @@ struct TraceTicket {
   char seen_mode[kMaxGenerationSlots];
   double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // include/prt.h prt_trace_stats
   // resources of the ticket
-  int64_t* host_pinned = nullptr;               // 8 x int64 pinned staging (three-kernel path)
+  int64_t* host_pinned = nullptr;               // 16 x int64 pinned staging (three-kernel path: control block, row count)
   struct HostMirror* mirror = nullptr;          // host-mapped: the device publishes a batch's counts here
   struct HostMirror* mirror_dev = nullptr;      // the same memory as the device addresses it
   unsigned long long epoch = 0;                 // number of batches published so far
@@ -176,9 +176,9 @@ struct Compiler {
     const prt_node& n = s->nodes[node];
     if (s->options.no_implied) return false;  // test knob: every node tests its cull box exactly
     if (n.op == PRT_NODE_LEAF) return true;
-    // the argument needs every leaf to see directions of length >= 0.1 in object space as long as
-    // the world direction has |d|^2 >= kImpliedMinLen2 (csg_keep sends shorter ones to the exact test)
-    if (short_direction_bound(s, node) > kImpliedMinLen2) return false;
+    // the argument needs every leaf to see |d_obj|^2 >= 1e-3 for every well-formed ray, i.e. for world
+    // directions with |d|^2 >= kWellFormedLen2Lo (csg_keep sends every other ray to the exact test)
+    if (short_direction_bound(s, node) > kWellFormedLen2Lo) return false;
     bool structural = false;
     if (n.op == PRT_NODE_INTERSECT) structural = box_contains_solid(n.left) && box_contains_solid(n.right);
     if (n.op == PRT_NODE_DIFFERENCE) structural = box_contains_solid(n.left);
@@ -462,9 +462,10 @@ static Operand compile_component(const prt_scene* s, int root_node, std::vector<
   if (root_rule == ROOT_TRACE && (int)s->roots.size() >= cull_min && !cull_off) {
     DevInstr in = Compiler::blank(I_BOX);
     double* box = in.data;
-    if (solid_bounds(s, root_node, box)) {
+    // (a cull step argues about well-formed rays only; a component so large in object space that even
+    // a unit direction may be "short" to one of its leaves -- short_direction_bound -- gets none)
+    if (solid_bounds(s, root_node, box) && short_direction_bound(s, root_node) <= kWellFormedLen2Lo) {
       pad_box(box);
-      box[6] = short_direction_bound(s, root_node);
       box_at = code.size();
       code.push_back(in);
     }
@@ -542,9 +543,8 @@ static void compile_trace_run(prt_scene* s, int lo, int hi, bool grouped) {
           box[2 * k + 1] = std::max(box[2 * k + 1], member[2 * k + 1]);
         }
       }
-      if (ok) {
+      if (ok && short_bound <= kWellFormedLen2Lo) {
         pad_box(box);
-        box[6] = short_bound;
         box_at = prog.code.size();
         prog.code.push_back(in);
       }
@@ -795,7 +795,7 @@ static int on_device(prt_scene* s, int device, DeviceCopy** out) {
       c.component_code.push_back(code);
     }
     for (TraceTicket& t : c.ticket) {
-      HIP_TRY(hipHostMalloc((void**)&t.host_pinned, 8 * sizeof(int64_t), hipHostMallocDefault));
+      HIP_TRY(hipHostMalloc((void**)&t.host_pinned, 16 * sizeof(int64_t), hipHostMallocDefault));
       HIP_TRY(hipHostMalloc((void**)&t.mirror, 64 + (kMaxBatch + 4) * 64, hipHostMallocMapped | hipHostMallocCoherent));  // header + GenCtrl slots of 64 B
       std::memset((void*)t.mirror, 0, 64 + (kMaxBatch + 4) * 64);
       HIP_TRY(hipHostGetDevicePointer((void**)&t.mirror_dev, (void*)t.mirror, 0));

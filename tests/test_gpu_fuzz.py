@@ -52,6 +52,13 @@ def build_random_scene(seed):
     # (absolute thresholds) fire for short directions whether or not they are parallel to anything
     short = rng.choice(rays.shape[1] - 1000, size=600, replace=False) + 500
     rays[4:7, short] *= 10.0 ** rng.uniform(-9.0, 1.0, size=600)
+    # ... and lengths at the edges of the band in which a ray counts as well formed (the one gate of every
+    # shortcut: |d|^2 in [0.81, 1.21], prt_device.hpp well_formed): a hair inside, on, and a hair outside
+    edge_rng = np.random.default_rng(77_000 + seed)  # (its own stream: the families above stay as they were)
+    edge = edge_rng.choice(2000, size=90, replace=False) + 16_000
+    scale = np.concatenate((np.repeat([0.9, 1.1], 15) * (1.0 + edge_rng.integers(-4, 5, 30) * 2.0 ** -52),
+                            edge_rng.uniform(0.85, 1.15, 30), edge_rng.choice([0.9, 1.1], 30) + edge_rng.normal(0, 1e-9, 30)))
+    rays[4:7, edge] *= scale
     # rays that start inside some medium (their index row is what Snell's law takes for n1), of any brightness
     inside = rng.choice(18_000, size=1500, replace=False)
     rays[11, inside] = rng.uniform(1.0, 2.0, 1500)

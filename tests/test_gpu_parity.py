@@ -935,3 +935,43 @@ def test_a_missed_hint_with_an_exact_fit_record_block_is_repeated_not_reported()
         assert counts == want_counts and ds.telemetry()["speculation_misses"] == 1
         helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"exact fit after a miss, stride {stride}")
         ds.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# PRT_TRACE_COUNT_PATHS: the shipping library says how often its shortcuts fall through
+# ---------------------------------------------------------------------------------------------
+def test_path_counters_tell_well_formed_rays_from_the_others():
+    from pyrayt_amd.engine import DeviceScene
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    CountedObject.reset_ids()
+    n, limit = 20_000, 10
+    parts, rays = scenes.config2(scenes.product_api(), n)
+    snap = SceneSnapshot(parts)
+    flat = helpers.flat_scene(snap)
+    ds = DeviceScene(snap)
+    want, want_counts = orc.trace(flat, rays, limit)
+    rows, counts = ds.trace(dev(rays), limit, flags=engine.TRACE_COUNT_PATHS)
+    helpers.assert_frames_match(rows.cpu().numpy().T, want, what="counted trace")
+    tele = ds.telemetry()
+    assert tele["counted_traces"] == 1 and ds.trace_stats()["variant"] == 2  # (a counted trace runs on the three-kernel path)
+    assert tele["rays_not_well_formed"] == 0                                   # unit directions, w = 1 / 0
+    assert tele["implied_box_nodes"] >= 2 * n                                  # both nodes of the lens, generation 0 alone
+    assert tele["exact_box_tests"] < tele["implied_box_nodes"] // 100          # a cone through the middle of the lens: chords are long
+    # the same rays, every fourth one too long, every fifth with an origin w of 2: those take no shortcut
+    odd = rays.copy()
+    odd[4:7, ::4] *= 1.2
+    odd[3, ::5] = 2.0
+    want2, want2_counts = orc.trace(flat, odd, limit)
+    rows2, counts2 = ds.trace(dev(odd), limit, flags=engine.TRACE_COUNT_PATHS)
+    assert counts2 == want2_counts
+    helpers.assert_frames_match(rows2.cpu().numpy().T, want2, what="counted trace, odd rays")
+    tele2 = ds.telemetry()
+    gen0_bad = len(set(range(0, n, 4)) | set(range(0, n, 5)))
+    assert tele2["counted_traces"] == 2 and tele2["rays_not_well_formed"] >= gen0_bad
+    assert tele2["exact_box_tests"] - tele["exact_box_tests"] >= gen0_bad  # each of them tests the first node's box exactly
+    # an uncounted trace leaves the counters alone
+    ds.trace(dev(odd), limit)
+    assert ds.telemetry()["rays_not_well_formed"] == tele2["rays_not_well_formed"]
+    ds.close()
