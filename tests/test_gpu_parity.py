@@ -970,7 +970,9 @@ def test_path_counters_tell_well_formed_rays_from_the_others():
     tele2 = ds.telemetry()
     gen0_bad = len(set(range(0, n, 4)) | set(range(0, n, 5)))
     assert tele2["counted_traces"] == 2 and tele2["rays_not_well_formed"] >= gen0_bad
-    assert tele2["exact_box_tests"] - tele["exact_box_tests"] >= gen0_bad  # each of them tests the first node's box exactly
+    # (the over-long ones cross the lens like their unit twins and test the first node's box exactly;
+    # what a ray with origin w = 2 meets is another matter)
+    assert tele2["exact_box_tests"] - tele["exact_box_tests"] >= n // 4
     # an uncounted trace leaves the counters alone
     ds.trace(dev(odd), limit)
     assert ds.telemetry()["rays_not_well_formed"] == tele2["rays_not_well_formed"]
