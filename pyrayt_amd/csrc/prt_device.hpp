@@ -110,23 +110,23 @@ struct Ray8 {
 // for a ray that is what a RaySet holds (pyrayt/_pyrayt.py:29-36, sources and materials keep it so):
 //   * homogeneous coordinates w = 1 (origin) and 0 (direction): the object-space ray is then the image
 //     M^-1 of the world ray (world_objects.py:367-369 multiplies the translation by w);
-//   * a direction of unit length, here |d|^2 in [0.81, 1.21]: upstream's `isclose(.., 0)` branches use
-//     absolute 1e-8 thresholds on object-space quantities and fire for any SHORT direction, parallel
-//     or not, and what they then report is not a point of the surface; the scene compiler allows a
-//     shortcut only where |d|^2 >= 0.81 keeps every leaf's |d_obj|^2 >= 1e-3 (short_direction_bound);
-//   * a finite origin.
+//   * a direction that is not short, here |d|^2 >= 0.81 (RaySet directions are unit vectors): upstream's
+//     `isclose(.., 0)` branches use absolute 1e-8 thresholds on object-space quantities and fire for any
+//     SHORT direction, parallel or not, and what they then report is not a point of the surface; the
+//     scene compiler allows a shortcut only where |d|^2 >= 0.81 keeps every leaf's |d_obj|^2 >= 1e-3
+//     (short_direction_bound).  (A NaN direction fails the test; an infinite or NaN origin needs no
+//     clause of its own: hit lists of such a ray hold no robust pair of survivors, and may_reach answers
+//     "yes" whenever a comparison involves a NaN.)
 // Any other ray takes none of them: every component, every upstream cull box exactly, every leaf.
 // One predicate for all of them; DESIGN.md section 4 has the argument per shortcut.  (It is a pure function
 // of the ray and is written out at every site: holding its value across the hit phase instead costs the
 // generation kernel its register allocation -- the lane mask lives in SGPRs, of which the kernel has none
 // to spare -- while the compiler is free to share it between neighbouring sites as it is.)
 #define kWellFormedLen2Lo 0.81
-#define kWellFormedLen2Hi 1.21
 __device__ __forceinline__ bool well_formed(const Ray8& r) {
   if (!r.gated) return false;
   const double len2 = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;
-  bool ok = len2 >= kWellFormedLen2Lo && len2 <= kWellFormedLen2Hi;  // (NaN and infinite directions fail)
-  ok = ok && fabs(r.ox) < PRT_INF && fabs(r.oy) < PRT_INF && fabs(r.oz) < PRT_INF;
+  bool ok = len2 >= kWellFormedLen2Lo;  // (a NaN fails)
   if (r.any_w) ok = ok && r.ow == 1.0 && r.dw == 0.0;
   return ok;
 }

@@ -53,7 +53,8 @@ def build_random_scene(seed):
     short = rng.choice(rays.shape[1] - 1000, size=600, replace=False) + 500
     rays[4:7, short] *= 10.0 ** rng.uniform(-9.0, 1.0, size=600)
     # ... and lengths at the edges of the band in which a ray counts as well formed (the one gate of every
-    # shortcut: |d|^2 in [0.81, 1.21], prt_device.hpp well_formed): a hair inside, on, and a hair outside
+    # shortcut: |d|^2 >= 0.81, prt_device.hpp well_formed): a hair inside, on, and a hair outside (and around
+    # 1.1, which an earlier form of the gate also excluded)
     edge_rng = np.random.default_rng(77_000 + seed)  # (its own stream: the families above stay as they were)
     edge = edge_rng.choice(2000, size=90, replace=False) + 16_000
     scale = np.concatenate((np.repeat([0.9, 1.1], 15) * (1.0 + edge_rng.integers(-4, 5, 30) * 2.0 ** -52),
