@@ -99,6 +99,7 @@ struct Ray8 {
   // (set by nearest_hit(); a ray built from its eight numbers alone has gated == false: no shortcut)
   bool gated;                 // the ray may take shortcuts if well_formed() says so
   bool any_w;                 // its w components are not known to be 1 / 0 (well_formed() looks at them)
+  bool lex;                   // the program may visit components out of list order: see beats()
   unsigned long long* paths;  // PRT_TRACE_COUNT_PATHS counters, or null
 };
 
@@ -129,6 +130,16 @@ __device__ __forceinline__ bool well_formed(const Ray8& r) {
   bool ok = len2 >= kWellFormedLen2Lo;  // (a NaN fails)
   if (r.any_w) ok = ok && r.ow == 1.0 && r.dw == 0.0;
   return ok;
+}
+// The running nearest hit over components (pyrayt/_pyrayt.py:380-386): a candidate replaces it when it
+// is strictly nearer -- so among equal parameters the component that comes first in the LIST keeps it.
+// A program that visits components in list order gets that from the strict '<' alone.  One whose cull
+// steps are grouped by position (prt_scene.hpp) visits them in another order and compares
+// lexicographically on (t, primitive index) instead: primitives are numbered component by component
+// (checked by the scene compiler), so that is (t, list index).  In a list-order program the second clause
+// never fires.
+__device__ __forceinline__ bool beats(const Ray8& ray, double t, int prim, double best_t, int best_prim) {
+  return t < best_t || (ray.lex && t == best_t && prim < best_prim);
 }
 // PRT_TRACE_COUNT_PATHS: one atomic per wave and site; `paths` is null (a compile-time constant in the
 // fused kernel, which carries none of this) unless the trace asked for the counts
@@ -993,7 +1004,7 @@ __device__ __forceinline__ void chain_candidate(const DevChain* __restrict__ ch,
     const int lid[4] = {id0, id0, id1, id1}, rid[2] = {id2, id2};
     csg_root_pick<4, 2>(l4, lid, keep4, r2, rid, keep2, t, prim);
   }
-  if (t < best_t) {
+  if (beats(ray, t, prim, best_t, best_prim)) {
     best_t = t;
     best_prim = prim;
   }
@@ -1080,7 +1091,7 @@ __device__ __forceinline__ void run_step(const DevInstr* in, const Ray8& ray, co
       double t = pos0 ? t0 : (pos1 ? t1 : PRT_INF);
       bool hit = pos0 || pos1;
       if (RENDER && !hit) { t = t0; hit = t0 < PRT_INF; }
-      if (hit && t < best_t) {
+      if (hit && beats(ray, t, p, best_t, best_prim)) {
         best_t = t;
         best_prim = p;
       }
@@ -1101,7 +1112,7 @@ __device__ __forceinline__ void run_step(const DevInstr* in, const Ray8& ray, co
 #else
     csg_step(in, ray, lists, ra, rb, is_root, t, prim);
 #endif
-    if (is_root && t < best_t) {
+    if (is_root && beats(ray, t, prim, best_t, best_prim)) {
       best_t = t;
       best_prim = prim;
     }
@@ -1113,7 +1124,7 @@ __device__ __forceinline__ void run_step(const DevInstr* in, const Ray8& ray, co
       first_positive_else_first(o, lists, ra, rb, t, prim);
     else
       first_positive(o, lists, ra, rb, t, prim);
-    if (t < best_t) {
+    if (beats(ray, t, prim, best_t, best_prim)) {
       best_t = t;
       best_prim = prim;
     }
@@ -1218,6 +1229,7 @@ __device__ __forceinline__ void nearest_hit(const DevPrim* __restrict__ prims,
   Ray8 gated_ray = ray;
   gated_ray.gated = true;
   gated_ray.any_w = ANY_W;
+  gated_ray.lex = CULL && !RENDER;  // (only programs with cull steps are ever grouped by position)
   const Ray8 rays1[1] = {gated_ray};
   double t1[1];
   int p1[1];

@@ -47,6 +47,7 @@ __device__ __forceinline__ Ray8 load_ray8(const double* __restrict__ rays, int64
   r.dx = rays[4 * ld + i]; r.dy = rays[5 * ld + i]; r.dz = rays[6 * ld + i]; r.dw = rays[7 * ld + i];
   r.gated = false;    // (nearest_hit() opens the gate; a ray that never meets it takes no shortcut)
   r.any_w = true;
+  r.lex = false;
   r.paths = nullptr;
   return r;
 }
@@ -166,6 +167,8 @@ k_hit_lanes(SceneDev scene, const int32_t* __restrict__ comp_first, int n_comp,
   if (i < n) {
     Ray8 r = load_ray8(rays, ld, i);
     r.gated = true;  // well_formed() is the one gate of every shortcut (prt_device.hpp)
+    // (each lane reduces ITS components with the strict '<' in ascending list index; the group reduce below
+    // is lexicographic on (t, list index) whatever order the program stores the components in)
     double best_t = PRT_INF;
     int best_prim = -1, best_comp = 0x7fffffff;
     for (int c = sub; c < n_comp; c += K) {

@@ -98,6 +98,7 @@ struct prt_scene {
   std::vector<DeviceCopy> per_device;
   bool has_untracable = false;
   bool has_cull_steps = false;                  // the trace program carries I_BOX steps (k_generation<CULL>)
+  bool spatial_groups = false;                  // ... grouped by position: components are visited out of list order
   int stats_device = -1, stats_ticket = 0;      // whose statistics prt_trace_stats reports: the trace ended last
   int last_generations = 0;  // working generations of the previous trace: sizes the first batch
   long lookback_fallbacks = 0;  // traces of this scene that fell back to the three-kernel path
@@ -506,53 +507,184 @@ static Operand compile_component(const prt_scene* s, int root_node, std::vector<
   return res;
 }
 
-// The trace program of components [lo, hi) of the scene, in list order.  Scenes of many components
-// get a hierarchy of cull steps over *runs of consecutive components*: a run of more than
-// kGroupFanout components is split into kGroupFanout sub-runs, each led by an I_BOX step holding
-// the union of its members' solid boxes whose jump spans the whole sub-run (the interpreter's I_BOX
-// semantic nests as it is).  A coherent wave then tests O(fanout * log n) boxes instead of n: the
-// runs behind it, or beyond its nearest hit so far, go with one test each.  Order of evaluation
-// -- and with it the strict '<' tie rule of _pyrayt.py:384 -- stays the component list's.
+// The trace program: every component's steps, and for scenes of many components a hierarchy of cull steps
+// over GROUPS of components: a group of more than kGroupFanout components is split into kGroupFanout
+// sub-groups, each led by an I_BOX step holding the union of its members' solid boxes whose jump spans
+// the whole sub-group (the interpreter's I_BOX semantic nests as it is).  A coherent wave then tests
+// O(fanout * log n) boxes instead of n: the groups behind it, or beyond its nearest hit so far, go with
+// one test each.
+// Two ways to form the groups.  LIST ORDER: runs of consecutive components -- tight when the parts are
+// listed the way an optical train is written down, along the axis.  BY POSITION: the components are split
+// at the median of their box centres along the longest axis of those centres, twice per level (four
+// sub-groups), so the boxes are tight whatever order the caller listed the parts in; the program then
+// visits components out of list order, which the tie rule of pyrayt/_pyrayt.py:380-386 (the first
+// component in list order among those with the smallest t) survives because the running minimum is then
+// kept lexicographically on (t, primitive index) -- primitives are numbered component by component, so
+// that IS (t, list index) (Ray8::lex, `beats`).  The spatial form is taken when its boxes are clearly
+// smaller (summed half surface area below 0.9 of the list-order form's); prt_scene_options.list_order_groups
+// keeps the list-order form.
 static const int kGroupFanout = 4;
 static const int kGroupMinComponents = 8;
-static void compile_trace_run(prt_scene* s, int lo, int hi, bool grouped) {
+
+struct Group {
+  std::vector<int> comps;    // list indices of the components under this node, ascending
+  std::vector<Group> kids;   // empty: a single component
+  bool boxed = false;        // led by its own cull step (a sub-group of several components)
+};
+struct ComponentBox {
+  bool ok = false;           // solid_bounds() succeeded and the cull argument applies (short_direction_bound)
+  double box[6] = {0, 0, 0, 0, 0, 0};
+};
+
+static bool union_box(const std::vector<ComponentBox>& boxes, const std::vector<int>& comps, double* out) {
+  for (int k = 0; k < 3; ++k) { out[2 * k] = HUGE_VAL; out[2 * k + 1] = -HUGE_VAL; }
+  for (int c : comps) {
+    if (!boxes[c].ok) return false;
+    for (int k = 0; k < 3; ++k) {
+      out[2 * k] = std::min(out[2 * k], boxes[c].box[2 * k]);
+      out[2 * k + 1] = std::max(out[2 * k + 1], boxes[c].box[2 * k + 1]);
+    }
+  }
+  return !comps.empty();
+}
+
+// split `comps` into up to kGroupFanout parts: consecutive runs, or by position (median splits)
+static std::vector<std::vector<int>> split_group(const std::vector<ComponentBox>& boxes, const std::vector<int>& comps,
+                                                 bool spatial) {
+  std::vector<std::vector<int>> parts;
+  const int n = (int)comps.size();
+  if (!spatial) {
+    const int step = (n + kGroupFanout - 1) / kGroupFanout;
+    for (int at = 0; at < n; at += step) parts.emplace_back(comps.begin() + at, comps.begin() + std::min(n, at + step));
+    return parts;
+  }
+  auto halve = [&](const std::vector<int>& in, std::vector<int>& lo, std::vector<int>& hi) {
+    double cmin[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, cmax[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+    for (int c : in)
+      for (int k = 0; k < 3; ++k) {
+        const double mid = 0.5 * (boxes[c].box[2 * k] + boxes[c].box[2 * k + 1]);
+        cmin[k] = std::min(cmin[k], mid);
+        cmax[k] = std::max(cmax[k], mid);
+      }
+    int axis = 0;
+    for (int k = 1; k < 3; ++k) if (cmax[k] - cmin[k] > cmax[axis] - cmin[axis]) axis = k;
+    std::vector<int> sorted = in;
+    std::stable_sort(sorted.begin(), sorted.end(), [&](int a, int b) {
+      return boxes[a].box[2 * axis] + boxes[a].box[2 * axis + 1] < boxes[b].box[2 * axis] + boxes[b].box[2 * axis + 1];
+    });
+    const size_t half = (sorted.size() + 1) / 2;
+    lo.assign(sorted.begin(), sorted.begin() + half);
+    hi.assign(sorted.begin() + half, sorted.end());
+  };
+  std::vector<int> lo, hi, q[4];
+  halve(comps, lo, hi);
+  if (lo.size() > 1) halve(lo, q[0], q[1]); else q[0] = lo;
+  if (hi.size() > 1) halve(hi, q[2], q[3]); else q[2] = hi;
+  for (auto& part : q)
+    if (!part.empty()) {
+      std::sort(part.begin(), part.end());  // inside a group: list order
+      parts.push_back(part);
+    }
+  return parts;
+}
+
+static Group build_groups(const std::vector<ComponentBox>& boxes, const std::vector<int>& comps, bool grouped,
+                          bool spatial) {
+  Group g;
+  g.comps = comps;
+  if (comps.size() <= 1) return g;
+  std::vector<std::vector<int>> parts;
+  if (grouped && (int)comps.size() > kGroupFanout) {
+    parts = split_group(boxes, comps, spatial);
+  } else {
+    for (int c : comps) parts.push_back({c});
+  }
+  for (const auto& part : parts) {
+    Group kid = build_groups(boxes, part, grouped, spatial);
+    double unused[6];
+    kid.boxed = part.size() > 1 && union_box(boxes, part, unused);
+    g.kids.push_back(std::move(kid));
+  }
+  return g;
+}
+
+// summed half surface area of the group boxes: what a ray has to get past, per level
+static double group_cost(const std::vector<ComponentBox>& boxes, const Group& g) {
+  double cost = 0.0;
+  for (const Group& kid : g.kids) {
+    double b[6];
+    if (kid.boxed && union_box(boxes, kid.comps, b)) {
+      const double dx = b[1] - b[0], dy = b[3] - b[2], dz = b[5] - b[4];
+      cost += dx * dy + dy * dz + dz * dx;
+    }
+    cost += group_cost(boxes, kid);
+  }
+  return cost;
+}
+
+static void emit_groups(prt_scene* s, const std::vector<ComponentBox>& boxes, const Group& g) {
   Program& prog = s->trace_program;
-  const int n = hi - lo;
-  if (n == 1) {
-    prog.component_first.push_back((int32_t)prog.code.size());
-    compile_component(s, s->roots[lo], prog.code, ROOT_TRACE, &prog.lds_slots);
-    prog.component_first.push_back((int32_t)prog.code.size());
+  if (g.kids.empty()) {
+    for (int c : g.comps) {  // (one component)
+      prog.component_first[2 * c] = (int32_t)prog.code.size();
+      compile_component(s, s->roots[c], prog.code, ROOT_TRACE, &prog.lds_slots);
+      prog.component_first[2 * c + 1] = (int32_t)prog.code.size();
+    }
     return;
   }
-  const int step = grouped && n > kGroupFanout ? (n + kGroupFanout - 1) / kGroupFanout : 1;
-  for (int at = lo; at < hi; at += step) {
-    const int end = std::min(hi, at + step);
+  for (const Group& kid : g.kids) {
     size_t box_at = (size_t)-1;
-    if (end - at > 1) {  // a sub-run of several components: its own cull step in front
+    if (kid.boxed) {  // a sub-group of several components: its own cull step in front
       DevInstr in = Compiler::blank(I_BOX);
-      double* box = in.data;
-      bool ok = true;
-      for (int k = 0; k < 3; ++k) { box[2 * k] = HUGE_VAL; box[2 * k + 1] = -HUGE_VAL; }
-      double short_bound = 0.0;
-      for (int c = at; c < end && ok; ++c) {
-        double member[6];
-        ok = solid_bounds(s, s->roots[c], member);
-        short_bound = std::max(short_bound, short_direction_bound(s, s->roots[c]));
-        for (int k = 0; k < 3 && ok; ++k) {
-          box[2 * k] = std::min(box[2 * k], member[2 * k]);
-          box[2 * k + 1] = std::max(box[2 * k + 1], member[2 * k + 1]);
-        }
-      }
-      if (ok && short_bound <= kWellFormedLen2Lo) {
-        pad_box(box);
+      if (union_box(boxes, kid.comps, in.data)) {
+        pad_box(in.data);
         box_at = prog.code.size();
         prog.code.push_back(in);
       }
     }
     const size_t from = prog.code.size();
-    compile_trace_run(s, at, end, grouped);
+    emit_groups(s, boxes, kid);
     if (box_at != (size_t)-1) prog.code[box_at].a0 = (int)(prog.code.size() - from);
   }
+}
+
+static void first_and_last_prim(const prt_scene* s, int node, int* lo, int* hi) {
+  const prt_node& n = s->nodes[node];
+  if (n.op == PRT_NODE_LEAF) { *lo = std::min(*lo, n.prim); *hi = std::max(*hi, n.prim); return; }
+  first_and_last_prim(s, n.left, lo, hi);
+  first_and_last_prim(s, n.right, lo, hi);
+}
+
+static void compile_trace_program(prt_scene* s) {
+  Program& prog = s->trace_program;
+  const int n = (int)s->roots.size();
+  prog.component_first.assign((size_t)2 * n, 0);
+  s->spatial_groups = false;
+  if (n == 0) return;
+  const bool cull_off = s->options.no_cull != 0 || s->options.no_groups != 0;
+  const bool grouped = n >= kGroupMinComponents && !cull_off;
+  std::vector<ComponentBox> boxes(n);
+  std::vector<int> all(n);
+  bool every_box = true, prims_follow_components = true;
+  int last_prim = -1;
+  for (int c = 0; c < n; ++c) {
+    all[c] = c;
+    boxes[c].ok = solid_bounds(s, s->roots[c], boxes[c].box) && short_direction_bound(s, s->roots[c]) <= kWellFormedLen2Lo;
+    every_box = every_box && boxes[c].ok;
+    int lo = INT32_MAX, hi = -1;
+    first_and_last_prim(s, s->roots[c], &lo, &hi);
+    prims_follow_components = prims_follow_components && lo > last_prim;  // (t, primitive index) == (t, list index)
+    last_prim = std::max(last_prim, hi);
+  }
+  Group tree = build_groups(boxes, all, grouped, false);
+  if (grouped && every_box && prims_follow_components && !s->options.list_order_groups) {
+    Group by_position = build_groups(boxes, all, grouped, true);
+    if (group_cost(boxes, by_position) < 0.9 * group_cost(boxes, tree)) {
+      tree = std::move(by_position);
+      s->spatial_groups = true;
+    }
+  }
+  emit_groups(s, boxes, tree);
 }
 
 static int validate_tree(const prt_scene* s, int node, int depth, std::vector<char>& seen) {
@@ -635,12 +767,8 @@ extern "C" int prt_scene_create(const prt_prim* prims, int n_prims, const prt_no
     if (m.kind == PRT_MAT_NONE) s->has_untracable = true;
     s->dev_prims.push_back(d);
   }
-  {
-    const bool cull_off = s->options.no_cull != 0 || s->options.no_groups != 0;
-    const bool grouped = (int)s->roots.size() >= kGroupMinComponents && !cull_off;
-    if (!s->roots.empty()) compile_trace_run(s, 0, (int)s->roots.size(), grouped);
-    s->has_cull_steps = count_steps(s->trace_program.code, I_BOX) > 0;
-  }
+  compile_trace_program(s);
+  s->has_cull_steps = count_steps(s->trace_program.code, I_BOX) > 0;
   for (int r : s->roots) {
     compile_component(s, r, s->render_program.code, ROOT_RENDER, &s->render_program.lds_slots);
     Program p;
@@ -734,14 +862,17 @@ extern "C" int prt_scene_update(prt_scene* s, const prt_prim* prims, int n_prims
   std::swap(s->render_program, t->render_program);
   s->options = t->options;
   s->has_cull_steps = t->has_cull_steps;
+  s->spatial_groups = t->spatial_groups;
   s->component_programs.swap(t->component_programs);
   s->component_result.swap(t->component_result);
   prt_scene_destroy(t);  // (never reached a device: host memory only)
   return PRT_OK;
 }
 
-extern "C" int prt_scene_info(const prt_scene* s, int64_t* out8) {
-  if (!s || !out8) return fail(PRT_ERR_ARG, "null argument");
+extern "C" int prt_scene_info(const prt_scene* s, int64_t* out9) {
+  int64_t* out8 = out9;
+  if (!s || !out9) return fail(PRT_ERR_ARG, "null argument");
+  out9[8] = s->spatial_groups ? 1 : 0;
   const int64_t culls = count_steps(s->trace_program.code, I_BOX);
   out8[0] = (int64_t)s->prims.size();
   out8[1] = (int64_t)s->roots.size();

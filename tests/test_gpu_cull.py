@@ -141,3 +141,68 @@ def test_random_scenes_of_many_components(api, seed):
 def test_two_components_carry_no_cull_steps(api):
     parts, rays = scenes.config2(api, 2048)
     check(parts, rays, 10, expect_culls=False)
+
+
+# ---- groups formed by position: components listed in any order ------------------------------------------
+def test_shuffled_lens_train_groups_by_position(api):
+    """32 lenses + detector listed in random order: the cull-step hierarchy is built over positions, the
+    program visits components out of list order, ids and frames still equal the C oracle's."""
+    from pyrayt_amd.engine import DeviceScene
+    from pyrayt_amd.scene import SceneSnapshot
+
+    c = api.components
+    order = np.random.default_rng(11).permutation(32)
+    parts = [c.biconvex_lens(4, 4, 0.25, aperture=1).move_x(1.0 * k) for k in order]
+    parts.insert(7, c.baffle((2, 2)).move_x(33.0))
+    assert DeviceScene(SceneSnapshot(parts)).info()["spatial_groups"] == 1
+    rays = np.hstack((scenes.cone_rays(5000, (-3.0, 0.0, 0.0), 3.0, 41),
+                      scenes.cone_rays(3000, (12.5, 0.0, 0.0), 30.0, 42),
+                      scenes.random_rays(4288, 43, box=20.0, degenerate=True)))
+    rays[4, 5000:6500] *= -1.0
+    rays[12] = np.arange(rays.shape[1])
+    counts = check(parts, rays, 70)
+    assert len(counts) > 60
+    check(parts, rays, 12, options={"list_order_groups": 1})
+
+
+def test_ties_between_components_resolve_in_list_order_whatever_the_program_order(api):
+    """Coincident surfaces in different components: the reference keeps the component that comes first in
+    the LIST (strict '<' running minimum, pyrayt/_pyrayt.py:380-386).  With groups formed by position the
+    program meets them in another order and has to compare (t, list index)."""
+    from pyrayt_amd.engine import DeviceScene
+    from pyrayt_amd.scene import SceneSnapshot
+
+    cg, m, c = api.cg, api.materials, api.components
+    rng = np.random.default_rng(23)
+    parts = []
+    # pairs of identical surfaces at identical places, the twins far apart in the list; materials differ,
+    # so a wrong winner changes the frame as well as the surface id
+    spots = [(float(x), float(y)) for x in (-6, -2, 2, 6) for y in (-3, 3)]
+    twins = []
+    for k, (x, y) in enumerate(spots):
+        first = cg.Sphere(0.8, material=m.mirror).move(x, y, 0.0)
+        second = cg.Sphere(0.8, material=m.absorber if k % 2 else m.glass["BK7"]).move(x, y, 0.0)
+        parts.append(first)
+        twins.append(second)
+    plates = [c.baffle((3, 3)).move_x(9.0), c.baffle((3, 3)).move_x(9.0)]   # the same plane twice
+    order = rng.permutation(len(twins))
+    parts = parts[:3] + [plates[1]] + parts[3:] + [twins[k] for k in order] + [plates[0]]
+    assert DeviceScene(SceneSnapshot(parts)).info()["spatial_groups"] == 1
+    rays = scenes.random_rays(16384, 77, box=7.0, degenerate=True)
+    aim = np.array([spots[k % len(spots)] + (0.0,) for k in range(4000)]).T + rng.normal(0, 0.3, (3, 4000))
+    rays[4:7, 200:4200] = aim - rays[0:3, 200:4200]
+    rays[4:7, 200:4200] /= np.linalg.norm(rays[4:7, 200:4200], axis=0)
+    rays[12] = np.arange(rays.shape[1])
+    check(parts, rays, 6)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scenes_listed_in_random_order(api, seed):
+    rng = np.random.default_rng(9000 + seed)
+    parts = []
+    for _ in range(int(rng.integers(9, 20))):
+        comp = random_component(rng, api.cg, api.materials, depth=int(rng.integers(0, 3)))
+        parts.append(comp.scale(*rng.uniform(0.4, 0.9, 3)).move(*rng.uniform(-6.0, 6.0, 3)))
+    rays = scenes.random_rays(12_000, seed=9100 + seed, box=7.0, wavelength=0.55)
+    check(parts, rays, 6)
+    check(parts, rays, 3, options={"hit_lanes": 8})

@@ -270,3 +270,34 @@ def test_scene_update_keeps_the_object_for_the_same_shape_only():
     assert ds.snapshot is moved and ds.info() == before
     assert ds.update(SceneSnapshot(parts + [api.components.baffle((1, 1)).move_x(90)])) is False
     ds.close()
+
+
+def test_cull_step_hierarchy_follows_space_when_the_list_does_not():
+    """Scenes of eight or more components get a hierarchy of cull steps over groups of components.  Listed
+    along the axis, runs of consecutive components are tight groups and are kept; listed in any other
+    order, the groups are formed by position (host-only: prt_scene_info says which)."""
+    import numpy as np
+
+    import scenes
+    from pyrayt_amd import engine
+    from pyrayt_amd.g3d.objects import CountedObject
+
+    api = scenes.product_api()
+
+    def train(order):
+        CountedObject.reset_ids()
+        lenses = [api.components.biconvex_lens(4, 4, 0.25, aperture=1).move_x(1.0 * k) for k in order]
+        return lenses + [api.components.baffle((2, 2)).move_x(len(order) + 1.0)]
+
+    in_order = engine.DeviceScene.from_components(train(range(32))).info()
+    assert in_order["spatial_groups"] == 0 and in_order["cull_steps"] > 33
+    shuffled = np.random.default_rng(5).permutation(32)
+    by_position = engine.DeviceScene.from_components(train(shuffled)).info()
+    assert by_position["spatial_groups"] == 1
+    assert by_position["cull_steps"] > 33                               # one per component plus the group steps
+    kept = engine.DeviceScene.from_components(train(shuffled), options={"list_order_groups": 1}).info()
+    assert kept["spatial_groups"] == 0 and kept["cull_steps"] == in_order["cull_steps"]
+    flat = engine.DeviceScene.from_components(train(shuffled), options={"no_groups": 1}).info()
+    assert flat["spatial_groups"] == 0 and flat["cull_steps"] == 33
+    few = engine.DeviceScene.from_components(train(np.random.default_rng(6).permutation(6))).info()
+    assert few["spatial_groups"] == 0 and few["cull_steps"] == 7         # below eight components: no groups at all
