@@ -158,11 +158,12 @@ int prt_scene_update(prt_scene* scene, const prt_prim* prims, int n_prims, const
 /* rows of the hit list component `root` returns from intersect(): 2 * (#leaves under it) */
 int prt_scene_component_rows(const prt_scene* scene, int root);
 /* what the scene compiled to (no counterpart upstream; host-only, needs no GPU):
- * out9 = { primitives, components, step slots of the trace program, LDS hit-list slots per ray of the
+ * out10 = { primitives, components, step slots of the trace program, LDS hit-list slots per ray of the
  * trace program, component cull steps in it, steps / slots of the render program, components of the
  * trace program compiled to a single register-only chain step, 1 if the cull steps are grouped by the
- * components' position in space rather than by their place in the list } */
-int prt_scene_info(const prt_scene* scene, int64_t* out9);
+ * components' position in space rather than by their place in the list, 1 if the trace program is stored
+ * in both directions (waves that run against its axis take the mirror image) } */
+int prt_scene_info(const prt_scene* scene, int64_t* out10);
 
 /* ---- per-state entry points (drop-ins for the reference's Python methods) ------------------ */
 

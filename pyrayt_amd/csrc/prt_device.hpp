@@ -44,6 +44,11 @@ __device__ __forceinline__ ConstPrimPtr const_prim(const DevPrim* prims, int ind
 }
 
 enum { I_LEAF = 0, I_CSG = 1, I_ROOT = 2, I_BOX = 3, I_CHAIN = 4 };
+// I_BOX steps ("jump a0 steps ahead if no lane of the wave wants what follows"), a1 says what is asked:
+//   BOX_TEST  can the ray reach the box (data[0..5]) before its nearest hit so far?   (component cull step)
+//   BOX_PICK  does the wave mostly run ALONG the program's axis (a2)?  -- if not, jump to the mirror image
+//   BOX_JUMP  nothing is wanted: the end of the program proper, over its mirror image
+enum { BOX_TEST = 0, BOX_PICK = 1, BOX_JUMP = 2 };
 enum { OPER_REGA = 0, OPER_REGB = 1, OPER_LDS = 2 };
 enum { CSG_UNION = 1, CSG_INTERSECT = 2, CSG_DIFFERENCE = 3 };
 enum { PRIM_SPHERE = 0, PRIM_CYLINDER = 1, PRIM_PLANE = 2, PRIM_CUBE = 3, PRIM_PARABOLOID = 4 };
@@ -1178,6 +1183,17 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
     }
     const DevInstr step = code[pc];  // the whole record, one batch of scalar loads
     if (CULL && !RENDER && step.kind == I_BOX) {
+      if (step.a1 != BOX_TEST) {  // (uniform) the frame of a program that is stored in both directions
+        bool jump = true;
+        if (step.a1 == BOX_PICK) {
+          const int axis = step.a2 & 3;
+          const double along = axis == 0 ? ray[0].dx : (axis == 1 ? ray[0].dy : ray[0].dz);
+          const int down = __popcll(__ballot(along < 0.0)), up = __popcll(__ballot(along > 0.0));
+          jump = (step.a2 & 4) ? up > down : down > up;  // most rays run against the program: take the mirror image
+        }
+        if (jump) pc += step.a0;
+        continue;
+      }
       bool wanted = false;
 #pragma unroll
       for (int k = 0; k < R; ++k)

@@ -254,10 +254,10 @@ class DeviceScene:
 
     def info(self):
         """What the scene compiled to (host-only): step / slot / cull-step counts."""
-        out = (ctypes.c_int64 * 9)()
+        out = (ctypes.c_int64 * 10)()
         _check(library().prt_scene_info(self.handle, out))
         keys = ("primitives", "components", "trace_steps", "trace_slots", "cull_steps", "render_steps",
-                "render_slots", "chain_steps", "spatial_groups")
+                "render_slots", "chain_steps", "spatial_groups", "both_directions")
         return dict(zip(keys, (int(v) for v in out)))
 
     def close(self):

@@ -291,6 +291,7 @@ def test_cull_step_hierarchy_follows_space_when_the_list_does_not():
 
     in_order = engine.DeviceScene.from_components(train(range(32))).info()
     assert in_order["spatial_groups"] == 0 and in_order["cull_steps"] > 33
+    assert in_order["both_directions"] == 1   # a grouped program is stored forwards and in mirror image
     shuffled = np.random.default_rng(5).permutation(32)
     by_position = engine.DeviceScene.from_components(train(shuffled)).info()
     assert by_position["spatial_groups"] == 1
@@ -301,3 +302,4 @@ def test_cull_step_hierarchy_follows_space_when_the_list_does_not():
     assert flat["spatial_groups"] == 0 and flat["cull_steps"] == 33
     few = engine.DeviceScene.from_components(train(np.random.default_rng(6).permutation(6))).info()
     assert few["spatial_groups"] == 0 and few["cull_steps"] == 7         # below eight components: no groups at all
+    assert few["both_directions"] == 0 and flat["both_directions"] == 0
