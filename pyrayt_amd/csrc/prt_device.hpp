@@ -46,8 +46,9 @@ __device__ __forceinline__ ConstPrimPtr const_prim(const DevPrim* prims, int ind
 enum { I_LEAF = 0, I_CSG = 1, I_ROOT = 2, I_BOX = 3, I_CHAIN = 4 };
 // I_BOX steps ("jump a0 steps ahead if no lane of the wave wants what follows"), a1 says what is asked:
 //   BOX_TEST  can the ray reach the box (data[0..5]) before its nearest hit so far?   (component cull step)
-//   BOX_PICK  does the wave mostly run ALONG the program's axis (a2)?  -- if not, jump to the mirror image
-//   BOX_JUMP  nothing is wanted: the end of the program proper, over its mirror image
+//   BOX_PICK  does the wave mostly run AGAINST the program's axis (a2)?  the mirror image follows; if not,
+//             jump over it to the program proper
+//   BOX_JUMP  nothing is wanted: the end of the mirror image, over the program proper
 enum { BOX_TEST = 0, BOX_PICK = 1, BOX_JUMP = 2 };
 enum { OPER_REGA = 0, OPER_REGB = 1, OPER_LDS = 2 };
 enum { CSG_UNION = 1, CSG_INTERSECT = 2, CSG_DIFFERENCE = 3 };
@@ -144,7 +145,11 @@ __device__ __forceinline__ bool well_formed(const Ray8& r) {
 // (checked by the scene compiler), so that is (t, list index).  In a list-order program the second clause
 // never fires.
 __device__ __forceinline__ bool beats(const Ray8& ray, double t, int prim, double best_t, int best_prim) {
+#ifdef PRT_NO_LEX  // experiment: what the second clause costs (results wrong for ties in reordered programs)
+  return t < best_t;
+#else
   return t < best_t || (ray.lex && t == best_t && prim < best_prim);
+#endif
 }
 // PRT_TRACE_COUNT_PATHS: one atomic per wave and site; `paths` is null (a compile-time constant in the
 // fused kernel, which carries none of this) unless the trace asked for the counts
@@ -1180,18 +1185,24 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
         pc += CHAIN_SLOTS - 1;
         continue;
       }
+      // the frame of a program that is stored in both directions: decided on the step's first 16 bytes
+      // (kind, a0, a1, a2 -- the fetch that told a chain step apart), not on the whole record
+      if (CULL && kind == I_BOX && code[pc].a1 != BOX_TEST) {  // uniform
+        bool jump = true;
+        if (code[pc].a1 == BOX_PICK) {
+          const int axis = code[pc].a2 & 3;
+          const double along = axis == 0 ? ray[0].dx : (axis == 1 ? ray[0].dy : ray[0].dz);
+          const int down = __popcll(__ballot(along < 0.0)), up = __popcll(__ballot(along > 0.0));
+          jump = (code[pc].a2 & 4) ? down >= up : up >= down;  // most rays run along the program: skip the mirror image
+        }
+        if (jump) pc += shape;  // (a0)
+        continue;
+      }
     }
     const DevInstr step = code[pc];  // the whole record, one batch of scalar loads
     if (CULL && !RENDER && step.kind == I_BOX) {
-      if (step.a1 != BOX_TEST) {  // (uniform) the frame of a program that is stored in both directions
-        bool jump = true;
-        if (step.a1 == BOX_PICK) {
-          const int axis = step.a2 & 3;
-          const double along = axis == 0 ? ray[0].dx : (axis == 1 ? ray[0].dy : ray[0].dz);
-          const int down = __popcll(__ballot(along < 0.0)), up = __popcll(__ballot(along > 0.0));
-          jump = (step.a2 & 4) ? up > down : down > up;  // most rays run against the program: take the mirror image
-        }
-        if (jump) pc += step.a0;
+      if (step.a1 != BOX_TEST) {  // (programs of several rays per lane / render programs have no such frame)
+        pc += step.a1 == BOX_JUMP ? step.a0 : 0;
         continue;
       }
       bool wanted = false;

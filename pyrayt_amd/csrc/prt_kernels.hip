@@ -86,7 +86,9 @@ __device__ __forceinline__ int prim_of_surface(const DevPrim* __restrict__ prims
 // prt_propagate uses the same kernel with counts == nullptr and surf_out != nullptr.
 // STAGED (experiment, A/B partner of the scalar-load step fetch): the workgroup first copies the
 // program into LDS and the interpreter reads its steps from there.
-template <bool STAGED>
+// COUNT: the PRT_TRACE_COUNT_PATHS instantiation (the counters cost the kernel 40 VGPRs and a wave of
+// occupancy, so the kernel that serves prt_propagate and the ordinary three-kernel trace carries none)
+template <bool STAGED, bool COUNT = false>
 __global__ void __launch_bounds__(PRT_BLOCK)
 k_hit(SceneDev scene, const double* __restrict__ rays, int64_t ld, const TraceCtrl* __restrict__ ctrl,
       int64_t n_fixed, double* __restrict__ hit_t, int32_t* __restrict__ hit_prim,
@@ -107,7 +109,7 @@ k_hit(SceneDev scene, const double* __restrict__ rays, int64_t ld, const TraceCt
   bool live = false, carry = false;
   if (i < n) {
     Ray8 r = load_ray8(rays, ld, i);
-    r.paths = paths;  // PRT_TRACE_COUNT_PATHS (null otherwise)
+    r.paths = COUNT ? paths : nullptr;
     double t;
     int prim;
     nearest_hit(scene.prims, code, scene.n_instr, r, lists, t, prim);
@@ -1088,8 +1090,9 @@ k_material_trace(const DevPrim* __restrict__ prim, double* __restrict__ rays, in
 static int raise_lds_limits() {
   HIP_TRY(hipFuncSetAttribute((const void*)k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_render_hits, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
-  HIP_TRY(hipFuncSetAttribute((const void*)k_hit<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
-  HIP_TRY(hipFuncSetAttribute((const void*)k_hit<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_hit<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_hit<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_hit<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_hit_lanes<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_hit_lanes<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
   HIP_TRY(hipFuncSetAttribute((const void*)k_hit_lanes<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLdsBytes));
@@ -1157,7 +1160,7 @@ static int launch_hit(const prt_scene* s, const DeviceCopy* c, const SceneDev& s
   if (v.staged) lds = align_up(lds, 16) + (size_t)sd.n_instr * sizeof(DevInstr) + 8 * PRT_BLOCK;
   if (lds > kMaxLdsBytes) return fail(PRT_ERR_SCENE, "program too large to stage in LDS");
   if (v.lanes == 1) {
-    auto kernel = v.staged ? k_hit<true> : k_hit<false>;
+    auto kernel = v.staged ? k_hit<true, false> : (paths ? k_hit<false, true> : k_hit<false, false>);
     hipLaunchKernelGGL(kernel, dim3(blocks_for(n_bound)), dim3(PRT_BLOCK), lds, st, sd, rays, ld, ctrl, n_fixed,
                        hit_t, hit_prim, surf_out, tile_counts, keep_absorbed, paths);
   } else {
@@ -1427,7 +1430,7 @@ static int64_t trace_unfused(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_
   const int keep_absorbed = (t->flags & PRT_TRACE_KEEP_ABSORBED) ? 1 : 0;
   // PRT_TRACE_COUNT_PATHS: the nearest-hit kernel of this path counts (one ray per lane only: the k-lanes
   // kernels evaluate components per lane and would count a ray once per lane group member)
-  const bool count_paths = (t->flags & PRT_TRACE_COUNT_PATHS) != 0 && s->options.hit_lanes <= 1;
+  const bool count_paths = (t->flags & PRT_TRACE_COUNT_PATHS) != 0 && s->options.hit_lanes <= 1 && !s->options.hit_staged;
   if (t->user == 0) t->user = g_next_user.fetch_add(1);
   (void)workspace_taken_over(w, t->user);  // the block is ours now: a fused trace behind this one re-initialises
   t->ready_workspace = nullptr;

@@ -36,7 +36,7 @@ struct Program {
   std::vector<DevInstr> code;
   int lds_slots = 0;
   std::vector<int32_t> component_first;  // per component: first and one-past-last step slot (its own cull step included)
-  int forward_steps = 0;                 // trace programs: slots of the program proper (with its I_PICK / I_JUMP frame); behind it (if any) its mirror image
+  int mirror_steps = 0;                  // trace programs stored in both directions: slots of [PICK][mirror image][JUMP] in front of the program proper
 };
 
 // One trace in flight (prt_trace_begin ... prt_trace_end).  A scene has PRT_TRACE_TICKETS of them per
@@ -696,9 +696,9 @@ static void compile_trace_program(prt_scene* s) {
   // the centres of the first and the last top-level group lie furthest apart.  Any order gives the same
   // result: the running minimum of such programs is lexicographic on (t, list index), see `beats`.
   // In the program this is two more steps of the I_BOX kind (the interpreter's "jump if no lane wants what
-  // follows"):  [PICK -> mirror][program][JUMP -> end][mirror image].
+  // follows"), PICK and JUMP, see the layout below.
   int pick_axis = -1;
-  if (grouped && every_box && prims_follow_components && tree.kids.size() > 1) {
+  if (grouped && every_box && prims_follow_components && tree.kids.size() > 1 && !s->options.one_direction) {
     double first[6], last[6];
     if (union_box(boxes, tree.kids.front().comps, first) && union_box(boxes, tree.kids.back().comps, last)) {
       double axis[3];
@@ -712,21 +712,24 @@ static void compile_trace_program(prt_scene* s) {
   }
   if (pick_axis < 0) {
     emit_groups(s, boxes, tree, false);
-    prog.forward_steps = (int)prog.code.size();
     return;
   }
+  // layout: [PICK][mirror image][JUMP -> end][program proper]: a wave that runs along the axis jumps from
+  // PICK straight to the program proper and pays one extra step; one that runs against it falls into the
+  // mirror image and pays two
   DevInstr pick = Compiler::blank(I_BOX);
   pick.a1 = BOX_PICK;
-  pick.a2 = pick_axis;  // 0 / 1 / 2: the program runs along +x / +y / +z, 4 / 5 / 6: along -x / -y / -z
+  pick.a2 = pick_axis;  // 0 / 1 / 2: the program proper runs along +x / +y / +z, 4 / 5 / 6: along -x / -y / -z
   prog.code.push_back(pick);
-  emit_groups(s, boxes, tree, false);
+  emit_groups(s, boxes, tree, true);
   DevInstr jump = Compiler::blank(I_BOX);
   jump.a1 = BOX_JUMP;
   prog.code.push_back(jump);
-  prog.forward_steps = (int)prog.code.size();
-  prog.code[0].a0 = prog.forward_steps - 1;          // PICK: over the program and its JUMP, onto the mirror image
-  emit_groups(s, boxes, tree, true);
-  prog.code[prog.forward_steps - 1].a0 = (int)prog.code.size() - prog.forward_steps;  // JUMP: over the mirror image
+  const int mirror_steps = (int)prog.code.size();
+  prog.code[0].a0 = mirror_steps - 1;                // PICK: over the mirror image and its JUMP, onto the program proper
+  emit_groups(s, boxes, tree, false);
+  prog.code[mirror_steps - 1].a0 = (int)prog.code.size() - mirror_steps;  // JUMP: over the program proper
+  prog.mirror_steps = mirror_steps;
 }
 
 static int validate_tree(const prt_scene* s, int node, int depth, std::vector<char>& seen) {
@@ -811,7 +814,6 @@ extern "C" int prt_scene_create(const prt_prim* prims, int n_prims, const prt_no
   }
   compile_trace_program(s);
   s->has_cull_steps = count_steps(s->trace_program.code, I_BOX) > 0;
-  if (s->trace_program.forward_steps == 0) s->trace_program.forward_steps = (int)s->trace_program.code.size();
   for (int r : s->roots) {
     compile_component(s, r, s->render_program.code, ROOT_RENDER, &s->render_program.lds_slots);
     Program p;
@@ -867,7 +869,7 @@ extern "C" int prt_scene_update(prt_scene* s, const prt_prim* prims, int n_prims
   if (rc) return rc;
   auto same_program = [](const Program& a, const Program& b) {
     return a.code.size() == b.code.size() && a.lds_slots == b.lds_slots &&
-           a.component_first.size() == b.component_first.size() && a.forward_steps == b.forward_steps;
+           a.component_first.size() == b.component_first.size() && a.mirror_steps == b.mirror_steps;
   };
   bool same = t->dev_prims.size() == s->dev_prims.size() && same_program(t->trace_program, s->trace_program) &&
               same_program(t->render_program, s->render_program) &&
@@ -916,8 +918,8 @@ extern "C" int prt_scene_info(const prt_scene* s, int64_t* out10) {
   int64_t* out8 = out10;
   if (!s || !out10) return fail(PRT_ERR_ARG, "null argument");
   out10[8] = s->spatial_groups ? 1 : 0;
-  out10[9] = (int)s->trace_program.code.size() > s->trace_program.forward_steps ? 1 : 0;
-  const std::vector<DevInstr> forward(s->trace_program.code.begin(), s->trace_program.code.begin() + s->trace_program.forward_steps);
+  out10[9] = s->trace_program.mirror_steps > 0 ? 1 : 0;
+  const std::vector<DevInstr> forward(s->trace_program.code.begin() + s->trace_program.mirror_steps, s->trace_program.code.end());
   const int64_t culls = count_steps(forward, I_BOX);  // (a grouped program is followed by its mirror image: not counted)
   out8[0] = (int64_t)s->prims.size();
   out8[1] = (int64_t)s->roots.size();
