@@ -1185,24 +1185,18 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
         pc += CHAIN_SLOTS - 1;
         continue;
       }
-      // the frame of a program that is stored in both directions: decided on the step's first 16 bytes
-      // (kind, a0, a1, a2 -- the fetch that told a chain step apart), not on the whole record
-      if (CULL && kind == I_BOX && code[pc].a1 != BOX_TEST) {  // uniform
-        bool jump = true;
-        if (code[pc].a1 == BOX_PICK) {
-          const int axis = code[pc].a2 & 3;
-          const double along = axis == 0 ? ray[0].dx : (axis == 1 ? ray[0].dy : ray[0].dz);
-          const int down = __popcll(__ballot(along < 0.0)), up = __popcll(__ballot(along > 0.0));
-          jump = (code[pc].a2 & 4) ? down >= up : up >= down;  // most rays run along the program: skip the mirror image
-        }
-        if (jump) pc += shape;  // (a0)
-        continue;
-      }
     }
     const DevInstr step = code[pc];  // the whole record, one batch of scalar loads
     if (CULL && !RENDER && step.kind == I_BOX) {
-      if (step.a1 != BOX_TEST) {  // (programs of several rays per lane / render programs have no such frame)
-        pc += step.a1 == BOX_JUMP ? step.a0 : 0;
+      if (step.a1 != BOX_TEST) {  // (uniform) the frame of a program that is stored in both directions
+        bool jump = true;
+        if (step.a1 == BOX_PICK) {
+          const int axis = step.a2 & 3;
+          const double along = axis == 0 ? ray[0].dx : (axis == 1 ? ray[0].dy : ray[0].dz);
+          const int down = __popcll(__ballot(along < 0.0)), up = __popcll(__ballot(along > 0.0));
+          jump = (step.a2 & 4) ? down >= up : up >= down;  // most rays run along the program: skip the mirror image
+        }
+        if (jump) pc += step.a0;
         continue;
       }
       bool wanted = false;
