@@ -325,9 +325,11 @@ int prt_place_rows(int device, const double* staging, int64_t stride_rank, int64
  * examples compute from that frame (examples/lens_design.ipynb cells 11-16, 19-20, 38) is: keep
  * the rows of one surface and / or generation, group them by source (id // rays_per_source,
  * _pyrayt.py:349-354), and reduce spot positions (y1, z1) and axis intercepts
- * x0 - x_tilt * y0 / y_tilt per group.  One pass over the block; out is (n_groups, 8) float64 on
+ * x0 - x_tilt * y0 / y_tilt per group.  One pass over the block; out is (n_groups, 9) float64 on
  * the device: count, sum(y1 - py), sum(z1 - pz), sum((y1 - py)^2 + (z1 - pz)^2), sum(focus - pf),
- * sum((focus - pf)^2), sum(wavelength), sum(intensity), with pivots = DEVICE (n_groups, 3) float64, per
+ * sum((focus - pf)^2), sum(wavelength), sum(intensity), number of rows with a finite axis intercept (the
+ * two focus sums run over those: a ray parallel to the axis has none, and pandas' mean skips such a
+ * NaN), with pivots = DEVICE (n_groups, 3) float64, per
  * group the (py, pz, pf) its rows are measured from (a second pass about the first pass's means gives
  * well-conditioned second moments), or NULL for 0.
  * surface / generation: NaN selects every row; rays_per_source <= 0: a single group.
@@ -341,7 +343,8 @@ int prt_frame_reduce(int device, const double* rows, int64_t ld, int64_t n_rows,
 /* The statistics themselves in one stream-ordered call (two prt_frame_reduce passes, the second about
  * the first one's per-group means, computed on the device): out = (n_groups, 8) float64 on the device,
  * per group count, mean y1, mean z1, rms spot radius about that centroid, mean axis intercept, its
- * standard deviation, mean wavelength, mean intensity (NaN in 1..7 for a group without rows).
+ * standard deviation (both over the rows that have an intercept, NaN if none has), mean wavelength, mean
+ * intensity (NaN in 1..7 for a group without rows).
  * workspace: prt_frame_stats_workspace_bytes(n_groups) device bytes. */
 int64_t prt_frame_stats_workspace_bytes(int n_groups);
 int prt_frame_stats(int device, const double* rows, int64_t ld, int64_t n_rows, double surface,

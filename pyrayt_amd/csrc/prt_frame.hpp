@@ -9,12 +9,15 @@
 // all of it in one pass over the eleven columns involved: per group
 //     [0] count  [1] sum (y1 - py)  [2] sum (z1 - pz)  [3] sum ((y1 - py)^2 + (z1 - pz)^2)
 //     [4] sum (focus - pf)  [5] sum (focus - pf)^2  [6] sum wavelength  [7] sum intensity
+//     [8] number of rows with a finite axis intercept (a ray parallel to the axis -- y_tilt = 0, e.g. the
+//         axial ray of a cone -- has none: 0 / 0; sums 4 and 5 run over the others, like pandas' mean / std
+//         skip NaN, so they are divided by this count and not by [0])
 // accumulated in registers per wave, then added to the output with one atomic per touched entry.
 // The pivots (py, pz, pf) make the second moments well conditioned: the host wrapper runs the pass
 // twice, the second time about the first pass's means.
 #pragma once
 
-enum { FRAME_STATS = 8 };
+enum { FRAME_STATS = 9, FRAME_OUT = 8 };  // sums per group in a reduction pass / statistics per group of prt_frame_stats
 static const int kFrameRowsPerWave = 16 * 64;  // a wave's share of the block: 16 consecutive slices of 64 rows
                                                // (3M rows = 2 930 waves: three per SIMD)
 
@@ -44,7 +47,7 @@ k_frame_reduce(const double* __restrict__ rows, int64_t ld, int64_t n_rows, doub
   const int64_t wave = (int64_t)blockIdx.x * (PRT_BLOCK / 64) + (threadIdx.x >> 6);
   const int64_t first = wave * kFrameRowsPerWave;
   const int64_t last = first + kFrameRowsPerWave < n_rows ? first + kFrameRowsPerWave : n_rows;
-  double acc[FRAME_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double acc[FRAME_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   int current = -1;  // wave-uniform: the group the sums in `acc` belong to
   // waves spread their totals over `slots` copies of the output (k_frame_fold adds them up): with a
   // handful of groups every wave would otherwise queue up on the same eight words
@@ -60,7 +63,7 @@ k_frame_reduce(const double* __restrict__ rows, int64_t ld, int64_t n_rows, doub
         group = (g >= 0 && g < (double)n_groups) ? (int)g : -1;
       }
     }
-    double v[FRAME_STATS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double v[FRAME_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (group >= 0) {
       double pivot_y = 0.0, pivot_z = 0.0, pivot_focus = 0.0;
       if (pivots) { pivot_y = pivots[3 * group]; pivot_z = pivots[3 * group + 1]; pivot_focus = pivots[3 * group + 2]; }
@@ -72,6 +75,7 @@ k_frame_reduce(const double* __restrict__ rows, int64_t ld, int64_t n_rows, doub
       v[0] = 1.0; v[1] = y; v[2] = z; v[3] = y * y + z * z;
       v[4] = f_ok ? f : 0.0; v[5] = f_ok ? f * f : 0.0;
       v[6] = rows[PRT_COL_WAVELENGTH * ld + j]; v[7] = rows[PRT_COL_INTENSITY * ld + j];
+      v[8] = f_ok ? 1.0 : 0.0;
     }
     unsigned long long pending = __ballot(group >= 0);
     while (pending) {  // one turn per group present in the slice: almost always exactly one
@@ -102,7 +106,7 @@ k_frame_fold(const double* __restrict__ partial, int slots, int n, double* __res
   out[e] = v;
 }
 
-// out: (n_groups, 8) float64 on the device, overwritten.  surface / generation: NaN = every row.
+// out: (n_groups, 9) float64 on the device, overwritten.  surface / generation: NaN = every row.
 // rays_per_source <= 0: one group.  pivots: DEVICE (n_groups, 3) float64 -- per group the (y, z, focus)
 // subtracted before accumulating -- or null for zeros.
 static const int kFrameSlots = 64;           // copies of the output the waves spread their atomics over ...
@@ -143,17 +147,18 @@ extern "C" int prt_frame_reduce(int device, const double* rows, int64_t ld, int6
 // Two reduction passes without a trip to the host in between: the first pass's sums become per-group
 // pivots (means) on the device, the second pass accumulates about them, and a last small kernel turns
 // the sums into what the notebook looks at.  Per group: [0] count  [1] mean y1  [2] mean z1
-// [3] rms spot radius about that centroid  [4] mean axis intercept  [5] its standard deviation
-// [6] mean wavelength  [7] mean intensity; NaN in [1..7] for a group without rows.
+// [3] rms spot radius about that centroid  [4] mean axis intercept  [5] its standard deviation (both over
+// the rows that have one, as pandas would; NaN if none has)  [6] mean wavelength  [7] mean intensity;
+// NaN in [1..7] for a group without rows.
 __global__ void __launch_bounds__(PRT_BLOCK)
 k_frame_pivots(const double* __restrict__ sums, int n_groups, double* __restrict__ pivots) {
   const int g = blockIdx.x * PRT_BLOCK + threadIdx.x;
   if (g >= n_groups) return;
-  const double count = sums[g * FRAME_STATS];
+  const double count = sums[g * FRAME_STATS], with_focus = sums[g * FRAME_STATS + 8];
   const double safe = count > 0 ? count : 1.0;
   pivots[3 * g + 0] = sums[g * FRAME_STATS + 1] / safe;
   pivots[3 * g + 1] = sums[g * FRAME_STATS + 2] / safe;
-  pivots[3 * g + 2] = sums[g * FRAME_STATS + 4] / safe;
+  pivots[3 * g + 2] = sums[g * FRAME_STATS + 4] / (with_focus > 0 ? with_focus : 1.0);
 }
 
 __global__ void __launch_bounds__(PRT_BLOCK)
@@ -162,18 +167,18 @@ k_frame_finish(const double* __restrict__ sums, const double* __restrict__ pivot
   const int g = blockIdx.x * PRT_BLOCK + threadIdx.x;
   if (g >= n_groups) return;
   const double* s = sums + (size_t)g * FRAME_STATS;
-  const double count = s[0];
-  const double safe = count > 0 ? count : 1.0;
-  const double dy = s[1] / safe, dz = s[2] / safe, df = s[4] / safe;
-  const double var_r = fmax(s[3] / safe - dy * dy - dz * dz, 0.0), var_f = fmax(s[5] / safe - df * df, 0.0);
+  const double count = s[0], with_focus = s[8];  // (rows without an axis intercept are not in sums 4 and 5)
+  const double safe = count > 0 ? count : 1.0, safe_f = with_focus > 0 ? with_focus : 1.0;
+  const double dy = s[1] / safe, dz = s[2] / safe, df = s[4] / safe_f;
+  const double var_r = fmax(s[3] / safe - dy * dy - dz * dz, 0.0), var_f = fmax(s[5] / safe_f - df * df, 0.0);
   const double nan = __longlong_as_double(0x7ff8000000000000ll);
-  double* o = out + (size_t)g * FRAME_STATS;
+  double* o = out + (size_t)g * FRAME_OUT;
   o[0] = count;
   o[1] = count > 0 ? pivots[3 * g + 0] + dy : nan;
   o[2] = count > 0 ? pivots[3 * g + 1] + dz : nan;
   o[3] = count > 0 ? sqrt(var_r) : nan;
-  o[4] = count > 0 ? pivots[3 * g + 2] + df : nan;
-  o[5] = count > 0 ? sqrt(var_f) : nan;
+  o[4] = with_focus > 0 ? pivots[3 * g + 2] + df : nan;
+  o[5] = with_focus > 0 ? sqrt(var_f) : nan;
   o[6] = count > 0 ? s[6] / safe : nan;
   o[7] = count > 0 ? s[7] / safe : nan;
 }

@@ -198,12 +198,28 @@ static int place_rows(int device, const double* staging, int64_t stride_rank, in
   (void)device;
   if (t.total == 0) return PRT_OK;
   int64_t* tables = (int64_t*)workspace;
-  // the source of an asynchronous copy has to outlive the call: keep the last few tables per thread
-  static thread_local std::vector<int64_t> keep[8];
+  // The source of an asynchronous copy has to stay as it is until the copy has run: the tables go through
+  // a small ring of page-locked blocks per host thread, each guarded by an event recorded behind its copy
+  // (a block is only written again once that event has passed -- any number of calls may be in flight).
+  struct Staging {
+    int64_t* block = nullptr;
+    size_t words = 0;
+    hipEvent_t copied = nullptr;
+  };
+  static thread_local Staging ring[4];
   static thread_local unsigned turn = 0;
-  std::vector<int64_t>& source = keep[turn++ % 8];
-  source = t.host;
-  HIP_TRY(hipMemcpyAsync(tables, source.data(), source.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  Staging& stage = ring[turn++ % 4];
+  if (stage.copied) HIP_TRY(hipEventSynchronize(stage.copied));
+  if (stage.words < t.host.size()) {
+    if (stage.block) HIP_TRY(hipHostFree(stage.block));
+    stage.block = nullptr;
+    stage.words = std::max<size_t>(t.host.size(), 1024);
+    HIP_TRY(hipHostMalloc((void**)&stage.block, stage.words * sizeof(int64_t), hipHostMallocDefault));
+  }
+  if (!stage.copied) HIP_TRY(hipEventCreateWithFlags(&stage.copied, hipEventDisableTiming));
+  std::memcpy(stage.block, t.host.data(), t.host.size() * sizeof(int64_t));
+  HIP_TRY(hipMemcpyAsync(tables, stage.block, t.host.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(stage.copied, st));
   hipLaunchKernelGGL(k_place_rows, dim3(blocks_for(t.total)), dim3(PRT_BLOCK), 0, st, staging, stride_rank,
                      stride_col, world, t.n_seg, (const int64_t*)tables, (const int64_t*)(tables + t.n_seg + 1),
                      out, ld_out, t.total);

@@ -34,11 +34,11 @@ def _pandas_stats(frame, rays_per_source):
     out = {}
     for sid, rows in work.groupby("source_id"):
         cy, cz = rows["y1"].mean(), rows["z1"].mean()
-        f = rows["focus"].fillna(0.0)  # the kernel counts a ray without an intercept as focus 0 about the pivot
         out[sid] = dict(count=len(rows), y=cy, z=cz,
                         rms_radius=np.sqrt(((rows["y1"] - cy) ** 2 + (rows["z1"] - cz) ** 2).mean()),
                         wavelength=rows["wavelength"].mean(), intensity=rows["intensity"].mean(),
-                        focus=rows["focus"].mean(), n_focus=int(rows["focus"].notna().sum()))
+                        focus=rows["focus"].mean(), focus_std=rows["focus"].std(ddof=0),
+                        n_focus=int(rows["focus"].notna().sum()))
     return out
 
 
@@ -65,8 +65,12 @@ def test_group_stats_match_pandas_on_the_reference_frame(name, rays_per_source):
             for key in ("y", "z", "wavelength", "intensity"):
                 assert np.isclose(g[key], w[key], rtol=1e-12, atol=1e-12), (name, sid, key)
             assert np.isclose(g["rms_radius"], w["rms_radius"], rtol=1e-9, atol=1e-12), (name, sid)
-            if w["n_focus"] == w["count"] and np.isfinite(w["focus"]) and abs(w["focus"]) < 1e6:
+            # rays without an axis intercept (y_tilt = 0: 0 / 0) are skipped, as pandas skips NaN
+            if w["n_focus"] == 0:
+                assert np.isnan(g["focus"]) and np.isnan(g["focus_std"]), (name, sid)
+            elif abs(w["focus"]) < 1e6:
                 assert np.isclose(g["focus"], w["focus"], rtol=1e-9, atol=1e-9), (name, sid, "focus")
+                assert np.isclose(g["focus_std"], w["focus_std"], rtol=1e-6, atol=1e-9 * (1 + abs(w["focus"]))), (name, sid)
         empty = got.loc[got["count"] == 0]
         assert empty[["y", "z", "rms_radius"]].isna().all().all()
 

@@ -18,7 +18,7 @@ COLUMNS_READ = 11  # surface, generation, id, y1, z1, x0, y0, x_tilt, y_tilt, wa
 def run(name, parts, rays, rays_per_source, n_groups, surface):
     ds = engine.DeviceScene(SceneSnapshot(parts))
     rows, counts = ds.trace(torch.from_numpy(rays).cuda(), 10)
-    out = torch.empty((n_groups, 8), dtype=torch.float64, device="cuda")
+    out = torch.empty((n_groups, 9), dtype=torch.float64, device="cuda")  # nine sums per group
     st = engine._stream_ptr(torch, rows.device)
     nan = float("nan")
 
