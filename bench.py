@@ -77,6 +77,8 @@ def parse_args():
                     help="experiments only: the north-star workload uses 10")
     ap.add_argument("--cpu-rays", type=int, default=1_000_000,
                     help="rays of the same workload timed on the CPU oracle")
+    ap.add_argument("--options", default="",
+                    help="A/B runs only: prt_scene_options for the scene, e.g. no_tail=1,no_cull=1 (the bench line uses none)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="time synchronous traces (prt_trace) instead of keeping one trace in flight "
                          "(prt_trace_begin / prt_trace_end)")
@@ -211,7 +213,8 @@ def main():
         rays[12] += rank * n_job
     n = rays.shape[1]
     snap = SceneSnapshot(parts)
-    scene = engine.DeviceScene(snap)
+    scene_options = {k: int(v or 1) for k, _, v in (item.partition("=") for item in args.options.split(",") if item)}
+    scene = engine.DeviceScene(snap, options=scene_options)
     rays_dev = torch.from_numpy(rays).to(device)
 
     limit = args.generation_limit
@@ -442,6 +445,7 @@ def main():
             # secondary metric of SURVEY.md section 8d: rays alive at generation entry x primitives
             "primitive_tests_per_s": ray_generations * len(snap.prims) * world / elapsed,
             "trace_flags": args.flags,
+            "scene_options": scene_options,
             "spinup_steps_untimed": spinup_steps,
             "parallelism": f"ray data-parallel x{world} (contiguous id shards), no collective in the timed region",
         },
