@@ -1,8 +1,9 @@
 #!/bin/bash
 # One GPU-box pass that regenerates everything under profiles/<round>/ from the current build:
 #   bench line, rocprofv3 kernel-trace stats of the same command, HBM traffic (PMC, calibrated),
-#   SQ issue/stall counters of k_generation and k_hit, renderer kernel stats, and the other
-#   BASELINE configs at their per-GPU sizes (bench line + kernel stats each).
+#   SQ issue/stall counters of k_generation and k_hit, renderer kernel stats, the other BASELINE configs at
+#   their per-GPU sizes (bench line + kernel stats each), the per-rank shard table of the 1/2/4/8-GPU curve,
+#   the shortcut counters of the shipping library, the cull-step tables and the nearest-hit kernel A/B.
 # usage (through gpurun): bash tools/refresh_profiles.sh ; then copy gpurun_out/refresh/* into profiles/<round>/
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -12,16 +13,16 @@ cd $R
 (cd tools/ubench && make -s copy_f64 >/dev/null 2>&1)
 python3 bench.py > $out/bench.json 2> $out/bench.err
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace -- python3 $R/bench.py --no-cpu-baseline > $out/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace -- python3 $R/bench.py --no-cpu-baseline --side-steps 0 > $out/trace.log 2>&1
 for cfg in "config3 4000000" "config4 8000000" "config5 2000000"; do
   set -- $cfg
   python3 $R/bench.py --workload $1 --rays $2 --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_$1.json 2>> $out/bench.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace_$1 -- python3 $R/bench.py --workload $1 --rays $2 --steps 50 --warmup 5 --no-cpu-baseline > $out/trace_$1.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace_$1 -- python3 $R/bench.py --workload $1 --rays $2 --steps 50 --warmup 5 --no-cpu-baseline --side-steps 0 > $out/trace_$1.log 2>&1
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o render -- python3 $R/tools/render_bench.py --width 640 8192 --cpu-pixels 20000 > $out/render.log 2>&1
 cd $R
 bash tools/traffic.sh > $out/traffic.log 2>&1
-bash tools/sq.sh gen python3 $R/bench.py --steps 3 --warmup 1 --spinup-ms 0 --no-cpu-baseline > /dev/null 2>&1
+bash tools/sq.sh gen python3 $R/bench.py --steps 3 --warmup 1 --spinup-ms 0 --no-cpu-baseline --side-steps 0 --no-pipeline > /dev/null 2>&1
 bash tools/sq.sh hit python3 $R/tools/hit_only.py 6 > /dev/null 2>&1
 python3 tools/sq.py gpurun_out/sq gen > $out/sq_counters.txt
 python3 tools/sq.py gpurun_out/sq hit >> $out/sq_counters.txt
@@ -30,6 +31,12 @@ cp gpurun_out/traffic/bench_FETCH_SIZE_counter_collection.csv $out/k_generation_
 cp gpurun_out/traffic/bench_WRITE_SIZE_counter_collection.csv $out/k_generation_pmc_WRITE_SIZE.csv
 cp gpurun_out/traffic/cal_FETCH_SIZE_counter_collection.csv $out/calibration_pmc_FETCH_SIZE.csv
 cp gpurun_out/traffic/cal_WRITE_SIZE_counter_collection.csv $out/calibration_pmc_WRITE_SIZE.csv
+python3 tools/shard_scaling.py > $out/shard_scaling.txt 2>&1
+python3 tools/slow_paths.py 2>&1 | grep -v amdgpu.ids > $out/slow_paths.txt
+{ echo "# tools/cull_scaling.py (lens train listed along the axis)"; python3 tools/cull_scaling.py --counts 1 2 4 8 16 32 2>&1 | grep -v amdgpu.ids;
+  echo; echo "# tools/cull_scaling.py --shuffle (lenses listed in random order, beams from both ends)"; python3 tools/cull_scaling.py --shuffle --counts 8 32 2>&1 | grep -v amdgpu.ids; } > $out/cull_scaling.txt
+python3 tools/hit_ab.py 2>&1 | grep -v amdgpu.ids > $out/hit_variants.txt
+{ python3 tools/aux_bench.py; python3 tools/frame_bench.py; } 2>&1 | grep -v amdgpu.ids > $out/aux_kernels.txt
 # keep the summaries, drop the bulky per-dispatch traces
 rm -f $out/*_kernel_trace.csv $out/*_agent_info.csv $out/*domain_stats.csv
 ls -la $out | head -60
