@@ -82,6 +82,8 @@ def parse_args():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="time synchronous traces (prt_trace) instead of keeping one trace in flight "
                          "(prt_trace_begin / prt_trace_end)")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="pipelined mode: 2 = the two tickets on two HIP streams (their kernels overlap on the device)")
     ap.add_argument("--side-steps", type=int, default=40,
                     help="steps of each untimed side measurement (synchronous / no hints / changing ray count)")
     return ap.parse_args()
@@ -229,6 +231,9 @@ def main():
     def step(flags=args.flags, rays_in=None):
         return scene.trace(rays_dev if rays_in is None else rays_in, limit, flags=flags, out=block)
 
+    streams = [torch.cuda.Stream(device) for _ in range(2)] if (pipelined and args.streams == 2) else None
+    torch.cuda.synchronize(device)
+
     class Totals:
         def __init__(self):
             self.kernel_ms = self.launches = self.ray_generations = self.rows_recorded = self.rays_carried = 0.0
@@ -252,10 +257,17 @@ def main():
                 if totals is not None:
                     totals.add()
             return rows, counts
-        scene.trace_begin(0, rays_dev, limit, blocks[0], flags=flags)
+        def begin(k):
+            if streams is None:
+                scene.trace_begin(k & 1, rays_dev, limit, blocks[k & 1], flags=flags)
+            else:
+                with torch.cuda.stream(streams[k & 1]):
+                    scene.trace_begin(k & 1, rays_dev, limit, blocks[k & 1], flags=flags)
+
+        begin(0)
         for k in range(count):
             if k + 1 < count:
-                scene.trace_begin((k + 1) & 1, rays_dev, limit, blocks[(k + 1) & 1], flags=flags)
+                begin(k + 1)
             rows, counts = scene.trace_end(k & 1)
             if totals is not None:
                 totals.add()
@@ -436,6 +448,7 @@ def main():
                          "(prt_trace_begin / prt_trace_end)" if pipelined else ", synchronous (prt_trace)") +
                         "; see value_synchronous / value_no_hints / value_changing_ray_count for the other kinds of step",
             "pipelined": pipelined,
+            "streams": args.streams if pipelined else 1,
             "rays_job": n_job * (1 if strong else world),
             "rays_per_gpu": n,
             "devices_visible_per_rank_process": n_devices,

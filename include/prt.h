@@ -282,9 +282,10 @@ int64_t prt_trace(prt_scene* scene, int device, const double* rays, int64_t n, i
  * their counts, enqueues whatever the trace still needs (more generations; a repeat when a hint did
  * not hold) and returns what prt_trace returns.  prt_trace is begin + end on ticket 0.
  * A scene has PRT_TRACE_TICKETS tickets per device: traces of different tickets may be in flight
- * together (they execute in stream order).  Every ticket in flight needs its own workspace and its own
- * record block, and all of them the same stream; rays, rows_out and the workspace must stay valid
- * until prt_trace_end.  Results are those of prt_trace, bit for bit. */
+ * together.  Every ticket in flight needs its own workspace and its own record block; on one stream they
+ * execute one after the other, on two streams their kernels overlap on the device (the workgroups of a
+ * generation leave the chip partly idle while they start up and drain).  rays, rows_out and the
+ * workspace must stay valid until prt_trace_end.  Results are those of prt_trace, bit for bit. */
 #define PRT_TRACE_TICKETS 2
 int prt_trace_begin(prt_scene* scene, int device, int ticket, const double* rays, int64_t n, int64_t ld,
                     int generation_limit, double ray_offset, double* rows_out, int64_t rows_cap,

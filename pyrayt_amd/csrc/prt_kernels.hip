@@ -1719,8 +1719,8 @@ extern "C" int prt_trace_begin(prt_scene* s, int device, int ticket, const doubl
   if (n >= (1ll << 31)) return fail(PRT_ERR_ARG, "at most 2^31-1 rays per call");
   for (int k = 0; k < PRT_TRACE_TICKETS; ++k)
     if (k != ticket && c->ticket[k].active && n && c->ticket[k].n &&
-        (c->ticket[k].w == (char*)workspace || c->ticket[k].rows_out == rows_out || c->ticket[k].st != (hipStream_t)stream))
-      return fail(PRT_ERR_ARG, "traces in flight together need their own workspace and record block, and one stream");
+        (c->ticket[k].w == (char*)workspace || c->ticket[k].rows_out == rows_out))
+      return fail(PRT_ERR_ARG, "traces in flight together need their own workspace and record block");
   rc = settle_timing(t);  // events of the ticket's previous trace, before they are recorded again
   if (rc) return rc;
   t->rays = rays; t->n = n; t->ld = ld; t->limit = generation_limit; t->ray_offset = ray_offset;

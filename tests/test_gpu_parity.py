@@ -977,3 +977,34 @@ def test_path_counters_tell_well_formed_rays_from_the_others():
     ds.trace(dev(odd), limit)
     assert ds.telemetry()["rays_not_well_formed"] == tele2["rays_not_well_formed"]
     ds.close()
+
+
+def test_traces_in_flight_on_two_streams_equal_synchronous_traces():
+    """The two tickets on two HIP streams: their kernels overlap on the device, the frames do not change."""
+    fx = helpers.load("scene_config3.npz")
+    limit = int(fx["generation_limit"])
+    ds = device_scene(helpers.scene_of(fx))
+    rays = dev(fx["rays0"])
+    n = rays.shape[1]
+    want, want_counts = ds.trace(rays, limit)
+    want = want.cpu().numpy().copy()
+    blocks = [torch.full((15, n * limit), float("nan"), dtype=torch.float64, device="cuda:0") for _ in range(2)]
+    streams = [torch.cuda.Stream("cuda:0") for _ in range(2)]
+    torch.cuda.synchronize()
+
+    def begin(k):
+        with torch.cuda.stream(streams[k & 1]):
+            ds.trace_begin(k & 1, rays, limit, blocks[k & 1])
+
+    steps = 9
+    begin(0)
+    for k in range(steps):
+        if k + 1 < steps:
+            begin(k + 1)
+        rows, counts = ds.trace_end(k & 1)
+        assert counts == want_counts, (k, counts)
+        streams[k & 1].synchronize()
+        assert np.array_equal(rows.cpu().numpy(), want, equal_nan=True), k
+        with torch.cuda.stream(streams[k & 1]):
+            blocks[k & 1].fill_(float("nan"))
+    ds.close()
