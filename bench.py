@@ -22,6 +22,12 @@ instead (secondary figure).  The re-assembly of the result frame (RCCL all-gathe
 kernel inside the library, pyrayt_amd/csrc/prt_gather.hpp) is timed separately after the timed
 region and reported under "gather" and "value_with_gather" -- it is not part of `value`.
 
+The timed steps are issued with 2-3 traces in flight, each ticket of the library on its own HIP stream
+(prt_trace_begin / prt_trace_end): the host enqueues ahead and the kernels of different traces overlap on
+the device.  `value` is that throughput.  The kernel's own launch duration -- what `roofline` prices --
+is measured on one stream, same steps, right behind the timed region (`roofline.measured_on`);
+`roofline.device_aggregate` says what the whole device sustains while the traces overlap.
+
 rank 0 prints ONE JSON line.  `roofline` is for the generation kernel(s): algorithmic bytes
 (328 B per ray alive at generation entry that is recorded and goes on) over the
 HIP-event time of those launches measured inside the library on the launch stream; the bytes the
@@ -82,8 +88,9 @@ def parse_args():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="time synchronous traces (prt_trace) instead of keeping one trace in flight "
                          "(prt_trace_begin / prt_trace_end)")
-    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
-                    help="pipelined mode: 2 = the two tickets on two HIP streams (their kernels overlap on the device)")
+    ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="traces in flight, each on its own HIP stream (their kernels overlap on the device); "
+                         "1 = one stream with one trace ahead; 0 (default) = 2 for 750k rays per GPU and more, else 3")
     ap.add_argument("--side-steps", type=int, default=40,
                     help="steps of each untimed side measurement (synchronous / no hints / changing ray count)")
     return ap.parse_args()
@@ -221,17 +228,26 @@ def main():
 
     limit = args.generation_limit
     pipelined = not args.no_pipeline
-    # record blocks handed back to every step (what a design loop does once it has consumed the
-    # previous frame); n * limit columns always suffice.  Pipelined: the step in flight and the step
-    # being collected record into different blocks (prt_trace_begin / prt_trace_end, two tickets).
+    # How the timed steps are issued.  "overlap": prt_trace_begin / prt_trace_end with `depth` traces in
+    # flight, each ticket on its own HIP stream -- the host enqueues ahead AND the kernels of different
+    # traces overlap on the device (a generation's workgroups leave the chip partly idle while they start
+    # up and drain; another trace's kernels fill that).  "one_stream": the same with two tickets on one
+    # stream (host hidden, kernels strictly one after the other).  "sync": prt_trace, one call at a time.
+    # Measured on config 2 (profiles/r3/streams.txt): 1M rays 0.179 -> 0.151 ms per step with two streams
+    # (three: 0.155), 125k rays 0.050 -> 0.040 -> 0.034 with two / three.
+    streams_wanted = args.streams if args.streams else (2 if n >= 750_000 else 3)
+    mode = "sync" if not pipelined else ("overlap" if streams_wanted >= 2 else "one_stream")
+    depth = streams_wanted if mode == "overlap" else 2  # traces in flight, the one being collected included
+    # record blocks handed back to every step (what a design loop does once it has consumed the previous
+    # frame); n * limit columns always suffice; every ticket in flight records into its own block
     blocks = [torch.empty((engine.RECORD_COLS, max(n, 1) * limit), dtype=torch.float64, device=device)
-              for _ in range(2 if pipelined else 1)]
+              for _ in range(max(depth, 2))]
     block = blocks[0]
 
     def step(flags=args.flags, rays_in=None):
         return scene.trace(rays_dev if rays_in is None else rays_in, limit, flags=flags, out=block)
 
-    streams = [torch.cuda.Stream(device) for _ in range(2)] if (pipelined and args.streams == 2) else None
+    streams = [torch.cuda.Stream(device) for _ in range(depth)] if mode == "overlap" else None
     torch.cuda.synchronize(device)
 
     class Totals:
@@ -246,38 +262,43 @@ def main():
             self.rows_recorded += st["rows"]
             self.rays_carried += st["rays_carried"]
 
-    def run_steps(count, totals=None, flags=args.flags):
-        """`count` traces back to back; returns (rows, counts) of the last one.  Pipelined: trace k + 1 is
-        enqueued before the counts of trace k are collected, so the host's share of a step (launch
-        calls, the wait for the counts, Python) overlaps with the GPU's work on the next trace."""
+    def run_steps(count, totals=None, flags=args.flags, how=None):
+        """`count` traces back to back, issued as `how` says (default: the bench's mode); returns (rows,
+        counts) of the last one."""
+        how = how or mode
         rows = counts = None
-        if not pipelined:
+        if how == "sync":
             for _ in range(count):
                 rows, counts = step(flags)
                 if totals is not None:
                     totals.add()
             return rows, counts
-        def begin(k):
-            if streams is None:
-                scene.trace_begin(k & 1, rays_dev, limit, blocks[k & 1], flags=flags)
-            else:
-                with torch.cuda.stream(streams[k & 1]):
-                    scene.trace_begin(k & 1, rays_dev, limit, blocks[k & 1], flags=flags)
+        lanes = depth if how == "overlap" else 2
 
-        begin(0)
+        def begin(k):
+            if how == "overlap":
+                with torch.cuda.stream(streams[k % lanes]):
+                    scene.trace_begin(k % lanes, rays_dev, limit, blocks[k % lanes], flags=flags)
+            else:
+                scene.trace_begin(k % lanes, rays_dev, limit, blocks[k % lanes], flags=flags)
+
+        for k in range(min(lanes - 1, count)):
+            begin(k)
         for k in range(count):
-            if k + 1 < count:
-                begin(k + 1)
-            rows, counts = scene.trace_end(k & 1)
+            if k + lanes - 1 < count:
+                begin(k + lanes - 1)
+            rows, counts = scene.trace_end(k % lanes)
             if totals is not None:
                 totals.add()
+        if how == "overlap":
+            torch.cuda.synchronize(device)  # (the caller reads `rows` on the current stream)
         return rows, counts
 
     spinup_steps = 0
     t_spin = time.perf_counter()
     while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
-        run_steps(2)
-        spinup_steps += 2
+        run_steps(4)
+        spinup_steps += 4
     rows, counts = run_steps(max(args.warmup, 1)) if args.warmup else step()
     torch.cuda.synchronize(device)
     if distributed:
@@ -291,8 +312,25 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches, ray_generations = timed.kernel_ms, timed.launches, timed.ray_generations
-    rows_recorded, rays_carried = timed.rows_recorded, timed.rays_carried
+    ray_generations, rows_recorded, rays_carried = timed.ray_generations, timed.rows_recorded, timed.rays_carried
+    launches = timed.launches
+    # The generation kernel's own duration -- what the roofline prices -- is measured on ONE stream: with
+    # traces overlapping on the device the HIP events around a trace's launches also see the other trace's
+    # kernels (each launch looks ~1.6x longer while two run side by side).  Same steps, same process, right
+    # behind the timed region; `value` stays the overlapped throughput.
+    kernel_region = timed
+    one_stream = None
+    if mode == "overlap":
+        run_steps(3, how="one_stream")
+        torch.cuda.synchronize(device)
+        kernel_region = Totals()
+        k0 = time.perf_counter()
+        run_steps(args.steps, kernel_region, how="one_stream")
+        torch.cuda.synchronize(device)
+        one_stream = {"ms_per_step": (time.perf_counter() - k0) / args.steps * 1e3,
+                      "kernel_ms_per_step": kernel_region.kernel_ms / args.steps}
+        run_steps(2)
+    kernel_ms, kernel_launches = kernel_region.kernel_ms, kernel_region.launches
 
     # side measurements (untimed region, every rank so that the ranks stay in step): the same step
     # (a) synchronous: one trace at a time through prt_trace, host and GPU strictly alternating;
@@ -330,7 +368,8 @@ def main():
                 totals.add()
 
     side_sync = side("synchronous", sync_steps, args.side_steps)
-    side_no_hints = side("no hints", lambda c, t=None: run_steps(c, t, flags=args.flags | engine.TRACE_NO_HINTS),
+    side_no_hints = side("no hints", lambda c, t=None: run_steps(c, t, flags=args.flags | engine.TRACE_NO_HINTS,
+                                                                  how="sync" if mode == "sync" else "one_stream"),
                          args.side_steps)
     side_resized = side("changing ray count", resized_steps, args.side_steps)
     rows, counts = run_steps(2)  # (leave the scene with the hints of the north-star trace for what follows)
@@ -444,11 +483,15 @@ def main():
                          else f": {n_job} rays per GPU (weak scaling)") +
                         f", generation_limit {limit}, rays resident in HBM; the timed step is a REPEATED "
                         "IDENTICAL trace: dense-mode hints of the previous trace active, first batch sized by it" +
-                        (", one trace kept in flight while the previous one's counts are collected "
-                         "(prt_trace_begin / prt_trace_end)" if pipelined else ", synchronous (prt_trace)") +
-                        "; see value_synchronous / value_no_hints / value_changing_ray_count for the other kinds of step",
-            "pipelined": pipelined,
-            "streams": args.streams if pipelined else 1,
+                        {"overlap": f", {depth} traces in flight on {depth} HIP streams (prt_trace_begin / prt_trace_end): the "
+                                    "host enqueues ahead and the kernels of different traces overlap on the device",
+                         "one_stream": ", one trace kept in flight on the same stream while the previous one's counts are "
+                                       "collected (prt_trace_begin / prt_trace_end)",
+                         "sync": ", synchronous (prt_trace)"}[mode] +
+                        "; see value_one_stream / value_synchronous / value_no_hints / value_first_trace for the other kinds of step",
+            "issue_mode": mode,
+            "traces_in_flight": depth if mode != "sync" else 1,
+            "streams": depth if mode == "overlap" else 1,
             "rays_job": n_job * (1 if strong else world),
             "rays_per_gpu": n,
             "devices_visible_per_rank_process": n_devices,
@@ -473,12 +516,22 @@ def main():
             "traffic_source": os.path.relpath(traffic_file, ROOT) + " (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, "
                               "calibrated; same command, separate passes)" if traffic else None,
             "kernel": "k_generation" if not (args.flags & 2) else "k_hit + k_scan + k_shade + k_advance",
+            "measured_on": ("one stream, the same steps right behind the timed region (HIP events per trace; with "
+                            "traces overlapping on the device an event pair also sees the other trace's kernels)"
+                            if mode == "overlap" else "the timed region (HIP events per trace on the launch stream)"),
             "algorithmic_bytes_per_launch": algorithmic_bytes / launches if launches else 0,
-            "avg_launch_ms": kernel_ms / launches if launches else 0,
+            "avg_launch_ms": kernel_ms / kernel_launches if kernel_launches else 0,
             "launches_per_step": launches / args.steps,
             "kernel_ms_per_step": kernel_ms / args.steps,
+            # what the device as a whole sustains in the timed region (all traces in flight together):
+            # algorithmic bytes of a step over the step time
+            "device_aggregate": {"achieved": algorithmic_bytes / elapsed / 1e9 if elapsed > 0 else 0.0,
+                                 "frac": algorithmic_bytes / elapsed / 1e9 / HBM_PEAK_GBS if elapsed > 0 else 0.0,
+                                 "frac_of_measured_copy": algorithmic_bytes / elapsed / 1e9 / COPY_GBS if elapsed > 0 else 0.0,
+                                 "unit": "GB/s", "what": "algorithmic bytes of the timed steps / their wall time (this GPU)"},
             "bytes_per_ray_generation_if_all_survive": BYTES_PER_RAY_GENERATION,
             "moved_bytes_per_launch": moved_bytes / launches if launches else 0,
+            "one_stream_region": one_stream,
             "moved_frac": moved_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms > 0 else 0.0,
             "state_rows": "all 13" if full_rows else "10 of 13 between generations (w rows and generation row implied)",
         },
@@ -495,8 +548,10 @@ def main():
         return kind
 
     side_sync, side_no_hints, side_resized = publish(side_sync), publish(side_no_hints), publish(side_resized)
+    if one_stream:
+        line["value_one_stream"] = rows_per_step * world / (one_stream["ms_per_step"] * 1e-3)
     if side_sync:
-        line["value_synchronous"] = side_sync["rows_per_s_this_gpu"] * (world if strong else world)
+        line["value_synchronous"] = side_sync["rows_per_s_this_gpu"] * world
         line["synchronous"] = side_sync
     if side_no_hints:
         line["value_no_hints"] = side_no_hints["rows_per_s_this_gpu"] * world

@@ -286,7 +286,7 @@ int64_t prt_trace(prt_scene* scene, int device, const double* rays, int64_t n, i
  * execute one after the other, on two streams their kernels overlap on the device (the workgroups of a
  * generation leave the chip partly idle while they start up and drain).  rays, rows_out and the
  * workspace must stay valid until prt_trace_end.  Results are those of prt_trace, bit for bit. */
-#define PRT_TRACE_TICKETS 2
+#define PRT_TRACE_TICKETS 4
 int prt_trace_begin(prt_scene* scene, int device, int ticket, const double* rays, int64_t n, int64_t ld,
                     int generation_limit, double ray_offset, double* rows_out, int64_t rows_cap,
                     void* workspace, int flags, void* stream);

@@ -26,7 +26,7 @@ TRACE_PUBLISH_KERNEL = 16
 TRACE_TEST_STALL = 32
 TRACE_SYNC = 64
 TRACE_COUNT_PATHS = 128
-TRACE_TICKETS = 2
+TRACE_TICKETS = 4
 
 # prt_scene_options (include/prt.h): how a scene is compiled / which nearest-hit kernel serves
 # prt_propagate.  Zeros are the defaults; the rest are A/B and test knobs.  DEFAULT_OPTIONS and
