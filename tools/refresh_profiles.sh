@@ -14,10 +14,12 @@ cd $R
 python3 bench.py > $out/bench.json 2> $out/bench.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace -- python3 $R/bench.py --no-cpu-baseline --side-steps 0 > $out/trace.log 2>&1
+# the same steps on ONE stream: the generation kernel's own duration (what roofline.avg_launch_ms is measured on)
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace_one_stream -- python3 $R/bench.py --no-cpu-baseline --side-steps 0 --streams 1 > $out/trace_one_stream.log 2>&1
 for cfg in "config3 4000000" "config4 8000000" "config5 2000000"; do
   set -- $cfg
   python3 $R/bench.py --workload $1 --rays $2 --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_$1.json 2>> $out/bench.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace_$1 -- python3 $R/bench.py --workload $1 --rays $2 --steps 50 --warmup 5 --no-cpu-baseline --side-steps 0 > $out/trace_$1.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace_$1 -- python3 $R/bench.py --workload $1 --rays $2 --steps 50 --warmup 5 --no-cpu-baseline --side-steps 0 --streams 1 > $out/trace_$1.log 2>&1
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o render -- python3 $R/tools/render_bench.py --width 640 8192 --cpu-pixels 20000 > $out/render.log 2>&1
 cd $R
