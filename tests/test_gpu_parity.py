@@ -1008,3 +1008,28 @@ def test_traces_in_flight_on_two_streams_equal_synchronous_traces():
         with torch.cuda.stream(streams[k & 1]):
             blocks[k & 1].fill_(float("nan"))
     ds.close()
+
+
+def test_trace_many_overlaps_traces_and_keeps_their_frames():
+    """DeviceScene.trace_many: a sequence of ray sets, two or three traces in flight on as many streams."""
+    fx = helpers.load("scene_config2.npz")
+    limit = int(fx["generation_limit"])
+    ds = device_scene(helpers.scene_of(fx))
+    base = fx["rays0"]
+    sets, want = [], []
+    for k in range(7):                          # ray sets that differ (and differ in how their rays die)
+        rays = base.copy()
+        rays[5, k::5] += 0.02 * k
+        rays[4:7] /= np.linalg.norm(rays[4:7], axis=0)
+        sets.append(dev(rays))
+        rows, counts = ds.trace(sets[-1], limit)
+        want.append((rows.cpu().numpy().copy(), counts))
+    for depth in (1, 2, 3):
+        got = []
+        for rows, counts in ds.trace_many(iter(sets), limit, depth=depth):
+            got.append((rows.cpu().numpy().copy(), counts))  # (copied before the block is reused)
+        assert len(got) == len(want)
+        for k, ((rows, counts), (ref_rows, ref_counts)) in enumerate(zip(got, want)):
+            assert counts == ref_counts, (depth, k)
+            assert np.array_equal(rows, ref_rows, equal_nan=True), (depth, k)
+    ds.close()
