@@ -90,7 +90,8 @@ def parse_args():
                          "(prt_trace_begin / prt_trace_end)")
     ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="traces in flight, each on its own HIP stream (their kernels overlap on the device); "
-                         "1 = one stream with one trace ahead; 0 (default) = 2 for 750k rays per GPU and more, else 3")
+                         "1 = one stream with one trace ahead; 0 (default) = config 2: 2 for 750k rays per GPU and "
+                         "more, else 3; the other workloads: 1")
     ap.add_argument("--side-steps", type=int, default=40,
                     help="steps of each untimed side measurement (synchronous / no hints / changing ray count)")
     return ap.parse_args()
@@ -235,7 +236,9 @@ def main():
     # stream (host hidden, kernels strictly one after the other).  "sync": prt_trace, one call at a time.
     # Measured on config 2 (profiles/r3/streams.txt): 1M rays 0.179 -> 0.151 ms per step with two streams
     # (three: 0.155), 125k rays 0.050 -> 0.040 -> 0.034 with two / three.
-    streams_wanted = args.streams if args.streams else (2 if n >= 750_000 else 3)
+    # The other BASELINE scenes (informational runs) stay on one stream: their launches are closer to the HBM
+    # roof by themselves and lose 3-4 % when a second trace competes for the Infinity Cache (config 3: +1 %).
+    streams_wanted = args.streams if args.streams else ((2 if n >= 750_000 else 3) if args.workload == "config2" else 1)
     mode = "sync" if not pipelined else ("overlap" if streams_wanted >= 2 else "one_stream")
     depth = streams_wanted if mode == "overlap" else 2  # traces in flight, the one being collected included
     # record blocks handed back to every step (what a design loop does once it has consumed the previous
