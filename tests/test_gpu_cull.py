@@ -154,7 +154,9 @@ def test_shuffled_lens_train_groups_by_position(api):
     order = np.random.default_rng(11).permutation(32)
     parts = [c.biconvex_lens(4, 4, 0.25, aperture=1).move_x(1.0 * k) for k in order]
     parts.insert(7, c.baffle((2, 2)).move_x(33.0))
-    assert DeviceScene(SceneSnapshot(parts)).info()["spatial_groups"] == 1
+    from pyrayt_amd import engine
+    if not engine.DEFAULT_OPTIONS:  # (tools/run_matrix.sh runs the suite under other scene options)
+        assert DeviceScene(SceneSnapshot(parts)).info()["spatial_groups"] == 1
     rays = np.hstack((scenes.cone_rays(5000, (-3.0, 0.0, 0.0), 3.0, 41),
                       scenes.cone_rays(3000, (12.5, 0.0, 0.0), 30.0, 42),
                       scenes.random_rays(4288, 43, box=20.0, degenerate=True)))
@@ -187,7 +189,9 @@ def test_ties_between_components_resolve_in_list_order_whatever_the_program_orde
     plates = [c.baffle((3, 3)).move_x(9.0), c.baffle((3, 3)).move_x(9.0)]   # the same plane twice
     order = rng.permutation(len(twins))
     parts = parts[:3] + [plates[1]] + parts[3:] + [twins[k] for k in order] + [plates[0]]
-    assert DeviceScene(SceneSnapshot(parts)).info()["spatial_groups"] == 1
+    from pyrayt_amd import engine
+    if not engine.DEFAULT_OPTIONS:
+        assert DeviceScene(SceneSnapshot(parts)).info()["spatial_groups"] == 1
     rays = scenes.random_rays(16384, 77, box=7.0, degenerate=True)
     aim = np.array([spots[k % len(spots)] + (0.0,) for k in range(4000)]).T + rng.normal(0, 0.3, (3, 4000))
     rays[4:7, 200:4200] = aim - rays[0:3, 200:4200]

@@ -941,6 +941,8 @@ def test_a_missed_hint_with_an_exact_fit_record_block_is_repeated_not_reported()
 # PRT_TRACE_COUNT_PATHS: the shipping library says how often its shortcuts fall through
 # ---------------------------------------------------------------------------------------------
 def test_path_counters_tell_well_formed_rays_from_the_others():
+    if engine.DEFAULT_OPTIONS:
+        pytest.skip("the expected counts are those of the default scene options")
     from pyrayt_amd.engine import DeviceScene
     from pyrayt_amd.g3d.objects import CountedObject
     from pyrayt_amd.scene import SceneSnapshot
