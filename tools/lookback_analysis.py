@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Who makes the look-back wait?  From a PRT_TIMING build's stamps of generation 0: for every tile the
+"""Who makes the look-back wait?  From a PRT_TIMING build's stamps of generation 0 (dumped by tools/wave_stamps.py): for every tile the
 time its aggregate was published (stamp 3, wave 0), when it finished shading (stamp 5) and when its
 look-back + barrier ended (stamp 6); a tile can finish its look-back only after every predecessor
 has published."""
