@@ -1035,3 +1035,39 @@ def test_trace_many_overlaps_traces_and_keeps_their_frames():
             assert counts == ref_counts, (depth, k)
             assert np.array_equal(rows, ref_rows, equal_nan=True), (depth, k)
     ds.close()
+
+
+def test_ticket_edges_update_in_flight_bad_ticket_varying_sizes():
+    from pyrayt_amd.engine import DeviceScene
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    CountedObject.reset_ids()
+    api = scenes.product_api()
+    parts, rays = scenes.config2(api, 30_000)
+    snap = SceneSnapshot(parts)
+    flat = helpers.flat_scene(snap)
+    ds = DeviceScene(snap)
+    limit = 10
+    block = torch.empty((15, 30_000 * limit), dtype=torch.float64, device="cuda:0")
+    with pytest.raises(ValueError, match="ticket out of range"):
+        ds.trace_begin(engine.TRACE_TICKETS, dev(rays), limit, block)
+    ds.trace_begin(2, dev(rays), limit, block)
+    parts[1].move_x(0.01)                                   # a part moves while a trace is in flight:
+    with pytest.raises(ValueError, match="in flight"):     # the tables that trace reads are not overwritten
+        ds.update(SceneSnapshot(parts))
+    rows, counts = ds.trace_end(2)
+    want, want_counts = orc.trace(flat, rays, limit)
+    assert counts == want_counts
+    helpers.assert_frames_match(rows.cpu().numpy().T, want, what="ticket 2")
+    moved = SceneSnapshot(parts)
+    assert ds.update(moved)                                 # ... and afterwards they are
+    # ray sets of different sizes through all four tickets
+    sets = [np.ascontiguousarray(rays[:, : 30_000 - 3_001 * k]) for k in range(6)]
+    flat2 = helpers.flat_scene(moved)
+    got = [(r.cpu().numpy().copy(), c) for r, c in ds.trace_many((dev(s) for s in sets), limit, depth=4)]
+    for k, (rows_k, counts_k) in enumerate(got):
+        want_k, want_counts_k = orc.trace(flat2, sets[k], limit)
+        assert counts_k == want_counts_k, k
+        helpers.assert_frames_match(rows_k.T, want_k, what=f"trace_many set {k}")
+    ds.close()
