@@ -333,6 +333,8 @@ class DeviceScene:
         assert out.is_cuda and out.dtype == torch.float64 and out.dim() == 2 and out.device == rays.device
         assert out.shape[0] == RECORD_COLS and out.is_contiguous()
         n, dev, limit = rays.shape[1], rays.device, int(generation_limit)
+        if not 0 <= int(ticket) < TRACE_TICKETS:
+            raise ValueError(f"ticket out of range (0..{TRACE_TICKETS - 1})")
         works = getattr(self, "_ticket_work", None)
         if works is None:
             works = self._ticket_work = [None] * TRACE_TICKETS
