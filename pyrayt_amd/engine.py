@@ -324,7 +324,7 @@ class DeviceScene:
 
     # --- the hot loop in two halves: enqueue now, collect the counts later -----------------------------
     def trace_begin(self, ticket, rays, generation_limit, out, ray_offset=DEFAULT_RAY_OFFSET, flags=0):
-        """Enqueue a trace on ticket 0 or 1 and return at once (``prt_trace_begin``).  `out`: the (15, cap)
+        """Enqueue a trace on one of the TRACE_TICKETS tickets and return at once (``prt_trace_begin``).  `out`: the (15, cap)
         CUDA float64 record block of this ticket -- tickets in flight together record into different
         blocks (and get their own workspace here).  Collect with ``trace_end(ticket)``."""
         torch = _torch()
