@@ -580,7 +580,10 @@ __device__ __forceinline__ bool lookback(unsigned long long* state, int tile, un
     }
     if (closed) break;
     if (consumed == 0) {
-      if (++idle > (1 << 20)) { ok = false; break; }
+      // (an idle poll is a fabric round trip plus s_sleep 8, ~1 us: 2^17 of them are ~0.15 s -- three orders
+      // of magnitude beyond the longest a live predecessor has been seen to take, and short enough that a
+      // box whose dispatcher does not start workgroups in index order falls back without a visible stall)
+      if (++idle > (1 << 17)) { ok = false; break; }
       __builtin_amdgcn_s_sleep(8);
       continue;
     }
