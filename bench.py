@@ -375,6 +375,9 @@ def main():
                                                                   how="sync" if mode == "sync" else "one_stream"),
                          args.side_steps)
     side_resized = side("changing ray count", resized_steps, args.side_steps)
+    # ... and (b) once more issued like the timed region, so that there is a figure to put next to `value`
+    side_no_hints_overlap = side("no hints, overlapped", lambda c, t=None: run_steps(
+        c, t, flags=args.flags | engine.TRACE_NO_HINTS), args.side_steps) if mode == "overlap" else None
     rows, counts = run_steps(2)  # (leave the scene with the hints of the north-star trace for what follows)
 
     rows_per_step = int(rows.shape[1])
@@ -556,8 +559,11 @@ def main():
     if side_sync:
         line["value_synchronous"] = side_sync["rows_per_s_this_gpu"] * world
         line["synchronous"] = side_sync
+    if side_no_hints_overlap:
+        side_no_hints_overlap.pop("_bytes"), side_no_hints_overlap.pop("_kernel_ms")
+        line["value_no_hints_overlapped"] = side_no_hints_overlap["rows_per_s_this_gpu"] * world  # issued like `value`
     if side_no_hints:
-        line["value_no_hints"] = side_no_hints["rows_per_s_this_gpu"] * world
+        line["value_no_hints"] = side_no_hints["rows_per_s_this_gpu"] * world  # one stream, like value_one_stream
         line["roofline"]["no_hints"] = {k: side_no_hints[k] for k in ("avg_launch_ms", "frac", "kernel_ms_per_step",
                                                                       "launches_per_step", "ms_per_step")}
     if side_resized:
