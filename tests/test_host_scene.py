@@ -303,3 +303,43 @@ def test_cull_step_hierarchy_follows_space_when_the_list_does_not():
     few = engine.DeviceScene.from_components(train(np.random.default_rng(6).permutation(6))).info()
     assert few["spatial_groups"] == 0 and few["cull_steps"] == 7         # below eight components: no groups at all
     assert few["both_directions"] == 0 and flat["both_directions"] == 0
+
+
+def test_scene_options_are_validated_and_versioned():
+    """prt_scene_options: zeros are the defaults, unknown names and bad values are rejected on the host, and
+    a caller compiled against a shorter struct is served (struct_size says how much of it there is)."""
+    import ctypes
+
+    import numpy as np
+
+    import scenes
+    from pyrayt_amd import engine
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    CountedObject.reset_ids()
+    parts, _ = scenes.config3(scenes.product_api(), 8)
+    snap = SceneSnapshot(parts)
+    assert engine.DeviceScene(snap).info()["cull_steps"] == 5
+    assert engine.DeviceScene(snap, options={"no_cull": 1}).info()["cull_steps"] == 0
+    assert engine.DeviceScene(snap, options={"cull_min": 6}).info()["cull_steps"] == 0
+    assert engine.DeviceScene(snap, options={"no_chain": 1}).info()["chain_steps"] == 0
+    with pytest.raises(ValueError, match="unknown scene option"):
+        engine.DeviceScene(snap, options={"no_such_knob": 1})
+    with pytest.raises(ValueError, match="hit_lanes"):
+        engine.DeviceScene(snap, options={"hit_lanes": 3})
+    # a struct that stops after `no_cull` (12 bytes): the rest counts as zero
+    lib = engine.library()
+    short = np.zeros(3, dtype=np.int32)
+    short[0], short[2] = 12, 1
+    handle = ctypes.c_void_p()
+    prims, nodes, roots, mats = (np.ascontiguousarray(a) for a in (snap.prims, snap.nodes, snap.roots, snap.materials))
+    rc = lib.prt_scene_create(prims.ctypes.data, len(prims), nodes.ctypes.data, len(nodes), roots.ctypes.data, len(roots),
+                              mats.ctypes.data, len(mats), short.ctypes.data, ctypes.byref(handle))
+    assert rc == 0
+    info = (ctypes.c_int64 * 10)()
+    assert lib.prt_scene_info(handle, info) == 0 and info[4] == 0  # no cull steps
+    lib.prt_scene_destroy(handle)
+    short[0] = 0  # struct_size not set
+    assert lib.prt_scene_create(prims.ctypes.data, len(prims), nodes.ctypes.data, len(nodes), roots.ctypes.data, len(roots),
+                                mats.ctypes.data, len(mats), short.ctypes.data, ctypes.byref(handle)) == -1
