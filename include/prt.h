@@ -269,6 +269,9 @@ int prt_generate_rays(int device, const prt_source* source, int64_t n_total, int
 #define PRT_TRACE_TEST_STALL 32   /* test hook: one tile reports an expired look-back, so that the
                                      fallback to the three-kernel path can be exercised */
 #define PRT_TRACE_SYNC 64         /* hipStreamSynchronize(stream) before returning */
+#define PRT_TRACE_NO_TIMING 256   /* do not bracket the generation launches with HIP events (prt_trace_stats then
+                                     reports 0 ms of kernel time): two event records and one event query less per
+                                     trace, which is most of what a 125k-ray trace costs the host */
 #define PRT_TRACE_COUNT_PATHS 128 /* count, in prt_trace_telemetry, the rays that are not well formed and
                                      the CSG node evaluations that took an exact path (see there) */
 int64_t prt_trace_workspace_bytes(int64_t n);

@@ -1558,7 +1558,8 @@ static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
   if (rc) return rc;
   HP(2);
   const unsigned long long epoch = ++t->epoch;
-  HIP_TRY(hipEventRecord(t->ev0, st));
+  const bool timed = !(t->flags & PRT_TRACE_NO_TIMING);
+  if (timed) HIP_TRY(hipEventRecord(t->ev0, st));
   HP(3);
   const bool culls = s->has_cull_steps;
   auto kernel = t->compact ? (culls ? k_generation<true, true> : k_generation<false, true>)
@@ -1582,8 +1583,10 @@ static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
     t->flip ^= 1;
     if (b == 0) HP(4);
   }
-  HIP_TRY(hipEventRecord(t->ev1, st));
-  t->timing_pending = true;
+  if (timed) {
+    HIP_TRY(hipEventRecord(t->ev1, st));
+    t->timing_pending = true;
+  }
   // Behind the batch, only when the generation kernels did not tell the host themselves: a one-block
   // kernel that does (and re-arms the control words if the batch turns out to end the trace).  In
   // the usual case nothing runs behind the batch: the status buffers recycle each other, a

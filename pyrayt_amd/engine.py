@@ -26,6 +26,7 @@ TRACE_PUBLISH_KERNEL = 16
 TRACE_TEST_STALL = 32
 TRACE_SYNC = 64
 TRACE_COUNT_PATHS = 128
+TRACE_NO_TIMING = 256
 TRACE_TICKETS = 4
 
 # prt_scene_options (include/prt.h): how a scene is compiled / which nearest-hit kernel serves
@@ -323,10 +324,12 @@ class DeviceScene:
         return self._view, per_generation
 
     # --- the hot loop in two halves: enqueue now, collect the counts later -----------------------------
-    def trace_begin(self, ticket, rays, generation_limit, out, ray_offset=DEFAULT_RAY_OFFSET, flags=0):
+    def trace_begin(self, ticket, rays, generation_limit, out, ray_offset=DEFAULT_RAY_OFFSET, flags=0, stream=None):
         """Enqueue a trace on one of the TRACE_TICKETS tickets and return at once (``prt_trace_begin``).  `out`: the (15, cap)
         CUDA float64 record block of this ticket -- tickets in flight together record into different
-        blocks (and get their own workspace here).  Collect with ``trace_end(ticket)``."""
+        blocks (and get their own workspace here).  Collect with ``trace_end(ticket)``.
+        stream: the torch stream to enqueue on (default: the current one); tickets on different streams
+        overlap on the device."""
         torch = _torch()
         assert rays.is_cuda and rays.dtype == torch.float64 and rays.dim() == 2
         assert rays.shape[0] == RAY_ROWS and rays.stride(1) == 1
@@ -344,7 +347,8 @@ class DeviceScene:
             work = works[ticket] = torch.empty(need, dtype=torch.uint8, device=dev)
         _check(library().prt_trace_begin(self.handle, dev.index or 0, int(ticket), rays.data_ptr(), n, rays.stride(0),
                                          limit, float(ray_offset), out.data_ptr(), out.shape[1], work.data_ptr(),
-                                         int(flags) | self.trace_flags, _stream_ptr(torch, dev)))
+                                         int(flags) | self.trace_flags,
+                                         _stream_ptr(torch, dev) if stream is None else ctypes.c_void_p(stream.cuda_stream)))
         counts = self._pending[ticket]
         if counts is None or len(counts[0]) != limit:
             counts = ((ctypes.c_int64 * max(limit, 1))(), None, None)
@@ -383,8 +387,7 @@ class DeviceScene:
                 here = torch.cuda.current_stream(rays.device)
                 for s in streams:
                     s.wait_stream(here)  # whatever produced the ray sets so far
-            with torch.cuda.stream(streams[lane]):
-                self.trace_begin(lane, rays, limit, blocks[lane], ray_offset=ray_offset, flags=flags)
+            self.trace_begin(lane, rays, limit, blocks[lane], ray_offset=ray_offset, flags=flags, stream=streams[lane])
             pending.append(lane)
         while pending:
             yield self._collect(torch, pending.pop(0), streams)
