@@ -264,6 +264,9 @@ class DeviceScene:
     def close(self):
         self._view_of = self._view = None
         self._pending = [None] * TRACE_TICKETS
+        self._begin_cache = [None] * TRACE_TICKETS
+        self._end_views = [None] * TRACE_TICKETS
+        self._ticket_work = None
         if self._handle:
             library().prt_scene_destroy(self._handle)
             self._handle = ctypes.c_void_p()
@@ -330,25 +333,40 @@ class DeviceScene:
         blocks (and get their own workspace here).  Collect with ``trace_end(ticket)``.
         stream: the torch stream to enqueue on (default: the current one); tickets on different streams
         overlap on the device."""
-        torch = _torch()
-        assert rays.is_cuda and rays.dtype == torch.float64 and rays.dim() == 2
-        assert rays.shape[0] == RAY_ROWS and rays.stride(1) == 1
-        assert out.is_cuda and out.dtype == torch.float64 and out.dim() == 2 and out.device == rays.device
-        assert out.shape[0] == RECORD_COLS and out.is_contiguous()
-        n, dev, limit = rays.shape[1], rays.device, int(generation_limit)
         if not 0 <= int(ticket) < TRACE_TICKETS:
             raise ValueError(f"ticket out of range (0..{TRACE_TICKETS - 1})")
-        works = getattr(self, "_ticket_work", None)
-        if works is None:
-            works = self._ticket_work = [None] * TRACE_TICKETS
-        work = works[ticket]
-        need = int(library().prt_trace_workspace_bytes(n))
-        if work is None or work.device != dev or work.numel() < need:
-            work = works[ticket] = torch.empty(need, dtype=torch.uint8, device=dev)
-        _check(library().prt_trace_begin(self.handle, dev.index or 0, int(ticket), rays.data_ptr(), n, rays.stride(0),
-                                         limit, float(ray_offset), out.data_ptr(), out.shape[1], work.data_ptr(),
-                                         int(flags) | self.trace_flags,
-                                         _stream_ptr(torch, dev) if stream is None else ctypes.c_void_p(stream.cuda_stream)))
+        # the same tensors as this ticket's previous trace (a loop re-tracing into its own blocks): the call's
+        # arguments are as they were (checking and converting them again costs as much as the call itself)
+        cached = self._begin_cache[ticket] if hasattr(self, "_begin_cache") else None
+        key = (rays, out, generation_limit, ray_offset, flags, stream)
+        if cached is not None and cached[0][0] is rays and cached[0][1] is out and cached[0][2:5] == key[2:5] \
+                and cached[0][5] is stream and cached[2] == (rays.data_ptr(), out.data_ptr()):
+            args = cached[1]
+        else:
+            torch = _torch()
+            assert rays.is_cuda and rays.dtype == torch.float64 and rays.dim() == 2
+            assert rays.shape[0] == RAY_ROWS and rays.stride(1) == 1
+            assert out.is_cuda and out.dtype == torch.float64 and out.dim() == 2 and out.device == rays.device
+            assert out.shape[0] == RECORD_COLS and out.is_contiguous()
+            n, dev, limit = rays.shape[1], rays.device, int(generation_limit)
+            works = getattr(self, "_ticket_work", None)
+            if works is None:
+                works = self._ticket_work = [None] * TRACE_TICKETS
+            work = works[ticket]
+            need = int(library().prt_trace_workspace_bytes(n))
+            if work is None or work.device != dev or work.numel() < need:
+                work = works[ticket] = torch.empty(need, dtype=torch.uint8, device=dev)
+            args = (self.handle, dev.index or 0, int(ticket), rays.data_ptr(), n, rays.stride(0), limit,
+                    float(ray_offset), out.data_ptr(), out.shape[1], work.data_ptr(), int(flags) | self.trace_flags,
+                    None if stream is None else ctypes.c_void_p(stream.cuda_stream))
+            if not hasattr(self, "_begin_cache"):
+                self._begin_cache = [None] * TRACE_TICKETS
+            self._begin_cache[ticket] = (key, args, (rays.data_ptr(), out.data_ptr()))
+        if args[12] is None:  # the current stream, whatever it is now
+            torch = _torch()
+            args = args[:12] + (_stream_ptr(torch, rays.device),)
+        _check(library().prt_trace_begin(*args))
+        limit = args[6]
         counts = self._pending[ticket]
         if counts is None or len(counts[0]) != limit:
             counts = ((ctypes.c_int64 * max(limit, 1))(), None, None)
@@ -363,7 +381,14 @@ class DeviceScene:
         per_generation = counts[:]
         while per_generation and per_generation[-1] == 0:
             per_generation.pop()
-        return out[:, :total], per_generation
+        # (slicing a tensor costs about 2 us: the view of the same block with the same row count is kept)
+        views = self._end_views if hasattr(self, "_end_views") else None
+        if views is None:
+            views = self._end_views = [None] * TRACE_TICKETS
+        view = views[ticket]
+        if view is None or view[0] is not out or view[1] != total:
+            view = views[ticket] = (out, total, out[:, :total])
+        return view[2], per_generation
 
     def trace_many(self, ray_sets, generation_limit, depth=2, ray_offset=DEFAULT_RAY_OFFSET, flags=0):
         """Trace a sequence of ray sets with `depth` traces in flight, each ticket on its own HIP stream:
