@@ -8,6 +8,7 @@ with a one-rank communicator.  The assembled frame must equal the single-rank fr
 row order included (pyrayt/_pyrayt.py:168-186)."""
 import os
 import socket
+import time
 
 import numpy as np
 import pytest
@@ -165,8 +166,14 @@ def test_rccl_allgather_rows_across_real_devices(tmp_path, name, n, mode):
     from pyrayt_amd import engine
 
     world = min(torch.cuda.device_count(), 4)
-    mp.start_processes(_rccl_worker, args=(world, _free_port(), name, n, mode, str(tmp_path)), nprocs=world,
-                       join=True, start_method="spawn")
+    ctx = mp.start_processes(_rccl_worker, args=(world, _free_port(), name, n, mode, str(tmp_path)), nprocs=world,
+                             join=False, start_method="spawn")
+    deadline = time.time() + 300  # (a rank that dies leaves the others waiting in a collective: do not hang the suite)
+    while not ctx.join(timeout=5):
+        if time.time() > deadline:
+            for proc in ctx.processes:
+                proc.terminate()
+            pytest.fail("the RCCL ranks did not finish within 300 s")
     snap, rays = _scene_and_rays(name, n)
     rows, counts = engine.DeviceScene(snap).trace(torch.from_numpy(rays).to("cuda:0"), LIMIT)
     want = rows.cpu().numpy()
