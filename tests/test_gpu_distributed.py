@@ -129,7 +129,10 @@ def _rccl_worker(rank, world, port, name, n, mode, result_dir):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(rank)
     device = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    import datetime
+
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device,
+                            timeout=datetime.timedelta(seconds=120))
     try:
         from pyrayt_amd import distributed as pdist
         from pyrayt_amd import engine
