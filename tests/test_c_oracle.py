@@ -73,3 +73,22 @@ def test_untracable_surface():
         c_oracle.trace(flat, rays, 5)
     with pytest.raises(AttributeError):
         prt_oracle.trace(flat, rays, 5)
+
+
+def test_all_cores_baseline_worker_runs():
+    """oracle/cpu_bench.py (bench.py's `cpu_baseline_all_cores` leg): P processes over contiguous id ranges of
+    the seeded job give the same number of rows as one process, and a JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = []
+    for procs in (1, 3):
+        done = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", "--rays", "6000", "--procs", str(procs),
+                               "--repeat", "2", "--limit", "10"], cwd=root, capture_output=True, text=True, timeout=300)
+        assert done.returncode == 0, done.stderr[-1000:]
+        lines.append(json.loads(done.stdout.strip().splitlines()[-1]))
+    assert lines[0]["rows"] == lines[1]["rows"] > 2 * 2 * 6000
+    assert lines[1]["procs"] == 3 and lines[1]["rows_per_s"] > 0
