@@ -400,6 +400,16 @@ class DeviceScene:
         depth = max(1, min(int(depth), TRACE_TICKETS))
         limit = int(generation_limit)
         pending, blocks, streams = [], [None] * depth, None
+        try:
+            yield from self._trace_many(torch, ray_sets, limit, depth, ray_offset, flags, pending, blocks, streams)
+        finally:
+            for lane in pending:  # a caller that stops early: collect what is in flight, the tickets are free again
+                try:
+                    self.trace_end(lane)
+                except Exception:  # noqa: BLE001
+                    pass
+
+    def _trace_many(self, torch, ray_sets, limit, depth, ray_offset, flags, pending, blocks, streams):
         for k, rays in enumerate(ray_sets):
             lane = k % depth
             if len(pending) == depth:  # the ticket about to be reused: collect its trace first
@@ -409,9 +419,7 @@ class DeviceScene:
                 blocks[lane] = torch.empty(need, dtype=torch.float64, device=rays.device)
             if streams is None:
                 streams = [torch.cuda.Stream(rays.device) for _ in range(depth)]
-                here = torch.cuda.current_stream(rays.device)
-                for s in streams:
-                    s.wait_stream(here)  # whatever produced the ray sets so far
+            streams[lane].wait_stream(torch.cuda.current_stream(rays.device))  # whatever produced this ray set
             self.trace_begin(lane, rays, limit, blocks[lane], ray_offset=ray_offset, flags=flags, stream=streams[lane])
             pending.append(lane)
         while pending:

@@ -1071,3 +1071,17 @@ def test_ticket_edges_update_in_flight_bad_ticket_varying_sizes():
         assert counts_k == want_counts_k, k
         helpers.assert_frames_match(rows_k.T, want_k, what=f"trace_many set {k}")
     ds.close()
+
+
+def test_trace_many_abandoned_midway_frees_its_tickets():
+    fx = helpers.load("scene_config2.npz")
+    limit = int(fx["generation_limit"])
+    ds = device_scene(helpers.scene_of(fx))
+    rays = dev(fx["rays0"])
+    stream = ds.trace_many((rays for _ in range(6)), limit, depth=3)
+    first_rows, first_counts = next(stream)
+    want = first_rows.cpu().numpy().copy()
+    stream.close()                                    # two more traces were in flight: they are collected
+    rows, counts = ds.trace(rays, limit)              # ... and ticket 0 is free for an ordinary trace
+    assert counts == first_counts and np.array_equal(rows.cpu().numpy(), want, equal_nan=True)
+    ds.close()
