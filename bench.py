@@ -90,8 +90,8 @@ def parse_args():
                          "(prt_trace_begin / prt_trace_end)")
     ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="traces in flight, each on its own HIP stream (their kernels overlap on the device); "
-                         "1 = one stream with one trace ahead; 0 (default) = config 2: 2 for 750k rays per GPU and "
-                         "more, else 3; the other workloads: 1")
+                         "1 = one stream with one trace ahead; 0 (default) = as many as keep their next states "
+                         "(80 B per ray) within ~200 MB of the Infinity Cache, at most 3")
     ap.add_argument("--side-steps", type=int, default=40,
                     help="steps of each untimed side measurement (synchronous / no hints / changing ray count)")
     return ap.parse_args()
@@ -236,9 +236,11 @@ def main():
     # stream (host hidden, kernels strictly one after the other).  "sync": prt_trace, one call at a time.
     # Measured on config 2 (profiles/r3/streams.txt): 1M rays 0.179 -> 0.151 ms per step with two streams
     # (three: 0.155), 125k rays 0.050 -> 0.040 -> 0.034 with two / three.
-    # The other BASELINE scenes (informational runs) stay on one stream: their launches are closer to the HBM
-    # roof by themselves and lose 3-4 % when a second trace competes for the Infinity Cache (config 3: +1 %).
-    streams_wanted = args.streams if args.streams else ((2 if n >= 750_000 else 3) if args.workload == "config2" else 1)
+    # How many: the state a generation hands to the next (80 B per ray) is meant to stay in the 256 MB Infinity
+    # Cache; traces in flight together share it.  As many traces as keep their next states within ~200 MB,
+    # at most three: 1M rays -> 2, 500k and less -> 3, 2M and more -> 1 (measured: config 2 at 1M rays 0.142 ms
+    # with two against 0.146 with three; config 5 at 2M and config 4 at 8M lose 3-4 % with two).
+    streams_wanted = args.streams if args.streams else max(1, min(3, int(200e6 // (80 * max(n, 1)))))
     mode = "sync" if not pipelined else ("overlap" if streams_wanted >= 2 else "one_stream")
     depth = streams_wanted if mode == "overlap" else 2  # traces in flight, the one being collected included
     # record blocks handed back to every step (what a design loop does once it has consumed the previous
