@@ -1085,3 +1085,27 @@ def test_trace_many_abandoned_midway_frees_its_tickets():
     rows, counts = ds.trace(rays, limit)              # ... and ticket 0 is free for an ordinary trace
     assert counts == first_counts and np.array_equal(rows.cpu().numpy(), want, equal_nan=True)
     ds.close()
+
+
+def test_one_million_rays_overlapped_equal_the_synchronous_trace():
+    """BASELINE config 2 at its full size through trace_many (two and three traces in flight on as many
+    streams): every frame is the synchronous trace's, bit for bit (compared on the device)."""
+    from pyrayt_amd.engine import DeviceScene
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    CountedObject.reset_ids()
+    parts, rays = scenes.config2(scenes.product_api(), 1_000_000, seed=1234)
+    ds = DeviceScene(SceneSnapshot(parts))
+    device_rays = dev(rays)
+    want, want_counts = ds.trace(device_rays, 10)
+    want = want.clone()
+    assert want_counts == [1_000_000, 1_000_000, 999_991]
+    for depth in (2, 3):
+        seen = 0
+        for rows, counts in ds.trace_many((device_rays for _ in range(2 * depth + 1)), 10, depth=depth):
+            assert counts == want_counts
+            assert torch.equal(rows, want)
+            seen += 1
+        assert seen == 2 * depth + 1
+    ds.close()
