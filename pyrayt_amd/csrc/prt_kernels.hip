@@ -1635,7 +1635,10 @@ static int fused_start(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
     s->hint_holdoff -= 1;
     allow_hints = false;
   }
-  t->use_hints = allow_hints && s->hint_n == n && s->hint_keep_absorbed == keep_absorbed && !t->test_stall;
+  // (the hints say how the scene treated the previous ray set -- which generations lost no ray -- and each
+  // tile checks them on its own rays, so they serve a ray set of another SIZE as well: a design loop that
+  // changes its ray count from call to call keeps them)
+  t->use_hints = allow_hints && s->hint_n >= 0 && s->hint_keep_absorbed == keep_absorbed && !t->test_stall;
   t->g = 0;
   t->n_seen = 0;
   t->total_rows = 0;

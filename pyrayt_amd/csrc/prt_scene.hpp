@@ -104,7 +104,7 @@ struct prt_scene {
   int last_generations = 0;  // working generations of the previous trace: sizes the first batch
   long lookback_fallbacks = 0;  // traces of this scene that fell back to the three-kernel path
   // what the previous trace's generations looked like (dense-mode hints for the next one, see k_generation)
-  int64_t hint_n = -1;          // ray count the hints were recorded for
+  int64_t hint_n = -1;          // ray count of the trace the hints were recorded from (-1: no hints)
   int hint_keep_absorbed = 0;
   std::vector<char> hint_mode;  // per generation: 0 general, 1 every ray recorded and carried on, 2 recorded, none carried
   long speculation_misses = 0;  // traces that had to be repeated because a hint did not hold
