@@ -344,8 +344,9 @@ def main():
     # (a) synchronous: one trace at a time through prt_trace, host and GPU strictly alternating;
     # (b) without the dense-mode hints of the previous trace (PRT_TRACE_NO_HINTS: what a first trace
     #     or a trace whose rays die differently runs on);
-    # (c) with a ray count that changes from call to call (no hints, control words re-initialised):
-    #     what a design loop that resizes its ray set every iteration sees.
+    # (c) with a ray count that changes from call to call (control words re-initialised every time; the hints
+    #     of the previous trace still apply -- they are checked per tile): what a design loop that resizes its
+    #     ray set every iteration sees.
     def side(label, fn, count):
         if count <= 0:
             return None
@@ -577,9 +578,9 @@ def main():
         line["roofline"]["no_hints"] = {k: side_no_hints[k] for k in ("avg_launch_ms", "frac", "kernel_ms_per_step",
                                                                       "launches_per_step", "ms_per_step")}
     if side_resized:
-        # "first trace" in the sense that matters to a caller: nothing learnt from the previous trace applies
-        # (other ray count: no hints, control words re-initialised); the one-off costs of a scene's very
-        # first call (table upload, kernel load) are in end_to_end_trace.first_call_ms instead
+        # a trace whose ray count differs from the previous one's (synchronous): the control words are
+        # re-initialised, the hints still serve; a scene's very first trace has no hints (value_no_hints) and
+        # its one-off costs (table upload, kernel load) are in end_to_end_trace.first_call_ms
         line["value_first_trace"] = side_resized["rows_per_s_this_gpu"] * world
         line["changing_ray_count"] = side_resized
     if gather:
