@@ -373,7 +373,7 @@ int prt_trace_stats(const prt_scene* scene, double* out8);
  * dense mode, traces repeated with all 13 state rows (see below; at most one per scene),
  * and from the traces run with PRT_TRACE_COUNT_PATHS: how many such traces, ray-generations whose ray was
  * not well formed (see "shortcuts" in DESIGN.md: such a ray takes none), CSG node evaluations with
- * survivors under an implied cull box, ... of which evaluated upstream's box test exactly }.  Dense mode: a generation in which the previous trace of the same scene and ray count
+ * survivors under an implied cull box, ... of which evaluated upstream's box test exactly }.  Dense mode: a generation in which the previous trace of the same scene (whatever its ray count)
  * recorded every ray and carried all or none of them on is launched on the assumption that it will
  * again -- every tile then knows its output position without the look-back; each tile checks the
  * assumption on its own counts and a miss repeats the trace without assumptions (results are exact
