@@ -38,7 +38,7 @@ python3 tools/slow_paths.py 2>&1 | grep -v amdgpu.ids > $out/slow_paths.txt
 { echo "# tools/cull_scaling.py (lens train listed along the axis)"; python3 tools/cull_scaling.py --counts 1 2 4 8 16 32 2>&1 | grep -v amdgpu.ids;
   echo; echo "# tools/cull_scaling.py --shuffle (lenses listed in random order, beams from both ends)"; python3 tools/cull_scaling.py --shuffle --counts 8 32 2>&1 | grep -v amdgpu.ids; } > $out/cull_scaling.txt
 python3 tools/hit_ab.py 2>&1 | grep -v amdgpu.ids > $out/hit_variants.txt
-{ python3 tools/aux_bench.py; python3 tools/frame_bench.py; } 2>&1 | grep -v amdgpu.ids > $out/aux_kernels.txt
+{ python3 tools/aux_bench.py; python3 tools/frame_bench.py; python3 tools/gather_bench.py; } 2>&1 | grep -v "RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl" | grep -v amdgpu.ids > $out/aux_kernels.txt
 # keep the summaries, drop the bulky per-dispatch traces
 rm -f $out/*_kernel_trace.csv $out/*_agent_info.csv $out/*domain_stats.csv
 ls -la $out | head -60
