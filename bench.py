@@ -92,6 +92,9 @@ def parse_args():
                     help="traces in flight, each on its own HIP stream (their kernels overlap on the device); "
                          "1 = one stream with one trace ahead; 0 (default) = as many as keep their next states "
                          "(80 B per ray) within ~200 MB of the Infinity Cache, at most 3")
+    ap.add_argument("--python-loop", action="store_true",
+                    help="issue the overlapped steps from a Python loop over prt_trace_begin / prt_trace_end "
+                         "(DeviceScene.trace_many's form) instead of one prt_trace_batch call per region")
     ap.add_argument("--side-steps", type=int, default=40,
                     help="steps of each untimed side measurement (synchronous / no hints / changing ray count)")
     return ap.parse_args()
@@ -252,7 +255,7 @@ def main():
     def step(flags=args.flags, rays_in=None):
         return scene.trace(rays_dev if rays_in is None else rays_in, limit, flags=flags, out=block)
 
-    streams = [torch.cuda.Stream(device) for _ in range(depth)] if mode == "overlap" else None
+    streams = scene.ticket_streams(device, depth) if mode == "overlap" else None
     torch.cuda.synchronize(device)
 
     class Totals:
@@ -267,6 +270,16 @@ def main():
             self.rows_recorded += st["rows"] * times
             self.rays_carried += st["rays_carried"] * times
 
+    batches = {}
+
+    def prepared_batch(count, flags=args.flags):
+        """The job table of `count` overlapped steps (built once per region size, outside the timed region)."""
+        key = (count, flags)
+        if key not in batches:
+            batches[key] = engine.TraceBatch(scene, [rays_dev] * count, limit, depth=depth, outs=blocks[:depth],
+                                             flags=flags | engine.TRACE_NO_TIMING)
+        return batches[key]
+
     def run_steps(count, totals=None, flags=args.flags, how=None):
         """`count` traces back to back, issued as `how` says (default: the bench's mode); returns (rows,
         counts) of the last one."""
@@ -279,6 +292,16 @@ def main():
                     totals.add()
             return rows, counts
         lanes = depth if how == "overlap" else 2
+        if how == "overlap" and not args.python_loop:
+            # the whole region as ONE library call (prt_trace_batch: the loop below, run by the library): what a
+            # caller with its ray sets up front uses; no Python inside the timed region.  (Same step time as the
+            # Python loop, --python-loop, at every shard size: profiles/r3/batch_issue.txt)
+            batch = prepared_batch(count, flags)
+            batch.run()
+            if totals is not None:
+                totals.add(count)
+            torch.cuda.synchronize(device)
+            return batch.result(-1)
 
         # overlapped traces are not bracketed with HIP events (an event pair would also see the other traces'
         # kernels; the generation kernel's own time comes from the one-stream region) and their statistics
@@ -308,6 +331,8 @@ def main():
         run_steps(4)
         spinup_steps += 4
     rows, counts = run_steps(max(args.warmup, 1)) if args.warmup else step()
+    if mode == "overlap" and not args.python_loop:
+        prepared_batch(args.steps)
     torch.cuda.synchronize(device)
     if distributed:
         dist.barrier()
@@ -502,6 +527,8 @@ def main():
                          "sync": ", synchronous (prt_trace)"}[mode] +
                         "; see value_one_stream / value_synchronous / value_no_hints / value_first_trace for the other kinds of step",
             "issue_mode": mode,
+            "issued_by": ("prt_trace_batch (one library call per timed region)" if mode == "overlap" and not args.python_loop
+                          else "a Python loop over prt_trace_begin / prt_trace_end" if mode != "sync" else "prt_trace"),
             "traces_in_flight": depth if mode != "sync" else 1,
             "streams": depth if mode == "overlap" else 1,
             "rays_job": n_job * (1 if strong else world),

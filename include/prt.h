@@ -295,6 +295,32 @@ int prt_trace_begin(prt_scene* scene, int device, int ticket, const double* rays
                     void* workspace, int flags, void* stream);
 int64_t prt_trace_end(prt_scene* scene, int device, int ticket, int64_t* rows_per_generation);
 
+/* A sequence of traces of one scene -- a tolerance run, a source sweep, the shards of a rank -- with `depth`
+ * of them in flight: job k runs on ticket k % depth with workspaces[k % depth] and on streams[k % depth]
+ * (NULL: all on the null stream), exactly as a caller of prt_trace_begin / prt_trace_end would run them,
+ * without the caller's interpreter between two launches (no counterpart upstream: pyrayt/_pyrayt.py:329-339
+ * traces one ray set per call).  It is a convenience and keeps a caller's interpreter out of the loop; it is
+ * not faster than a tight loop over the two entry points (125k-ray traces, three in flight: 25 us each either
+ * way -- what bounds them is the chain of dependent launches on the device, not the host).
+ *   jobs: per trace the ray set, its record block and HOST rows_per_generation[generation_limit]; `total`
+ *     receives what prt_trace would have returned for it.  Jobs `depth` apart may share a record block if
+ *     the caller wants only the last results (jobs in flight together may not).
+ *   workspaces: `depth` blocks, each of prt_trace_workspace_bytes(largest n it will see) bytes.
+ *   The ray sets must be complete before the call, or be produced on the stream their job runs on.
+ * Returns the rows of all jobs together, or the first error (jobs already in flight are collected, later
+ * ones are not started).  As with prt_trace the counts are on the host on return and the rows are ordered
+ * on their job's stream (PRT_TRACE_SYNC: every job synchronises its stream when it is collected). */
+typedef struct prt_trace_job {
+  const double* rays;  /* (13, n) with leading dimension ld */
+  int64_t n, ld;
+  double* rows_out;    /* (15, rows_cap) */
+  int64_t rows_cap;
+  int64_t* rows_per_generation;
+  int64_t total;       /* out */
+} prt_trace_job;
+int64_t prt_trace_batch(prt_scene* scene, int device, prt_trace_job* jobs, int64_t count, int generation_limit,
+                        double ray_offset, int depth, void* const* workspaces, void* const* streams, int flags);
+
 /* ---- frame re-assembly across the GPUs of a node ----------------------------
  * No counterpart upstream (pyrayt/_pyrayt.py:329-339 is one Python thread).  Rank r traces the
  * contiguous id range [r n/G, (r+1) n/G) with no communication; these entry points put the per-rank

@@ -1410,6 +1410,9 @@ static std::unordered_map<const void*, unsigned long long> g_workspace_user;
 static std::atomic<unsigned long long> g_next_user{1};
 static bool workspace_taken_over(const void* w, unsigned long long user) {
   std::lock_guard<std::mutex> lock(g_workspace_mutex);
+  // (addresses that were freed long ago would stay in here for ever: forgetting everybody is always safe,
+  // a forgotten owner just re-initialises its control words once)
+  if (g_workspace_user.size() > 4096) g_workspace_user.clear();
   unsigned long long& last = g_workspace_user[w];
   const bool same = last == user;
   last = user;
@@ -1821,6 +1824,45 @@ extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64
                                  workspace, flags, stream);
   if (rc) return rc;
   return prt_trace_end(s, device, 0, rows_per_generation);
+}
+
+// A sequence of traces of one scene, `depth` of them in flight (ticket k % depth, its workspace, its
+// stream): the loop DeviceScene.trace_many runs in Python, as one call.  (Measured with a host pause between
+// collecting a trace and starting the next, profiles/r3/batch_issue.txt: the pace of the host is not what
+// bounds overlapped traces -- a tight Python loop reaches the same step time down to 125k rays.)
+extern "C" int64_t prt_trace_batch(prt_scene* s, int device, prt_trace_job* jobs, int64_t count, int generation_limit,
+                                   double ray_offset, int depth, void* const* workspaces, void* const* streams,
+                                   int flags) {
+  DeviceCopy* c;
+  int rc = on_device(s, device, &c);
+  if (rc) return rc;
+  if (count < 0 || (count && !jobs) || depth < 1 || depth > PRT_TRACE_TICKETS || !workspaces)
+    return fail(PRT_ERR_ARG, "bad job list / depth out of range (1..PRT_TRACE_TICKETS) / null workspaces");
+  for (int64_t k = 0; k < count; ++k) {
+    if (!jobs[k].rows_per_generation) return fail(PRT_ERR_ARG, "a job has no rows_per_generation");
+    jobs[k].total = 0;
+  }
+  for (int k = 0; k < depth; ++k)
+    if (c->ticket[k].active) return fail(PRT_ERR_ARG, "a ticket this batch needs has a trace in flight");
+  int64_t sum = 0, first_error = 0;
+  std::string message;
+  for (int64_t k = 0; k < count + depth; ++k) {
+    const int lane = (int)(k % depth);
+    if (k >= depth && c->ticket[lane].active) {  // the ticket about to be reused: collect its trace first
+      prt_trace_job& done = jobs[k - depth];
+      done.total = prt_trace_end(s, device, lane, done.rows_per_generation);
+      if (done.total < 0 && !first_error) { first_error = done.total; message = g_error; }
+      if (done.total > 0) sum += done.total;
+    }
+    if (k < count && !first_error) {  // (after an error nothing new is started; what is in flight is collected)
+      const prt_trace_job& job = jobs[k];
+      rc = prt_trace_begin(s, device, lane, job.rays, job.n, job.ld, generation_limit, ray_offset, job.rows_out,
+                           job.rows_cap, workspaces[lane], flags, streams ? streams[lane] : nullptr);
+      if (rc) { jobs[k].total = rc; first_error = rc; message = g_error; }
+    }
+  }
+  if (first_error) return fail((int)first_error, message.c_str());
+  return sum;
 }
 
 

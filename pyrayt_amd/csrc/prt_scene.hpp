@@ -353,15 +353,17 @@ static void pad_box(double* box) {
 // leaf takes one of upstream's degenerate branches *spuriously* -- `isclose(a, 0)` / `isclose(d_z, 0)` with
 // their absolute 1e-8 thresholds on object-space quantities (primitives.py:346, 531, 683) fire for any ray
 // whose object-space direction is short, not only for one that really is parallel, and what the
-// branch then reports (e.g. the paraboloid's -c / b) is not a point of the surface.  So every cull
-// step carries the squared world-space direction length below which that can happen for one of its
+// branch then reports (e.g. the paraboloid's -c / b) is not a point of the surface.  So a component
+// has a bound on the squared world-space direction length below which that can happen for one of its
 // leaves -- 1e-3 over the smallest squared singular value of the leaf's M^-1, i.e. |d_obj|^2 >= 1e-3:
 // a branch that fires there (|d_obj,xy|^2 <= 1e-8) means sin^2 of the angle to the axis <= 1e-5, and
 // the point its linear root names is off the surface by about that times the squared distance
-// travelled, far inside the 1e-3-of-the-diagonal padding for anything an optical bench holds -- and
-// may_reach lets shorter directions through.  For unit directions and objects of ordinary size the bound
-// is far below 1; for an object scaled up by more than ~30 it exceeds 1 and the component is simply
-// never culled.  (Found by the adv_still fixture.)
+// travelled, far inside the 1e-3-of-the-diagonal padding for anything an optical bench holds.  The
+// kernels have ONE gate for all their shortcuts (well_formed(): w = 1 / 0 and |d|^2 >= kWellFormedLen2Lo,
+// prt_device.hpp), so the rule is applied here, at compile time: a component gets cull steps only if its
+// bound is at most kWellFormedLen2Lo, and may_reach lets every ray that is not well formed through.  For
+// objects of ordinary size the bound is far below that; an object scaled up by more than ~30 exceeds it
+// and is simply never culled.  (Found by the adv_still fixture.)
 static double min_singular_sq(const double* minv) {
   // smallest eigenvalue of B = A^T A, A = the 3x3 linear part of the row-major 4x4 M^-1 (analytic
   // symmetric 3x3 eigenvalues; the result is halved to stay below rounding)
@@ -836,6 +838,9 @@ extern "C" void prt_scene_destroy(prt_scene* s) {
     DeviceCopy& c = s->per_device[d];
     if (!c.prims && !c.trace_code) continue;
     (void)hipSetDevice((int)d);
+    // a trace that was begun and never ended, or one whose counts are out while its last stores are not,
+    // still reads the tables and writes the host mirror freed below
+    (void)hipDeviceSynchronize();
     (void)hipFree(c.prims);
     (void)hipFree(c.trace_code);
     (void)hipFree(c.trace_component_first);

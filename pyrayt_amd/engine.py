@@ -88,6 +88,7 @@ def _declare(lib):
                               c_int, c_p]),
         "prt_trace_begin": (c_int, [c_p, c_int, c_int, c_p, c_i64, c_i64, c_int, c_d, c_p, c_i64, c_p, c_int, c_p]),
         "prt_trace_end": (c_i64, [c_p, c_int, c_int, c_p]),
+        "prt_trace_batch": (c_i64, [c_p, c_int, c_p, c_i64, c_int, c_d, c_int, c_p, c_p, c_int]),
         "prt_trace_stats": (c_int, [c_p, c_p]),
         "prt_trace_telemetry": (c_int, [c_p, c_p]),
         "prt_generate_rays": (c_int, [c_int, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p]),
@@ -129,7 +130,7 @@ EXPORTED_SYMBOLS = (
     "prt_version", "prt_last_error", "prt_device_count", "prt_scene_create", "prt_scene_destroy", "prt_scene_update",
     "prt_scene_component_rows", "prt_scene_info", "prt_intersect", "prt_propagate", "prt_world_normals",
     "prt_material_trace", "prt_interact_workspace_bytes", "prt_interact",
-    "prt_trace_workspace_bytes", "prt_trace", "prt_trace_begin", "prt_trace_end", "prt_trace_stats", "prt_trace_telemetry", "prt_generate_rays",
+    "prt_trace_workspace_bytes", "prt_trace", "prt_trace_begin", "prt_trace_end", "prt_trace_batch", "prt_trace_stats", "prt_trace_telemetry", "prt_generate_rays",
     "prt_camera_rays", "prt_render_hits", "prt_gooch_shade", "prt_gooch_mix", "prt_render",
     "prt_edge_workspace_bytes", "prt_edge_canvas", "prt_reflect", "prt_refract", "prt_binomial_root",
     "prt_smallest_positive_root", "prt_dot", "prt_array_csg", "prt_primitive_intersect",
@@ -288,7 +289,7 @@ class DeviceScene:
         torch = _torch()
         lib = library()
         assert rays.is_cuda and rays.dtype == torch.float64 and rays.dim() == 2
-        assert rays.shape[0] == RAY_ROWS and rays.stride(1) == 1
+        assert rays.shape[0] == RAY_ROWS and (rays.shape[1] == 0 or rays.stride(1) == 1)
         n = rays.shape[1]
         dev = rays.device
         limit = int(generation_limit)
@@ -349,13 +350,7 @@ class DeviceScene:
             assert out.is_cuda and out.dtype == torch.float64 and out.dim() == 2 and out.device == rays.device
             assert out.shape[0] == RECORD_COLS and out.is_contiguous()
             n, dev, limit = rays.shape[1], rays.device, int(generation_limit)
-            works = getattr(self, "_ticket_work", None)
-            if works is None:
-                works = self._ticket_work = [None] * TRACE_TICKETS
-            work = works[ticket]
-            need = int(library().prt_trace_workspace_bytes(n))
-            if work is None or work.device != dev or work.numel() < need:
-                work = works[ticket] = torch.empty(need, dtype=torch.uint8, device=dev)
+            work = self._ticket_workspace(torch, ticket, n, dev)
             args = (self.handle, dev.index or 0, int(ticket), rays.data_ptr(), n, rays.stride(0), limit,
                     float(ray_offset), out.data_ptr(), out.shape[1], work.data_ptr(), int(flags) | self.trace_flags,
                     None if stream is None else ctypes.c_void_p(stream.cuda_stream))
@@ -418,12 +413,44 @@ class DeviceScene:
             if blocks[lane] is None or blocks[lane].shape[1] < need[1] or blocks[lane].device != rays.device:
                 blocks[lane] = torch.empty(need, dtype=torch.float64, device=rays.device)
             if streams is None:
-                streams = [torch.cuda.Stream(rays.device) for _ in range(depth)]
+                streams = self.ticket_streams(rays.device, depth)
             streams[lane].wait_stream(torch.cuda.current_stream(rays.device))  # whatever produced this ray set
             self.trace_begin(lane, rays, limit, blocks[lane], ray_offset=ray_offset, flags=flags, stream=streams[lane])
             pending.append(lane)
         while pending:
             yield self._collect(torch, pending.pop(0), streams)
+
+    def trace_batch(self, ray_sets, generation_limit, depth=2, outs=None, ray_offset=DEFAULT_RAY_OFFSET, flags=0):
+        """``trace_many`` for ray sets that all exist up front, as one library call (``prt_trace_batch``): the
+        loop over the tickets runs in the library (no interpreter between two launches; a tight Python loop over
+        trace_begin / trace_end is as fast, a generator with per-item work in between is not).  Returns [(rows, counts), ...]; see ``TraceBatch`` to run one
+        prepared batch many times."""
+        batch = TraceBatch(self, ray_sets, generation_limit, depth=depth, outs=outs, ray_offset=ray_offset, flags=flags)
+        batch.run()
+        return batch.results()
+
+    def _ticket_workspace(self, torch, ticket, n, dev):
+        """The workspace of one ticket (kept, grown when a larger ray set comes)."""
+        works = getattr(self, "_ticket_work", None)
+        if works is None:
+            works = self._ticket_work = [None] * TRACE_TICKETS
+        work = works[ticket]
+        need = int(library().prt_trace_workspace_bytes(n))
+        if work is None or work.device != dev or work.numel() < need:
+            work = works[ticket] = torch.empty(need, dtype=torch.uint8, device=dev)
+        return work
+
+    def ticket_streams(self, device, depth=TRACE_TICKETS):
+        """The HIP streams this scene's tickets run on when traces overlap (one per ticket, made once: the
+        runtime maps streams onto a handful of hardware queues -- four by default -- and two streams that
+        land on one queue run their kernels one after the other, so a program should not keep making new ones)."""
+        torch = _torch()
+        made = getattr(self, "_ticket_streams", None)
+        if made is None or made[0] != device:
+            made = self._ticket_streams = (device, [])
+        while len(made[1]) < depth:
+            made[1].append(torch.cuda.Stream(device))
+        return made[1][:depth]
 
     def _collect(self, torch, lane, streams):
         rows, counts = self.trace_end(lane)
@@ -594,6 +621,82 @@ class DeviceScene:
 # ---------------------------------------------------------------------------------------------
 # renderer helpers without a scene
 # ---------------------------------------------------------------------------------------------
+JOB_DTYPE = np.dtype(
+    [("rays", "<u8"), ("n", "<i8"), ("ld", "<i8"), ("rows_out", "<u8"), ("rows_cap", "<i8"),
+     ("rows_per_generation", "<u8"), ("total", "<i8")]
+)  # prt_trace_job
+
+
+class TraceBatch:
+    """A prepared ``prt_trace_batch`` call: the job table, record blocks, workspaces and streams of a
+    sequence of traces of one scene, `depth` of them in flight.  ``run()`` traces them all (again);
+    ``results()`` are the (rows, counts) of the last run.  outs: record blocks, (15, cap) each -- one per
+    ray set, or fewer (at least `depth`) to be reused in turn when only the last results are wanted."""
+
+    def __init__(self, scene, ray_sets, generation_limit, depth=2, outs=None, ray_offset=DEFAULT_RAY_OFFSET, flags=0):
+        torch = _torch()
+        self.scene, self.ray_sets = scene, list(ray_sets)
+        self.limit, self.ray_offset = int(generation_limit), float(ray_offset)
+        self.flags = int(flags) | scene.trace_flags
+        self.depth = depth = max(1, min(int(depth), TRACE_TICKETS))
+        count = len(self.ray_sets)
+        self.jobs = np.zeros(count, dtype=JOB_DTYPE)
+        self.counts = np.zeros((count, max(self.limit, 1)), dtype=np.int64)
+        self.totals = None
+        if count == 0:
+            return
+        dev = self.device = self.ray_sets[0].device
+        for rays in self.ray_sets:
+            assert rays.is_cuda and rays.dtype == torch.float64 and rays.dim() == 2 and rays.device == dev
+            assert rays.shape[0] == RAY_ROWS and (rays.shape[1] == 0 or rays.stride(1) == 1)
+        if outs is None:
+            outs = [torch.empty((RECORD_COLS, max(r.shape[1], 1) * max(self.limit, 1)), dtype=torch.float64, device=dev)
+                    for r in self.ray_sets]
+        self.outs = list(outs)
+        if len(self.outs) < min(depth, count):
+            raise ValueError("a batch needs a record block per trace in flight (len(outs) >= depth)")
+        for out in self.outs:
+            assert out.is_cuda and out.dtype == torch.float64 and out.dim() == 2 and out.device == dev
+            assert out.shape[0] == RECORD_COLS and out.is_contiguous()
+        lanes_n = [max((r.shape[1] for r in self.ray_sets[lane::depth]), default=0) for lane in range(depth)]
+        self.works = [scene._ticket_workspace(torch, lane, n, dev) for lane, n in enumerate(lanes_n)]
+        self.streams = scene.ticket_streams(dev, depth)
+        self._work_ptrs = (ctypes.c_void_p * depth)(*[w.data_ptr() for w in self.works])
+        self._stream_ptrs = (ctypes.c_void_p * depth)(*[s.cuda_stream for s in self.streams])
+        for k, rays in enumerate(self.ray_sets):
+            out = self.outs[k % len(self.outs)]
+            self.jobs[k] = (rays.data_ptr(), rays.shape[1], rays.stride(0), out.data_ptr(), out.shape[1],
+                            self.counts[k].ctypes.data, 0)
+
+    def run(self):
+        """Trace every ray set of the batch; returns the rows of all of them together."""
+        if len(self.ray_sets) == 0:
+            return 0
+        torch = _torch()
+        current = torch.cuda.current_stream(self.device)
+        for stream in self.streams:  # whatever produced the ray sets
+            stream.wait_stream(current)
+        total = _check(library().prt_trace_batch(
+            self.scene.handle, self.device.index or 0, self.jobs.ctypes.data, len(self.jobs), self.limit,
+            self.ray_offset, self.depth, self._work_ptrs, self._stream_ptrs, self.flags))
+        for stream in self.streams:  # consumers on the caller's stream
+            current.wait_stream(stream)
+        self.totals = self.jobs["total"].copy()
+        return total
+
+    def result(self, k):
+        """(rows, counts) of ray set `k` in the last run."""
+        assert self.totals is not None, "run() first"
+        k = range(len(self.ray_sets))[k]
+        per_generation = self.counts[k, :self.limit].tolist()
+        while per_generation and per_generation[-1] == 0:
+            per_generation.pop()
+        return self.outs[k % len(self.outs)][:, :int(self.totals[k])], per_generation
+
+    def results(self):
+        return [self.result(k) for k in range(len(self.ray_sets))]
+
+
 CAMERA_DTYPE = np.dtype(
     [("world", "<f8", (16,)), ("h_pixels", "<i8"), ("v_pixels", "<i8"), ("h_width", "<f8"),
      ("v_width", "<f8")], align=True)

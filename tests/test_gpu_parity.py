@@ -1109,3 +1109,77 @@ def test_one_million_rays_overlapped_equal_the_synchronous_trace():
             seen += 1
         assert seen == 2 * depth + 1
     ds.close()
+
+
+def test_trace_batch_is_trace_many_in_one_library_call():
+    """prt_trace_batch / DeviceScene.trace_batch: ray sets of different sizes (an empty one among them), one to
+    four traces in flight; every frame is the synchronous trace's, bit for bit."""
+    fx = helpers.load("scene_config2.npz")
+    limit = int(fx["generation_limit"])
+    ds = device_scene(helpers.scene_of(fx))
+    base = fx["rays0"]
+    sets, want = [], []
+    for k in range(9):
+        rays = base[:, : base.shape[1] - 37 * k].copy() if k != 4 else base[:, :0].copy()
+        rays[5, k::5] += 0.02 * k
+        if rays.shape[1]:
+            rays[4:7] /= np.linalg.norm(rays[4:7], axis=0)
+        sets.append(dev(rays))
+        rows, counts = ds.trace(sets[-1], limit)
+        want.append((rows.cpu().numpy().copy(), counts))
+    for depth in (1, 2, 3, 4):
+        got = ds.trace_batch(sets, limit, depth=depth)
+        assert len(got) == len(want)
+        for k, ((rows, counts), (ref_rows, ref_counts)) in enumerate(zip(got, want)):
+            assert counts == ref_counts, (depth, k)
+            assert np.array_equal(rows.cpu().numpy(), ref_rows, equal_nan=True), (depth, k)
+    assert ds.trace_batch([], limit) == []
+    ds.close()
+
+
+def test_a_prepared_batch_runs_again_and_may_reuse_its_record_blocks():
+    """TraceBatch: the same table traced twice; with as many record blocks as traces in flight only the
+    last `depth` frames remain, and those are right."""
+    fx = helpers.load("scene_config2.npz")
+    limit = int(fx["generation_limit"])
+    ds = device_scene(helpers.scene_of(fx))
+    rays = dev(fx["rays0"])
+    n = rays.shape[1]
+    want, want_counts = ds.trace(rays, limit)
+    want = want.clone()
+    depth = 3
+    outs = [torch.empty((15, n * limit), dtype=torch.float64, device="cuda:0") for _ in range(depth)]
+    batch = engine.TraceBatch(ds, [rays] * 8, limit, depth=depth, outs=outs)
+    for _ in range(2):
+        for out in outs:
+            out.fill_(-1.0)
+        assert batch.run() == 8 * want.shape[1]
+        found = batch.results()
+        for rows, counts in found[-depth:]:
+            assert counts == want_counts and torch.equal(rows, want)
+    with pytest.raises(ValueError, match="record block per trace in flight"):
+        engine.TraceBatch(ds, [rays] * 8, limit, depth=3, outs=outs[:2])
+    ds.close()
+
+
+def test_a_batch_reports_the_first_error_and_leaves_the_tickets_free():
+    fx = helpers.load("scene_config2.npz")
+    limit = int(fx["generation_limit"])
+    ds = device_scene(helpers.scene_of(fx))
+    rays = dev(fx["rays0"])
+    n = rays.shape[1]
+    want, want_counts = ds.trace(rays, limit)
+    want = want.clone()
+    outs = [torch.empty((15, n * limit), dtype=torch.float64, device="cuda:0") for _ in range(6)]
+    outs[2] = torch.empty((15, n), dtype=torch.float64, device="cuda:0")  # one generation's worth: too small
+    batch = engine.TraceBatch(ds, [rays] * 6, limit, depth=2, outs=outs)
+    with pytest.raises(RuntimeError, match="rows_cap too small"):
+        batch.run()
+    totals = batch.jobs["total"]
+    assert totals[0] == totals[1] == want.shape[1] and totals[2] == engine.ERR_ROWS_CAP
+    assert totals[4] == totals[5] == 0                      # never started
+    rows, counts = ds.trace(rays, limit)                    # every ticket was collected
+    assert counts == want_counts and torch.equal(rows, want)
+    got = ds.trace_batch([rays] * 3, limit, depth=3)
+    assert all(c == want_counts and torch.equal(r, want) for r, c in got)
+    ds.close()
