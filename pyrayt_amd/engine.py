@@ -341,7 +341,8 @@ class DeviceScene:
         cached = self._begin_cache[ticket] if hasattr(self, "_begin_cache") else None
         key = (rays, out, generation_limit, ray_offset, flags, stream)
         if cached is not None and cached[0][0] is rays and cached[0][1] is out and cached[0][2:5] == key[2:5] \
-                and cached[0][5] is stream and cached[2] == (rays.data_ptr(), out.data_ptr()):
+                and cached[0][5] is stream and cached[2] == (rays.data_ptr(), out.data_ptr()) \
+                and cached[3] is self._ticket_work[ticket]:  # (a larger trace since then replaced the workspace)
             args = cached[1]
         else:
             torch = _torch()
@@ -356,7 +357,7 @@ class DeviceScene:
                     None if stream is None else ctypes.c_void_p(stream.cuda_stream))
             if not hasattr(self, "_begin_cache"):
                 self._begin_cache = [None] * TRACE_TICKETS
-            self._begin_cache[ticket] = (key, args, (rays.data_ptr(), out.data_ptr()))
+            self._begin_cache[ticket] = (key, args, (rays.data_ptr(), out.data_ptr()), work)
         if args[12] is None:  # the current stream, whatever it is now
             torch = _torch()
             args = args[:12] + (_stream_ptr(torch, rays.device),)

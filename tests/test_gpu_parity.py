@@ -1183,3 +1183,30 @@ def test_a_batch_reports_the_first_error_and_leaves_the_tickets_free():
     got = ds.trace_batch([rays] * 3, limit, depth=3)
     assert all(c == want_counts and torch.equal(r, want) for r, c in got)
     ds.close()
+
+
+def test_a_ticket_keeps_no_stale_workspace_after_a_larger_trace_grew_it():
+    """trace_begin caches its arguments per ticket; the ticket's workspace is replaced when a larger ray set
+    comes (here through a batch): the cached call must not keep the freed block's address."""
+    fx = helpers.load("scene_config2.npz")
+    limit = int(fx["generation_limit"])
+    ds = device_scene(helpers.scene_of(fx))
+    base = fx["rays0"]
+    small, large = dev(base[:, :2000].copy()), dev(np.tile(base, (1, 3)))
+    want, want_counts = ds.trace(small, limit)
+    want = want.clone()
+    block = torch.empty((15, 2000 * limit), dtype=torch.float64, device="cuda:0")
+    for _ in range(2):                                   # the second call comes from the cache
+        ds.trace_begin(0, small, limit, block)
+        rows, counts = ds.trace_end(0)
+        assert counts == want_counts and torch.equal(rows, want)
+    before = ds._ticket_work[0]
+    ds.trace_batch([large, large], limit, depth=2)
+    assert ds._ticket_work[0] is not before              # grown: the old block went back to the allocator
+    del before
+    filler = [torch.full((1 << 20,), 7, dtype=torch.uint8, device="cuda:0") for _ in range(64)]  # ... and is reused
+    ds.trace_begin(0, small, limit, block)
+    rows, counts = ds.trace_end(0)
+    assert counts == want_counts and torch.equal(rows, want)
+    assert all(int(f.min()) == 7 for f in filler)         # nobody wrote through a stale pointer
+    ds.close()
