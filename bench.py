@@ -433,7 +433,7 @@ def main():
                 torch.cuda.synchronize(device)
                 dist.barrier()
                 g0 = time.perf_counter()
-                full, full_counts = pdist.assemble_rows(rows, counts, limit, dist.group.WORLD, "all", comm=comm)
+                full, full_counts = pdist.assemble_rows(rows, counts, limit, dist.group.WORLD, "all", comm=comm, reuse=True)
                 torch.cuda.synchronize(device)
                 dist.barrier()
                 times.append(time.perf_counter() - g0)

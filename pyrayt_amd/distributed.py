@@ -119,15 +119,16 @@ class LibraryComm:
                                                      engine._stream_ptr(torch, self.device)))
         return torch.tensor(list(everyone), dtype=torch.int64).view(self.world, limit)
 
-    def gather_rows(self, rows, matrix_host, limit, out=None):
+    def gather_rows(self, rows, matrix_host, limit, out=None, reuse=False):
         """All ranks' rows in reference order, (15, total) on this rank's GPU.  Stream-ordered.
 
         rows: this rank's record block (a (15, R) view of it is enough: the all-gather reads `widest`
         elements of every column, which the (15, cap) block the trace recorded into always has -- only a
         narrower or strided tensor is copied into a block of that width first).
-        out: a (15, >= total) block to assemble into (a loop hands the previous frame's block back);
-        otherwise the communicator reuses its own block while the size stays the same -- the caller is
-        done with the previous frame by then (pass ``out`` to keep several frames alive)."""
+        out: a (15, >= total) block to assemble into (a loop hands the previous frame's block back).
+        reuse: without `out`, assemble into the communicator's own block, kept while the size stays the same
+        -- for a loop that is done with the previous frame by then; the default is a new block per call, as
+        a single-GPU trace returns one (two frames a caller keeps never alias)."""
         from . import engine
 
         per_rank = matrix_host.sum(dim=1)
@@ -140,11 +141,13 @@ class LibraryComm:
         need = int(self._lib.prt_allgather_workspace_bytes(self.world, limit, widest))
         if self._work is None or self._work.numel() < need:
             self._work = torch.empty(need, dtype=torch.uint8, device=self.device)
-        if out is None:
+        if out is None and reuse:
             kept = getattr(self, "_out", None)
             if kept is None or kept.shape != (rows.shape[0], total) or kept.dtype != rows.dtype:
                 self._out = kept = torch.empty((rows.shape[0], total), dtype=rows.dtype, device=self.device)
             out = kept
+        elif out is None:
+            out = torch.empty((rows.shape[0], total), dtype=rows.dtype, device=self.device)
         else:
             assert out.is_cuda and out.shape[0] == rows.shape[0] and out.shape[1] >= total and out.stride(1) == 1
         flat = (ctypes.c_int64 * (limit * self.world))(*[int(v) for v in matrix_host.reshape(-1)])
@@ -192,7 +195,8 @@ def _place_with_torch(blocks, matrix_host, total):
     return out
 
 
-def assemble_rows(rows, counts, generation_limit, group=None, gather="all", comm=None, count_matrix=None, out=None):
+def assemble_rows(rows, counts, generation_limit, group=None, gather="all", comm=None, count_matrix=None, out=None,
+                  reuse=False):
     """Re-assemble per-rank record blocks into the reference's row order.
 
     rows: (15, R_local) tensor, generation-major; counts: rows per generation (list).
@@ -200,13 +204,13 @@ def assemble_rows(rows, counts, generation_limit, group=None, gather="all", comm
     comm: a ``LibraryComm`` -> the whole exchange runs inside the HIP library over RCCL.
     count_matrix: the (G, limit) rows-per-generation matrix if the caller already holds it (a repeated
     trace whose counts did not change): the count all-gather and its host synchronisation are skipped.
-    out: block for the assembled frame (``LibraryComm.gather_rows``)."""
+    out / reuse: where the frame is assembled (``LibraryComm.gather_rows``)."""
     if (group is None and comm is None) or gather == "none":
         return rows, list(counts)
     limit = int(generation_limit)
     if comm is not None:
         matrix_host = comm.gather_counts(counts, limit) if count_matrix is None else count_matrix
-        out = comm.gather_rows(rows, matrix_host, limit, out=out)
+        out = comm.gather_rows(rows, matrix_host, limit, out=out, reuse=reuse)
         if gather == "root" and comm.rank != 0:
             return rows[:, :0], _merged_counts(matrix_host)
         return out, _merged_counts(matrix_host)

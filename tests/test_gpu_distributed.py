@@ -98,6 +98,12 @@ def test_rccl_leg_with_a_one_rank_communicator():
         out, merged = pdist.assemble_rows(rows, counts, LIMIT, None, "all", comm=comm)
         assert merged == counts
         assert torch.equal(out, rows)
+        # two frames a caller keeps do not alias (as on one GPU); a loop may ask for the communicator's own block
+        again, _ = pdist.assemble_rows(rows, counts, LIMIT, None, "all", comm=comm)
+        assert again.data_ptr() != out.data_ptr() and torch.equal(again, rows)
+        kept, _ = pdist.assemble_rows(rows, counts, LIMIT, None, "all", comm=comm, reuse=True)
+        kept_again, _ = pdist.assemble_rows(rows, counts, LIMIT, None, "all", comm=comm, reuse=True)
+        assert kept.data_ptr() == kept_again.data_ptr() and torch.equal(kept_again, rows)
     finally:
         comm.close()
 
@@ -146,7 +152,7 @@ def _rccl_worker(rank, world, port, name, n, mode, result_dir):
         comm = pdist.LibraryComm.from_group(group, device)
         try:
             for repeat in range(2):  # the second pass runs on the communicator's reused buffers
-                full, full_counts = pdist.assemble_rows(rows, counts, LIMIT, group, mode, comm=comm)
+                full, full_counts = pdist.assemble_rows(rows, counts, LIMIT, group, mode, comm=comm, reuse=True)
             assert full.is_cuda and full.device == device
             torch.cuda.synchronize(device)
         finally:
