@@ -195,20 +195,24 @@ extern "C" int64_t prt_place_workspace_bytes(int world, int limit) {
 
 static int place_rows(int device, const double* staging, int64_t stride_rank, int64_t stride_col, int world,
                       const PlaceTables& t, double* out, int64_t ld_out, void* workspace, hipStream_t st) {
-  (void)device;
   if (t.total == 0) return PRT_OK;
   int64_t* tables = (int64_t*)workspace;
   // The source of an asynchronous copy has to stay as it is until the copy has run: the tables go through
-  // a small ring of page-locked blocks per host thread, each guarded by an event recorded behind its copy
-  // (a block is only written again once that event has passed -- any number of calls may be in flight).
+  // a small ring of page-locked blocks per host thread and device (an event belongs to the device it was
+  // made on), each guarded by an event recorded behind its copy (a block is only written again once that
+  // event has passed -- any number of calls may be in flight).
   struct Staging {
     int64_t* block = nullptr;
     size_t words = 0;
     hipEvent_t copied = nullptr;
   };
-  static thread_local Staging ring[4];
-  static thread_local unsigned turn = 0;
-  Staging& stage = ring[turn++ % 4];
+  struct Ring {
+    Staging slot[4];
+    unsigned turn = 0;
+  };
+  static thread_local std::unordered_map<int, Ring> rings;
+  Ring& ring = rings[device];
+  Staging& stage = ring.slot[ring.turn++ % 4];
   if (stage.copied) HIP_TRY(hipEventSynchronize(stage.copied));
   if (stage.words < t.host.size()) {
     if (stage.block) HIP_TRY(hipHostFree(stage.block));
