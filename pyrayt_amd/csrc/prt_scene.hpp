@@ -734,6 +734,65 @@ static void compile_trace_program(prt_scene* s) {
   prog.mirror_steps = mirror_steps;
 }
 
+// Walk a compiled trace program the way the interpreter does (nearest_hit_n) and check what the kernels take
+// for granted: every jump lands on the start of a step inside its own region, a chain record is never cut,
+// and each direction of the program yields exactly one candidate per component.  A compiler bug then is an
+// error from prt_scene_create, not a wave reading steps from beyond the table.
+static const char* verify_trace_program(const prt_scene* s) {
+  const std::vector<DevInstr>& code = s->trace_program.code;
+  const int size = (int)code.size(), mirror = s->trace_program.mirror_steps, n = (int)s->roots.size();
+  if (mirror < 0 || mirror > size) return "mirror image longer than the program";
+  std::vector<char> starts((size_t)size + 1, 0);
+  for (int pc = 0; pc < size; ++pc) {
+    starts[pc] = 1;
+    if (code[pc].kind == I_CHAIN) {
+      if (pc + CHAIN_SLOTS > size) return "a chain record runs past the end";
+      pc += CHAIN_SLOTS - 1;
+    }
+  }
+  starts[size] = 1;
+  struct Region { int from, to; };
+  std::vector<Region> regions;
+  if (mirror > 0) {
+    if (mirror < 2 || code[0].kind != I_BOX || code[0].a1 != BOX_PICK || code[mirror - 1].kind != I_BOX ||
+        code[mirror - 1].a1 != BOX_JUMP)
+      return "a program in both directions without its PICK / JUMP frame";
+    if (code[0].a0 + 1 != mirror || mirror - 1 + code[mirror - 1].a0 + 1 != size) return "PICK / JUMP land in the wrong place";
+    if ((code[0].a2 & 3) > 2) return "PICK without an axis";
+    regions.push_back({1, mirror - 1});
+  }
+  regions.push_back({mirror, size});
+  for (const Region& r : regions) {
+    int candidates = 0;
+    for (int pc = r.from; pc < r.to; ++pc) {
+      if (!starts[pc]) return "a step inside a chain record";
+      const DevInstr& in = code[pc];
+      if (in.kind == I_CHAIN) {
+        candidates += 1;
+        pc += CHAIN_SLOTS - 1;
+      } else if (in.kind == I_BOX) {
+        if (in.a1 != BOX_TEST) return "a PICK / JUMP step inside a program";
+        const int target = pc + in.a0 + 1;
+        if (in.a0 < 1 || target > r.to || !starts[target]) return "a cull step jumps out of its region or into a record";
+      } else if (in.kind == I_LEAF) {
+        candidates += in.pad[0] == 2 ? 1 : 0;
+      } else if (in.kind == I_CSG) {
+        candidates += in.pad[0] == 1 ? 1 : 0;
+      } else if (in.kind == I_ROOT) {
+        candidates += 1;
+      } else {
+        return "a step of unknown kind";
+      }
+    }
+    if (candidates != n) return "a direction of the program does not yield one candidate per component";
+  }
+  for (int c = 0; c < n; ++c) {
+    const int from = s->trace_program.component_first[2 * c], to = s->trace_program.component_first[2 * c + 1];
+    if (from < mirror || to > size || from >= to || !starts[from] || !starts[to]) return "a component's step range is off";
+  }
+  return nullptr;
+}
+
 static int validate_tree(const prt_scene* s, int node, int depth, std::vector<char>& seen) {
   if (node < 0 || node >= (int)s->nodes.size() || depth > 64 || seen[node]) return PRT_ERR_SCENE;
   seen[node] = 1;
@@ -815,6 +874,11 @@ extern "C" int prt_scene_create(const prt_prim* prims, int n_prims, const prt_no
     s->dev_prims.push_back(d);
   }
   compile_trace_program(s);
+  if (const char* wrong = verify_trace_program(s)) {
+    const std::string message = std::string("internal error, the compiled trace program is malformed: ") + wrong;
+    delete s;
+    return fail(PRT_ERR_SCENE, message);
+  }
   s->has_cull_steps = count_steps(s->trace_program.code, I_BOX) > 0;
   for (int r : s->roots) {
     compile_component(s, r, s->render_program.code, ROOT_RENDER, &s->render_program.lds_slots);

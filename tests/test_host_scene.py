@@ -343,3 +343,41 @@ def test_scene_options_are_validated_and_versioned():
     short[0] = 0  # struct_size not set
     assert lib.prt_scene_create(prims.ctypes.data, len(prims), nodes.ctypes.data, len(nodes), roots.ctypes.data, len(roots),
                                 mats.ctypes.data, len(mats), short.ctypes.data, ctypes.byref(handle)) == -1
+
+
+def test_every_compiled_program_passes_the_library_own_walk():
+    """prt_scene_create walks the trace program it compiled the way the kernels will (every jump lands on a
+    step of its own region, no chain record is cut, each direction yields one candidate per component) and
+    refuses a scene whose program fails: crowds of random parts at random places, under every option."""
+    import numpy as np
+
+    import scenes
+    from pyrayt_amd import engine
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    api = scenes.product_api()
+    switches = ("no_chain", "no_cull", "no_groups", "no_implied", "list_order_groups", "one_direction")
+    seen_groups = seen_mirror = 0
+    for seed in range(120):
+        rng = np.random.default_rng(9000 + seed)
+        CountedObject.reset_ids()
+        parts = []
+        for _ in range(int(rng.choice([1, 2, 3, 5, 8, 9, 16, 17, 33, 40]))):
+            if rng.random() < 0.5:
+                part = api.components.biconvex_lens(4, 4, 0.25, aperture=1)
+            else:
+                part = scenes.random_component(rng, api.cg, api.materials, depth=int(rng.integers(0, 4)))
+            spread = 10.0 ** rng.uniform(0.0, 1.5)
+            part.move(*(rng.uniform(-spread, spread, 3) * np.array([1.0, rng.random() < 0.5, rng.random() < 0.5])))
+            parts.append(part)
+        options = {name: 1 for name in switches if rng.random() < 0.2}
+        if rng.random() < 0.2:
+            options["cull_min"] = int(rng.integers(1, 12))
+        scene = engine.DeviceScene(SceneSnapshot(parts), options=options)     # raises if the walk fails
+        info = scene.info()
+        assert info["components"] == len(parts) and info["trace_steps"] >= len(parts)
+        seen_groups += info["spatial_groups"]
+        seen_mirror += info["both_directions"]
+        scene.close()
+    assert seen_groups > 5 and seen_mirror > 10      # the forms the walk is there for did come up
