@@ -23,8 +23,8 @@ kernel inside the library, pyrayt_amd/csrc/prt_gather.hpp) is timed separately a
 region and reported under "gather" and "value_with_gather" -- it is not part of `value`.
 
 The timed steps are issued with 2-3 traces in flight, each ticket of the library on its own HIP stream
-(prt_trace_begin / prt_trace_end): the host enqueues ahead and the kernels of different traces overlap on
-the device.  `value` is that throughput.  The kernel's own launch duration -- what `roofline` prices --
+(prt_trace_batch: the loop over prt_trace_begin / prt_trace_end, run by the library; --python-loop runs it
+from here): the host enqueues ahead and the kernels of different traces overlap on the device.  `value` is that throughput.  The kernel's own launch duration -- what `roofline` prices --
 is measured on one stream, same steps, right behind the timed region (`roofline.measured_on`);
 `roofline.device_aggregate` says what the whole device sustains while the traces overlap.
 
@@ -520,7 +520,7 @@ def main():
                          else f": {n_job} rays per GPU (weak scaling)") +
                         f", generation_limit {limit}, rays resident in HBM; the timed step is a REPEATED "
                         "IDENTICAL trace: dense-mode hints of the previous trace active, first batch sized by it" +
-                        {"overlap": f", {depth} traces in flight on {depth} HIP streams (prt_trace_begin / prt_trace_end): the "
+                        {"overlap": f", {depth} traces in flight on {depth} HIP streams (prt_trace_batch = prt_trace_begin / prt_trace_end per trace): the "
                                     "host enqueues ahead and the kernels of different traces overlap on the device",
                          "one_stream": ", one trace kept in flight on the same stream while the previous one's counts are "
                                        "collected (prt_trace_begin / prt_trace_end)",

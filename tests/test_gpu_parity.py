@@ -32,24 +32,7 @@ def dev(array):
     return torch.from_numpy(np.ascontiguousarray(array, dtype=np.float64)).to("cuda:0")
 
 
-class FixtureSnapshot:
-    """Adapter: a fixture's plain-array scene -> the structured arrays DeviceScene uploads."""
-
-    def __init__(self, scene):
-        from pyrayt_amd.scene import MATERIAL_DTYPE, NODE_DTYPE, PRIM_DTYPE
-
-        p = np.zeros(len(scene["prim_type"]), dtype=PRIM_DTYPE)
-        p["type"], p["material"] = scene["prim_type"], scene["prim_material"]
-        p["normal_scale"], p["surface_id"] = scene["prim_normal_scale"], scene["prim_surface_id"]
-        p["params"], p["minv"] = scene["prim_params"], scene["prim_minv"]
-        n = np.zeros(len(scene["node_op"]), dtype=NODE_DTYPE)
-        n["op"], n["left"], n["right"] = scene["node_op"], scene["node_left"], scene["node_right"]
-        n["prim"], n["aabb"] = scene["node_prim"], scene["node_aabb"]
-        m = np.zeros(max(1, len(scene["mat_kind"])), dtype=MATERIAL_DTYPE)
-        m["kind"][: len(scene["mat_kind"])] = scene["mat_kind"]
-        m["coef"][: len(scene["mat_kind"])] = scene["mat_coef"]
-        self.prims, self.nodes, self.materials = p, n, m
-        self.roots = scene["roots"].astype(np.int32)
+FixtureSnapshot = helpers.FixtureSnapshot  # (kept importable from here: the render tests and tools take it from this module)
 
 
 def device_scene(scene_dict, options=None):
