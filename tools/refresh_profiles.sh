@@ -34,6 +34,7 @@ cp gpurun_out/traffic/bench_WRITE_SIZE_counter_collection.csv $out/k_generation_
 cp gpurun_out/traffic/cal_FETCH_SIZE_counter_collection.csv $out/calibration_pmc_FETCH_SIZE.csv
 cp gpurun_out/traffic/cal_WRITE_SIZE_counter_collection.csv $out/calibration_pmc_WRITE_SIZE.csv
 python3 tools/shard_scaling.py > $out/shard_scaling.txt 2>&1
+{ echo; python3 tools/c_host_bench.py 2>&1 | grep -v amdgpu.ids; } >> $out/shard_scaling.txt
 python3 tools/slow_paths.py 2>&1 | grep -v amdgpu.ids > $out/slow_paths.txt
 { echo "# tools/cull_scaling.py (lens train listed along the axis)"; python3 tools/cull_scaling.py --counts 1 2 4 8 16 32 2>&1 | grep -v amdgpu.ids;
   echo; echo "# tools/cull_scaling.py --shuffle (lenses listed in random order, beams from both ends)"; python3 tools/cull_scaling.py --shuffle --counts 8 32 2>&1 | grep -v amdgpu.ids; } > $out/cull_scaling.txt
