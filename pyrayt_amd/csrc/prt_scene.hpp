@@ -83,6 +83,7 @@ struct DeviceCopy {
   DevInstr* render_code = nullptr;              // same with the renderers' selection rule
   std::vector<DevInstr*> component_code;        // one program per component, no I_ROOT
   TraceTicket ticket[PRT_TRACE_TICKETS];
+  bool ready = false;                           // everything above is in place (a copy whose upload failed half way is not)
 };
 
 struct prt_scene {
@@ -896,6 +897,22 @@ extern "C" int prt_scene_create(const prt_prim* prims, int n_prims, const prt_no
   return PRT_OK;
 }
 
+// give back whatever a device copy holds (the device is current)
+static void release_device_copy(DeviceCopy& c) {
+  (void)hipFree(c.prims);
+  (void)hipFree(c.trace_code);
+  (void)hipFree(c.trace_component_first);
+  (void)hipFree(c.render_code);
+  for (DevInstr* p : c.component_code) (void)hipFree(p);
+  for (TraceTicket& t : c.ticket) {
+    if (t.host_pinned) (void)hipHostFree(t.host_pinned);
+    if (t.mirror) (void)hipHostFree(t.mirror);
+    if (t.ev0) (void)hipEventDestroy(t.ev0);
+    if (t.ev1) (void)hipEventDestroy(t.ev1);
+  }
+  c = DeviceCopy();
+}
+
 extern "C" void prt_scene_destroy(prt_scene* s) {
   if (!s) return;
   for (size_t d = 0; d < s->per_device.size(); ++d) {
@@ -905,17 +922,7 @@ extern "C" void prt_scene_destroy(prt_scene* s) {
     // a trace that was begun and never ended, or one whose counts are out while its last stores are not,
     // still reads the tables and writes the host mirror freed below
     (void)hipDeviceSynchronize();
-    (void)hipFree(c.prims);
-    (void)hipFree(c.trace_code);
-    (void)hipFree(c.trace_component_first);
-    (void)hipFree(c.render_code);
-    for (DevInstr* p : c.component_code) (void)hipFree(p);
-    for (TraceTicket& t : c.ticket) {
-      if (t.host_pinned) (void)hipHostFree(t.host_pinned);
-      if (t.mirror) (void)hipHostFree(t.mirror);
-      if (t.ev0) (void)hipEventDestroy(t.ev0);
-      if (t.ev1) (void)hipEventDestroy(t.ev1);
-    }
+    release_device_copy(c);
   }
   delete s;
 }
@@ -952,7 +959,7 @@ extern "C" int prt_scene_update(prt_scene* s, const prt_prim* prims, int n_prims
   }
   for (size_t d = 0; d < s->per_device.size(); ++d) {
     DeviceCopy& c = s->per_device[d];
-    if (!c.prims) continue;
+    if (!c.ready) continue;
     HIP_TRY(hipSetDevice((int)d));
     HIP_TRY(hipDeviceSynchronize());  // the last trace may still be draining: it reads these tables
     auto put = [](void* dst, const void* src, size_t bytes) {
@@ -1026,7 +1033,8 @@ static int on_device(prt_scene* s, int device, DeviceCopy** out) {
   HIP_TRY(hipSetDevice(device));
   if ((int)s->per_device.size() <= device) s->per_device.resize(device + 1);
   DeviceCopy& c = s->per_device[device];
-  if (!c.prims) {
+  if (!c.ready) {
+    release_device_copy(c);  // (what an earlier attempt that failed half way left behind)
     int rc = upload(&c.prims, s->dev_prims);
     if (rc) return rc;
     rc = upload(&c.trace_code, s->trace_program.code);
@@ -1051,6 +1059,7 @@ static int on_device(prt_scene* s, int device, DeviceCopy** out) {
     }
     int rc_lds = raise_lds_limits();
     if (rc_lds) return rc_lds;
+    c.ready = true;
   }
   *out = &c;
   return PRT_OK;
