@@ -1193,3 +1193,23 @@ def test_a_ticket_keeps_no_stale_workspace_after_a_larger_trace_grew_it():
     assert counts == want_counts and torch.equal(rows, want)
     assert all(int(f.min()) == 7 for f in filler)         # nobody wrote through a stale pointer
     ds.close()
+
+
+@pytest.mark.parametrize("flags", [engine.TRACE_UNFUSED, engine.TRACE_NO_HINTS, engine.TRACE_FULL_ROWS | engine.TRACE_SYNC,
+                                   engine.TRACE_KEEP_ABSORBED, engine.TRACE_COUNT_PATHS])
+def test_trace_batch_under_the_trace_flags(flags):
+    """The batch entry hands its flags to every trace: the three-kernel path (collected synchronously in
+    prt_trace_end), no hints, all 13 state rows, upstream's bookkeeping of absorbed rays, the counting build."""
+    fx = helpers.load("scene_mirrors_and_stops.npz")
+    limit = int(fx["generation_limit"])
+    ds = device_scene(helpers.scene_of(fx))
+    rays = dev(fx["rays0"])
+    want, want_counts = ds.trace(rays, limit)
+    want = want.clone()
+    got = ds.trace_batch([rays] * 5, limit, depth=2, flags=flags)
+    torch.cuda.synchronize()
+    for rows, counts in got:
+        assert counts == want_counts
+        assert torch.equal(rows, want)
+    helpers.assert_frames_match(want.cpu().numpy().T, fx["frame"], what="mirrors_and_stops")
+    ds.close()
