@@ -272,15 +272,17 @@ def box_touches(aabb, rays):
 
 def node_hits(scene, node, rays):
     """(hits (m,n), ids (m,n)) of a component subtree; ids are surface ids where the hit is
-    finite and -1 elsewhere (the reference leaves arbitrary carried ids at +inf entries; they
-    are never consumed, _pyrayt.py:380-386)."""
+    not +inf and -1 there (the reference leaves arbitrary carried ids at +inf entries; they
+    are never consumed, _pyrayt.py:380-386).  A -inf entry -- a slab or linear branch that holds
+    the whole line -- keeps its id: the tracer discards it with every hit <= 0, but the renderers'
+    rule can select it (renderers.py:79-83), and the reference then reports that surface."""
     op = int(scene["node_op"][node])
     n = rays.shape[-1]
     if op == LEAF:
         p = int(scene["node_prim"][node])
         with np.errstate(invalid="ignore", divide="ignore"):
             hits = surface_hits(scene, p, rays)
-        ids = np.where(np.isfinite(hits), scene["prim_surface_id"][p], -1).astype(np.int64)
+        ids = np.where(hits < INF, scene["prim_surface_id"][p], -1).astype(np.int64)
         return hits, ids
     touched = box_touches(scene["node_aabb"][node], rays)
     sub = rays[:, :, touched]
@@ -291,7 +293,7 @@ def node_hits(scene, node, rays):
     ids = np.vstack((l_ids, r_ids))[order, cols]
     final = np.argsort(values, axis=0, kind="stable")
     values = values[final, cols]
-    ids = np.where(np.isfinite(values), ids[final, cols], -1)
+    ids = np.where(values < INF, ids[final, cols], -1)
     m = values.shape[0]
     hits_all = np.full((m, n), INF)
     ids_all = np.full((m, n), -1, dtype=np.int64)

@@ -49,7 +49,7 @@ enum { I_LEAF = 0, I_CSG = 1, I_ROOT = 2, I_BOX = 3, I_CHAIN = 4 };
 //   BOX_PICK  does the wave mostly run AGAINST the program's axis (a2)?  the mirror image follows; if not,
 //             jump over it to the program proper
 //   BOX_JUMP  nothing is wanted: the end of the mirror image, over the program proper
-enum { BOX_TEST = 0, BOX_PICK = 1, BOX_JUMP = 2 };
+enum { BOX_TEST = 0, BOX_PICK = 1, BOX_JUMP = 2, BOX_LINE = 3 };  // (LINE: render programs, see may_reach)
 enum { OPER_REGA = 0, OPER_REGB = 1, OPER_LDS = 2 };
 enum { CSG_UNION = 1, CSG_INTERSECT = 2, CSG_DIFFERENCE = 3 };
 enum { PRIM_SPHERE = 0, PRIM_CYLINDER = 1, PRIM_PLANE = 2, PRIM_CUBE = 3, PRIM_PARABOLOID = 4 };
@@ -948,8 +948,12 @@ __device__ __forceinline__ void csg_step(const DevInstr* __restrict__ in, const 
 // surfaces, so "no" means the component cannot change the running nearest hit: a tie with best_t
 // keeps the earlier component (_pyrayt.py:384), a larger value loses.  The test only ever errs
 // towards "yes": reciprocal by v_rcp_f64 with a 1e-6 relative allowance, NaN compares false.
+// LINE (render programs): does the whole LINE of the ray meet the box?  The renderers' rule lets a
+// component with no positive hit offer its first entry, a parameter behind the camera (renderers.py:79-83),
+// so only a component whose list holds no finite entry at all may be skipped: one whose box the line misses.
+template <bool LINE = false>
 __device__ __forceinline__ bool may_reach(const double* __restrict__ box, const Ray8& r, double best_t) {
-  double t_in = 0.0, t_out = best_t;
+  double t_in = LINE ? -PRT_INF : 0.0, t_out = LINE ? PRT_INF : best_t;
   bool never = false;
   const double o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
   // (asked only for well-formed rays: with a direction so short that a leaf of the component may take one
@@ -964,6 +968,7 @@ __device__ __forceinline__ bool may_reach(const double* __restrict__ box, const 
     t_in = parallel ? t_in : fmax(t_in, fmin(a, b));
     t_out = parallel ? t_out : fmin(t_out, fmax(a, b));
   }
+  if (LINE && (t_in == -PRT_INF || t_out == PRT_INF)) return !never;  // parallel to every slab: inside all of them or not
   const double slack = 1e-6 * (fabs(t_in) + fabs(t_out));
   return !never && !(t_in - slack > t_out + slack);
 }
@@ -1187,6 +1192,13 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
       }
     }
     const DevInstr step = code[pc];  // the whole record, one batch of scalar loads
+    if (CULL && RENDER && step.kind == I_BOX) {  // render programs: a component whose box the line of sight misses
+      bool wanted = false;
+#pragma unroll
+      for (int k = 0; k < R; ++k) wanted = wanted || !well_formed(ray[k]) || may_reach<true>(step.data, ray[k], PRT_INF);
+      if (__ballot(wanted) == 0ull) pc += step.a0;
+      continue;
+    }
     if (CULL && !RENDER && step.kind == I_BOX) {
       if (step.a1 != BOX_TEST) {  // (uniform) the frame of a program that is stored in both directions
         bool jump = true;

@@ -464,8 +464,12 @@ static Operand compile_component(const prt_scene* s, int root_node, std::vector<
   size_t box_at = (size_t)-1;
   const bool cull_off = s->options.no_cull != 0;  // A/B and test knobs (prt_scene_options)
   const int cull_min = s->options.cull_min > 0 ? s->options.cull_min : 3;
-  if (root_rule == ROOT_TRACE && (int)s->roots.size() >= cull_min && !cull_off) {
+  // render programs: every component behind a LINE test (the pictures' rays are coherent and most of a picture
+  // is background or another part: a wave whose lines of sight all miss a part's box skips the part)
+  const bool line_cull = root_rule == ROOT_RENDER && !cull_off;
+  if ((root_rule == ROOT_TRACE && (int)s->roots.size() >= cull_min && !cull_off) || line_cull) {
     DevInstr in = Compiler::blank(I_BOX);
+    in.a1 = line_cull ? BOX_LINE : BOX_TEST;
     double* box = in.data;
     // (a cull step argues about well-formed rays only; a component so large in object space that even
     // a unit direction may be "short" to one of its leaves -- short_direction_bound -- gets none)

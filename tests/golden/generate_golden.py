@@ -616,9 +616,55 @@ def render_vectors():
     print(f"render               -> {os.path.basename(path)} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def render_ray_vectors(seeds=range(12)):
+    """The renderers' nearest-hit rule (tinygfx/g3d/renderers.py:70-90, the reference's own _st_propagate) for
+    arbitrary rays over crowds of random parts (tests/scenes.py render_ray_case): what it selects when no entry is
+    positive -- a parameter behind the origin, or the -inf entry of a slab / linear branch -- and whose id it reports."""
+    import tinygfx.g3d.renderers as ref_render
+
+    out = {}
+    for seed in seeds:
+        runs = []
+        for stable in (False, True):
+            ref_csg.np = _StableNumpy() if stable else np
+            try:
+                reset_ids()
+                parts, rays = scenes.render_ray_case(API, seed)
+                renderer = ref_render.EdgeRender(None, parts)
+                renderer._rays = rays.reshape(2, 4, -1).copy()
+                with np.errstate(all="ignore"):
+                    renderer._st_propagate()
+                res = {"rays": rays, "t": renderer._hit_distances.copy(), "surf": renderer._hit_surfaces.astype(np.int64)}
+                res.update(snapshot(parts))
+            finally:
+                ref_csg.np = np
+            runs.append(res)
+        b, a = runs
+        # kept: the rays on which the default and the stable argsort agree (ties between coincident surfaces are
+        # upstream's to break), of those every ray of the degenerate families, every ray whose pick is not a
+        # positive parameter, and a seeded sample of the rest
+        same = np.array([np.array_equal(a["t"][k], b["t"][k], equal_nan=True) and a["surf"][k] == b["surf"][k]
+                         for k in range(len(a["t"]))])
+        odd = np.zeros(len(same), dtype=bool)
+        odd[:460] = True
+        odd |= ~(a["t"] > 0)
+        odd |= np.random.default_rng(seed).random(len(same)) < 0.1
+        keep = np.nonzero(same & odd)[0]
+        a["rays"], a["t"], a["surf"] = np.ascontiguousarray(a["rays"][:, keep]), a["t"][keep], a["surf"][keep]
+        assert all(np.array_equal(a[k], b[k], equal_nan=True) for k in a if k not in ("rays", "t", "surf")), seed
+        for k, v in a.items():
+            out[f"case{seed}__{k}"] = v
+        print(f"  render rays {seed:2d}: {len(a['roots'])} parts, {len(keep)} rays kept ({int((~same).sum())} argsort-sensitive dropped), "
+              f"{int((a['surf'] >= 0).sum())} hit, {int(np.isneginf(a['t']).sum())} at -inf, "
+              f"{int(((a['t'] < 0) & np.isfinite(a['t'])).sum())} behind")
+    path = os.path.join(HERE, "render_rays.npz")
+    np.savez_compressed(path, **out)
+    print(f"render rays          -> {os.path.basename(path)} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 def main():
     which = set(sys.argv[1:]) or {"scenes", "primitives", "csg", "shading", "sources", "summary", "render", "operations", "raw",
-                                  "adversarial", "stale"}
+                                  "adversarial", "stale", "render_rays"}
     print(f"numpy {np.__version__} pandas {pd.__version__} (reference locks numpy 1.20.2 / pandas 1.2.4)")
     if "scenes" in which:
         scene_fixture("config1", 100, 1000)
@@ -648,6 +694,8 @@ def main():
         config2_summary()
     if "render" in which:
         render_vectors()
+    if "render_rays" in which:
+        render_ray_vectors()
     if "operations" in which:
         operations_vectors()
     if "raw" in which:

@@ -765,3 +765,23 @@ SCENES = {
     "adv_bench_b": adv_bench_b,
     "adv_bench_c": adv_bench_c,
 }
+
+
+def render_ray_case(api, seed, n=6000):
+    """A crowd of random parts and arbitrary lines of sight for the renderers' nearest-hit rule (fixture
+    render_rays.npz and its tests): rays from everywhere, a parallel bundle, and the degenerate families --
+    short directions (the slab / linear branches then report -inf entries, which this rule can select),
+    w other than 1 / 0, zero directions."""
+    rng = np.random.default_rng(4200 + seed)
+    parts = []
+    for _ in range(int(rng.integers(1, 9))):
+        part = random_component(rng, api.cg, api.materials, depth=int(rng.integers(0, 3)))
+        part.scale(*rng.uniform(0.3, 1.2, 3)).move(*rng.uniform(-3.0, 3.0, 3))
+        parts.append(part)
+    rays = random_rays(n, seed=8000 + seed, box=5.0, wavelength=0.55)[:8]
+    rays[4:7, 100:400] *= 10.0 ** rng.uniform(-9.0, 1.0, 300)
+    rays[3, 400:420] = rng.uniform(0.3, 3.0, 20)
+    rays[7, 420:440] = 10.0 ** rng.uniform(-6.0, -1.0, 20)
+    rays[4:7, 440:460] = 0.0
+    rays[4:7, n // 2:] = np.array([[0.0], [1.0], [0.0]])
+    return parts, np.ascontiguousarray(rays)

@@ -202,7 +202,8 @@ def test_compiled_programs_carry_cull_steps_only_for_three_or_more_components():
         assert info["chain_steps"] == csg_parts, name
         assert info["trace_steps"] == 3 * csg_parts + (components - csg_parts) + culls, name
         # render programs: one step per leaf and per CSG node plus a root step per CSG component
-        assert info["render_steps"] == (2 * prims - components) + csg_parts, name
+        # ... behind one line-of-sight cull step per component
+        assert info["render_steps"] == (2 * prims - components) + csg_parts + components, name
 
 
 def test_coordinate_helpers_like_upstream():

@@ -3,6 +3,7 @@
 import numpy as np
 import pytest
 
+import helpers
 from helpers import load, scene_of
 from oracle import render_oracle as ro
 
@@ -72,3 +73,19 @@ def test_wavelength_colours(fx):
     w = fx["utils__wavelengths"]
     assert np.array_equal(ro.wavelength_to_rgb(w), fx["utils__rgb"])
     assert np.array_equal(ro.wavelength_to_rgb(w, gamma=1.7), fx["utils__rgb_gamma"])
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_nearest_hits_of_arbitrary_rays_match_the_reference(case):
+    """The renderers' rule for arbitrary rays, degenerate families included (fixture render_rays.npz): which entry it
+    selects when none is positive, and whose id it reports for a -inf entry (the reference: the surface's own)."""
+    fx = helpers.load("render_rays.npz")
+    prefix = f"case{case}__"
+    rays = np.ascontiguousarray(fx[prefix + "rays"]).reshape(2, 4, -1)
+    with np.errstate(all="ignore"):
+        t, surf = ro.nearest_hits(helpers.scene_of(fx, prefix), rays)
+    want_t, want_surf = fx[prefix + "t"], fx[prefix + "surf"]
+    assert np.array_equal(surf, want_surf)
+    finite = np.isfinite(want_t)
+    assert np.array_equal(np.isfinite(t), finite) and np.array_equal(np.isneginf(t), np.isneginf(want_t))
+    assert np.allclose(t[finite], want_t[finite], rtol=0, atol=helpers.ATOL)
