@@ -124,7 +124,7 @@ int prt_device_count(void);
 typedef struct prt_scene_options {
   int32_t struct_size;  /* sizeof(prt_scene_options) as the caller knows it */
   int32_t no_chain;     /* 1: components run on the step interpreter, none as a register-only chain step */
-  int32_t no_cull;      /* 1: no component cull steps in the trace program */
+  int32_t no_cull;      /* 1: no component cull steps in the trace program, no line-of-sight steps in the render program */
   int32_t cull_min;     /* components from which cull steps are compiled in (0 = the default, 3) */
   int32_t no_groups;    /* 1: no hierarchy of cull steps over groups of components */
   int32_t no_implied;   /* 1: every CSG node evaluates upstream's cull box (csg.py:126-128) exactly */
