@@ -630,13 +630,17 @@ static double group_cost(const std::vector<ComponentBox>& boxes, const Group& g)
   return cost;
 }
 
-static void emit_groups(prt_scene* s, const std::vector<ComponentBox>& boxes, const Group& g, bool mirrored) {
-  Program& prog = s->trace_program;
+// (root_rule ROOT_TRACE: into the trace program; ROOT_RENDER: into the render program, whose group steps test
+// the LINE of the ray like its component steps, see compile_component)
+static void emit_groups(prt_scene* s, const std::vector<ComponentBox>& boxes, const Group& g, bool mirrored,
+                        int root_rule = ROOT_TRACE) {
+  const bool tracing = root_rule == ROOT_TRACE;
+  Program& prog = tracing ? s->trace_program : s->render_program;
   if (g.kids.empty()) {
     for (int c : g.comps) {  // (one component)
-      if (!mirrored) prog.component_first[2 * c] = (int32_t)prog.code.size();
-      compile_component(s, s->roots[c], prog.code, ROOT_TRACE, &prog.lds_slots);
-      if (!mirrored) prog.component_first[2 * c + 1] = (int32_t)prog.code.size();
+      if (!mirrored && tracing) prog.component_first[2 * c] = (int32_t)prog.code.size();
+      compile_component(s, s->roots[c], prog.code, root_rule, &prog.lds_slots);
+      if (!mirrored && tracing) prog.component_first[2 * c + 1] = (int32_t)prog.code.size();
     }
     return;
   }
@@ -645,6 +649,7 @@ static void emit_groups(prt_scene* s, const std::vector<ComponentBox>& boxes, co
     size_t box_at = (size_t)-1;
     if (kid.boxed) {  // a sub-group of several components: its own cull step in front
       DevInstr in = Compiler::blank(I_BOX);
+      in.a1 = tracing ? BOX_TEST : BOX_LINE;
       if (union_box(boxes, kid.comps, in.data)) {
         pad_box(in.data);
         box_at = prog.code.size();
@@ -652,7 +657,7 @@ static void emit_groups(prt_scene* s, const std::vector<ComponentBox>& boxes, co
       }
     }
     const size_t from = prog.code.size();
-    emit_groups(s, boxes, kid, mirrored);
+    emit_groups(s, boxes, kid, mirrored, root_rule);
     if (box_at != (size_t)-1) prog.code[box_at].a0 = (int)(prog.code.size() - from);
   }
 }
@@ -743,9 +748,10 @@ static void compile_trace_program(prt_scene* s) {
 // for granted: every jump lands on the start of a step inside its own region, a chain record is never cut,
 // and each direction of the program yields exactly one candidate per component.  A compiler bug then is an
 // error from prt_scene_create, not a wave reading steps from beyond the table.
-static const char* verify_trace_program(const prt_scene* s) {
-  const std::vector<DevInstr>& code = s->trace_program.code;
-  const int size = (int)code.size(), mirror = s->trace_program.mirror_steps, n = (int)s->roots.size();
+static const char* verify_program(const prt_scene* s, const Program& program, bool tracing) {
+  const std::vector<DevInstr>& code = program.code;
+  const int size = (int)code.size(), mirror = program.mirror_steps, n = (int)s->roots.size();
+  const int box_kind = tracing ? BOX_TEST : BOX_LINE;  // (a render program's steps test the line of the ray)
   if (mirror < 0 || mirror > size) return "mirror image longer than the program";
   std::vector<char> starts((size_t)size + 1, 0);
   for (int pc = 0; pc < size; ++pc) {
@@ -776,7 +782,7 @@ static const char* verify_trace_program(const prt_scene* s) {
         candidates += 1;
         pc += CHAIN_SLOTS - 1;
       } else if (in.kind == I_BOX) {
-        if (in.a1 != BOX_TEST) return "a PICK / JUMP step inside a program";
+        if (in.a1 != box_kind) return "a cull step of the wrong kind (PICK / JUMP inside a program, or the other program's test)";
         const int target = pc + in.a0 + 1;
         if (in.a0 < 1 || target > r.to || !starts[target]) return "a cull step jumps out of its region or into a record";
       } else if (in.kind == I_LEAF) {
@@ -791,11 +797,28 @@ static const char* verify_trace_program(const prt_scene* s) {
     }
     if (candidates != n) return "a direction of the program does not yield one candidate per component";
   }
-  for (int c = 0; c < n; ++c) {
-    const int from = s->trace_program.component_first[2 * c], to = s->trace_program.component_first[2 * c + 1];
+  for (int c = 0; tracing && c < n; ++c) {
+    const int from = program.component_first[2 * c], to = program.component_first[2 * c + 1];
     if (from < mirror || to > size || from >= to || !starts[from] || !starts[to]) return "a component's step range is off";
   }
   return nullptr;
+}
+
+// The render program: every component behind its line-of-sight step, and from kGroupMinComponents components on
+// the same hierarchy of group steps as the trace program -- in LIST ORDER only: the renderers keep the first
+// component among equal parameters (renderers.py:84, strict '<'), and their programs have no lexicographic
+// running minimum that would let the visit leave that order.
+static void compile_render_program(prt_scene* s) {
+  const int n = (int)s->roots.size();
+  if (n == 0) return;
+  const bool grouped = n >= kGroupMinComponents && !s->options.no_cull && !s->options.no_groups;
+  std::vector<ComponentBox> boxes(n);
+  std::vector<int> all(n);
+  for (int c = 0; c < n; ++c) {
+    all[c] = c;
+    boxes[c].ok = solid_bounds(s, s->roots[c], boxes[c].box) && short_direction_bound(s, s->roots[c]) <= kWellFormedLen2Lo;
+  }
+  emit_groups(s, boxes, build_groups(boxes, all, grouped, false), false, ROOT_RENDER);
 }
 
 static int validate_tree(const prt_scene* s, int node, int depth, std::vector<char>& seen) {
@@ -879,14 +902,19 @@ extern "C" int prt_scene_create(const prt_prim* prims, int n_prims, const prt_no
     s->dev_prims.push_back(d);
   }
   compile_trace_program(s);
-  if (const char* wrong = verify_trace_program(s)) {
+  if (const char* wrong = verify_program(s, s->trace_program, true)) {
     const std::string message = std::string("internal error, the compiled trace program is malformed: ") + wrong;
     delete s;
     return fail(PRT_ERR_SCENE, message);
   }
   s->has_cull_steps = count_steps(s->trace_program.code, I_BOX) > 0;
+  compile_render_program(s);
+  if (const char* wrong = verify_program(s, s->render_program, false)) {
+    const std::string message = std::string("internal error, the compiled render program is malformed: ") + wrong;
+    delete s;
+    return fail(PRT_ERR_SCENE, message);
+  }
   for (int r : s->roots) {
-    compile_component(s, r, s->render_program.code, ROOT_RENDER, &s->render_program.lds_slots);
     Program p;
     Operand res = compile_component(s, r, p.code, ROOT_NONE, &p.lds_slots);
     s->component_programs.push_back(p);

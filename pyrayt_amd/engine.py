@@ -567,8 +567,13 @@ class DeviceScene:
 
     # --- renderers (include/prt.h: prt_render_hits / prt_gooch_shade / prt_render) ---------------
     def gooch_table(self, device):
+        """The (surfaces, 8) table of blended warm / cool shades on `device` (built from the snapshot once per
+        device: for a system of many parts, making and uploading it cost more than rendering the picture)."""
         torch = _torch()
-        return torch.from_numpy(self.snapshot.gooch_table()).to(device)
+        kept = getattr(self, "_gooch", None)
+        if kept is None or kept[0] is not self.snapshot or kept[1] != device:
+            kept = self._gooch = (self.snapshot, device, torch.from_numpy(self.snapshot.gooch_table()).to(device))
+        return kept[2]
 
     def render_hits(self, rays8):
         """Nearest hit per ray under the renderers' rule: (t (n) float64, surface (n) int64)."""
