@@ -171,6 +171,11 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started without a launcher: become one (nothing above or in here touches the GPU)
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    # The HIP runtime maps streams onto hardware queues, four by default (the null stream holds one): a fourth
+    # ticket stream would share a queue with another and serialise with it.  Small shards gain from a fourth trace
+    # in flight (profiles/r3/streams.txt: 125k rays 24.7 -> 23.1 us per step), so this process asks for eight queues
+    # -- before the runtime is loaded; a setting the user made stays.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import numpy as np
     import torch
 
@@ -241,9 +246,12 @@ def main():
     # (three: 0.155), 125k rays 0.050 -> 0.040 -> 0.034 with two / three.
     # How many: the state a generation hands to the next (80 B per ray) is meant to stay in the 256 MB Infinity
     # Cache; traces in flight together share it.  As many traces as keep their next states within ~200 MB,
-    # at most three: 1M rays -> 2, 500k and less -> 3, 2M and more -> 1 (measured: config 2 at 1M rays 0.142 ms
+    # at most three (four for shards of 125k rays: see GPU_MAX_HW_QUEUES above): 1M rays -> 2, 500k and less -> 3,
+    # 2M and more -> 1 (measured: config 2 at 1M rays 0.142 ms
     # with two against 0.146 with three; config 5 at 2M and config 4 at 8M lose 3-4 % with two).
-    streams_wanted = args.streams if args.streams else max(1, min(3, int(200e6 // (80 * max(n, 1)))))
+    hw_queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
+    most = 4 if (hw_queues >= 8 and n <= 160_000) else 3  # (a fourth only where it was measured to pay, and has a queue)
+    streams_wanted = args.streams if args.streams else max(1, min(most, int(200e6 // (80 * max(n, 1)))))
     mode = "sync" if not pipelined else ("overlap" if streams_wanted >= 2 else "one_stream")
     depth = streams_wanted if mode == "overlap" else 2  # traces in flight, the one being collected included
     # record blocks handed back to every step (what a design loop does once it has consumed the previous
