@@ -1830,6 +1830,7 @@ extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64
 // stream): the loop DeviceScene.trace_many runs in Python, as one call.  (Measured with a host pause between
 // collecting a trace and starting the next, profiles/r3/batch_issue.txt: the pace of the host is not what
 // bounds overlapped traces -- a tight Python loop reaches the same step time down to 125k rays.)
+static_assert(sizeof(prt_trace_job) == 56, "prt_trace_job is part of the ABI (engine.JOB_DTYPE, INTEGRATION.md)");
 extern "C" int64_t prt_trace_batch(prt_scene* s, int device, prt_trace_job* jobs, int64_t count, int generation_limit,
                                    double ray_offset, int depth, void* const* workspaces, void* const* streams,
                                    int flags) {

@@ -631,6 +631,7 @@ JOB_DTYPE = np.dtype(
     [("rays", "<u8"), ("n", "<i8"), ("ld", "<i8"), ("rows_out", "<u8"), ("rows_cap", "<i8"),
      ("rows_per_generation", "<u8"), ("total", "<i8")]
 )  # prt_trace_job
+assert JOB_DTYPE.itemsize == 56
 
 
 class TraceBatch:
