@@ -16,7 +16,12 @@ MAGIC = 0x70727431
 
 
 def build_host():
-    subprocess.run(["make", "-C", os.path.join(ROOT, "pyrayt_amd", "csrc"), "libprt_hip.so"], check=True, capture_output=True)
+    """The C host programs (the library itself is only built when it is missing: rebuilding it in place would pull
+    the file from under the processes that have it loaded -- the other tests of this session)."""
+    from pyrayt_amd import engine
+
+    if not os.path.exists(engine.LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "pyrayt_amd", "csrc"), "libprt_hip.so"], check=True, capture_output=True)
     subprocess.run(["make", "-C", HOST_DIR], check=True, capture_output=True)
     return HOST
 
