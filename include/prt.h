@@ -272,6 +272,8 @@ int prt_generate_rays(int device, const prt_source* source, int64_t n_total, int
 #define PRT_TRACE_NO_TIMING 256   /* do not bracket the generation launches with HIP events (prt_trace_stats then
                                      reports 0 ms of kernel time): two event records and one event query less per
                                      trace, which is most of what a 125k-ray trace costs the host */
+#define PRT_TRACE_NO_TILE_RECORDS 512 /* do not run compacting generations on the per-tile records of the ticket's
+                                     previous trace (they then run their look-back, as in a first trace); A/B, tests */
 #define PRT_TRACE_COUNT_PATHS 128 /* count, in prt_trace_telemetry, the rays that are not well formed and
                                      the CSG node evaluations that took an exact path (see there) */
 int64_t prt_trace_workspace_bytes(int64_t n);
@@ -394,16 +396,24 @@ int prt_frame_stats(int device, const double* rows, int64_t ld, int64_t n_rows, 
 #define PRT_VARIANT_KLANES 3      /* ... with the surface-parallel nearest-hit kernel (K lanes per ray,
                                      shuffle min-reduce; prt_scene_options.hit_lanes = 4 | 8 | 16) */
 int prt_trace_stats(const prt_scene* scene, double* out8);
-/* counters of this scene since it was created: out8 = { traces re-run on the three-kernel path after a
+/* counters of this scene since it was created: out10 = { traces re-run on the three-kernel path after a
  * look-back gave up, traces repeated because a dense-mode hint did not hold, generation launches made in
  * dense mode, traces repeated with all 13 state rows (see below; at most one per scene),
  * and from the traces run with PRT_TRACE_COUNT_PATHS: how many such traces, ray-generations whose ray was
  * not well formed (see "shortcuts" in DESIGN.md: such a ray takes none), CSG node evaluations with
- * survivors under an implied cull box, ... of which evaluated upstream's box test exactly }.  Dense mode: a generation in which the previous trace of the same scene (whatever its ray count)
+ * survivors under an implied cull box, ... of which evaluated upstream's box test exactly;
+ * generation launches made on per-tile records, traces repeated because a record did not hold }.  Dense mode: a generation in which the previous trace of the same scene (whatever its ray count)
  * recorded every ray and carried all or none of them on is launched on the assumption that it will
  * again -- every tile then knows its output position without the look-back; each tile checks the
  * assumption on its own counts and a miss repeats the trace without assumptions (results are exact
  * either way; PRT_TRACE_NO_HINTS turns the hints off for a call).
+ * Per-tile records: a generation that does lose rays leaves, for every tile, where the tile's rows and carried
+ * rays went and how many it had, in the workspace.  The next trace of the same ticket with the same workspace
+ * and ray count runs that generation on the record instead of a look-back; every tile checks its own counts
+ * against it, and a tile that finds other counts makes the library repeat the trace without the records
+ * (exact either way; they rest after a miss like the dense hints; PRT_TRACE_NO_TILE_RECORDS / NO_HINTS turn
+ * them off for a call).  They pay for traces whose rays are lost in the same places as last time -- a repeated
+ * trace, a design loop that moves a part the vignetted rays do not depend on.
  * Compact state: between the generations of a trace the ray state goes without its rows 3, 7 and 8
  * (origin w, direction w, generation): in a ray set that starts like RaySet's defaults
  * (pyrayt/_pyrayt.py:29-36: w = 1 / 0, generation 0) they hold 1, +0 and the generation's number in every
@@ -411,7 +421,7 @@ int prt_trace_stats(const prt_scene* scene, double* out8);
  * checks the caller's rows, every generation checks the rays it hands on; the first ray that differs
  * makes the library repeat the trace with all rows and keep doing so for this scene
  * (PRT_TRACE_FULL_ROWS forces that form for a call). */
-int prt_trace_telemetry(const prt_scene* scene, int64_t* out8);
+int prt_trace_telemetry(const prt_scene* scene, int64_t* out10);
 
 /* ---- renderers (second consumer of the intersect path) ----------
  * tinygfx/g3d/renderers.py: an OrthographicCamera grid (world_objects.py:499-537) is pushed

@@ -468,6 +468,18 @@ struct GenCtrl {
   uint32_t pad[8];
 };
 static_assert(sizeof(GenCtrl) == 64, "host_gen sizing");
+// Per-tile record of a generation that compacted (look-back): where the tile's rows and carried rays went and how
+// many it had.  The next trace of this ticket with this workspace may run that generation on the record instead
+// of a look-back (assume == 3): every tile checks its own counts against it, exactly as dense mode checks "all".
+// The records of the first kTileHintGenerations generations sit at a fixed distance behind the generation slots
+// (no kernel argument of their own: the generation kernel has no register to spare for one).
+struct TileHint { unsigned excl_live, excl_carry, live, carry; };
+static const int kTileHintGenerations = 16;
+static const size_t kTileHintOffset =
+    ((size_t)(kMaxGenerationSlots + 2) * sizeof(GenCtrl) + 255) / 256 * 256 - sizeof(GenCtrl);  // from gen[0], see trace_layout
+__device__ __forceinline__ TileHint* tile_hints(GenCtrl* gen, int g) {
+  return reinterpret_cast<TileHint*>(reinterpret_cast<char*>(gen) + kTileHintOffset) + (size_t)g * gridDim.x;
+}
 struct FusedCtrl {
   int32_t error;
   int32_t pad;
@@ -486,6 +498,7 @@ static_assert(offsetof(HostMirror, gen) == 64, "mirror header");
 
 #define PRT_ERR_SPECULATION (-101) /* internal: a generation launched in dense mode was not dense -> host re-runs without hints */
 #define PRT_ERR_STALL (-100) /* internal: look-back gave up -> host falls back to the unfused path */
+#define PRT_ERR_TILE_HINT (-103) /* internal: a generation launched on the per-tile record of its last run found other counts -> host re-runs without the records */
 #define PRT_ERR_FULL_ROWS (-102) /* internal: a ray set needs the rows the compact form leaves out -> host re-runs with all 13 */
 
 // Raising an error on the device.  The verdicts that make the host repeat the trace (SPECULATION, STALL,
@@ -836,12 +849,21 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   // the generation that ends the batch (known at launch in this mode) also tells the host: its tiles
   // check in on counters kept in the otherwise unused status buffer (cleared by the next generation like
   // any status word), and the last one to arrive publishes, with every tile's verdict visible to it
-  const bool publish_here = assume && mirror != nullptr && (assume == 2 || batch_last);
+  // (assume == 3: whether the generation ends the trace is in the previous trace's totals, still in its slot)
+  const bool publish_here = assume && mirror != nullptr &&
+                            (assume == 2 || batch_last || (assume == 3 && (gen[g].n_live == 0 || gen[g].n_carry == 0)));
   if (assume) {
     if (threadIdx.x == 0) {
       const int64_t mine = (n - (int64_t)tile * PRT_BLOCK) < PRT_BLOCK ? (n - (int64_t)tile * PRT_BLOCK) : PRT_BLOCK;
-      const bool holds = (int64_t)agg_live == mine && (int64_t)agg_carry == (assume == 1 ? mine : 0);
-      if (!holds && !failed) raise_verdict(&ctrl->error, PRT_ERR_SPECULATION);  // in place before this tile checks in below
+      bool holds = (int64_t)agg_live == mine && (int64_t)agg_carry == (assume == 1 ? mine : 0);
+      if (assume == 3) {  // the previous trace's record of this tile
+        const TileHint h = tile_hints(gen, g)[tile];
+        holds = agg_live == h.live && agg_carry == h.carry && n == *reinterpret_cast<const int64_t*>(gen[g].pad);
+        s_excl[0] = h.excl_live;
+        s_excl[1] = h.excl_carry;
+      }
+      if (!holds && !failed)  // in place before this tile checks in below
+        raise_verdict(&ctrl->error, assume == 3 ? PRT_ERR_TILE_HINT : PRT_ERR_SPECULATION);
       finisher = tile == 0;
       if (publish_here) {
         // Two levels (64 tiles to a counter, the last of each on to the root): thousands of increments of
@@ -880,7 +902,11 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   STAMP(5);
   const int64_t last_tile = (n - 1) / PRT_BLOCK;
   int64_t excl_live, excl_carry;
-  if (assume) {
+  if (assume == 3) {
+    __syncthreads();
+    excl_live = s_excl[0];
+    excl_carry = s_excl[1];
+  } else if (assume) {
     excl_live = (int64_t)tile * PRT_BLOCK;
     excl_carry = assume == 1 ? (int64_t)tile * PRT_BLOCK : 0;
   } else {
@@ -896,19 +922,24 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     // test hook: pretend the spin expired (such traces publish through k_fused_reinit behind the batch)
     if (ctrl->pad == 1 && tile == 3 && lane == 0) raise_verdict(&ctrl->error, PRT_ERR_STALL);
     (void)ok;
-    if (lane == 0) { s_excl[0] = e_live; s_excl[1] = e_carry; }
+    if (lane == 0) {
+      s_excl[0] = e_live; s_excl[1] = e_carry;
+      if (g < kTileHintGenerations) tile_hints(gen, g)[tile] = TileHint{e_live, e_carry, agg_live, agg_carry};
+    }
   }
   __syncthreads();
   excl_live = s_excl[0];
   excl_carry = s_excl[1];
   finisher = tile == last_tile;
+  if (finisher && threadIdx.x == 0) *reinterpret_cast<int64_t*>(gen[g].pad) = n;  // the ray count the tile records belong to
   }
   STAMP(6);
 
   if (finisher && threadIdx.x == 0) {  // totals are known here: hand over to g + 1
     // (dense mode: the totals are the assumption itself; if it failed the error word says so)
-    const int64_t total_live = assume ? n : excl_live + agg_live;
-    const int64_t total_carry = assume ? (assume == 1 ? n : 0) : excl_carry + agg_carry;
+    // (assume == 3: the totals of the previous trace's generation g are still in its slot)
+    const int64_t total_live = assume == 3 ? gen[g].n_live : assume ? n : excl_live + agg_live;
+    const int64_t total_carry = assume == 3 ? gen[g].n_carry : assume ? (assume == 1 ? n : 0) : excl_carry + agg_carry;
     const int64_t next_in = (total_live == 0) ? 0 : total_carry;
     gen[g].n_live = total_live;
     gen[g].n_carry = total_carry;
@@ -1363,7 +1394,7 @@ extern "C" int prt_interact(prt_scene* s, int device, const double* rays_in, int
 //   | block counts | block offsets | hit_t (n f64) | hit_prim (n i32)      [unfused path only]
 //   | ray buffer A (13 n) | ray buffer B (13 n)
 struct TraceLayout {
-  size_t ctrl, fctrl, gen, gen_rows, tiles_a, tiles_b, counts, offsets, hit_t, hit_prim, rays_a,
+  size_t ctrl, fctrl, gen, tile_hints, gen_rows, tiles_a, tiles_b, counts, offsets, hit_t, hit_prim, rays_a,
       rays_b, total;
 };
 static TraceLayout trace_layout(int64_t n) {
@@ -1377,6 +1408,7 @@ static TraceLayout trace_layout(int64_t n) {
   // host reads both back with one copy
   l.fctrl = take(sizeof(GenCtrl) + (kMaxGenerationSlots + 1) * sizeof(GenCtrl));
   l.gen = l.fctrl + sizeof(GenCtrl);
+  l.tile_hints = take((size_t)kTileHintGenerations * nb * sizeof(TileHint));  // (at kTileHintOffset from gen[0]: tile_hints())
   l.gen_rows = take(kMaxGenerationSlots * sizeof(int64_t));
   l.tiles_a = take(nb * sizeof(unsigned long long));
   l.tiles_b = take(nb * sizeof(unsigned long long));
@@ -1387,6 +1419,7 @@ static TraceLayout trace_layout(int64_t n) {
   l.rays_a = take(nn * PRT_RAY_ROWS * sizeof(double));
   l.rays_b = take(nn * PRT_RAY_ROWS * sizeof(double));
   l.total = at;
+  if (l.tile_hints - l.gen != kTileHintOffset) abort();  // (the kernel finds the records by this constant)
   return l;
 }
 
@@ -1576,6 +1609,12 @@ static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
     int assume = 0;
     if (t->use_hints && gg < (int)s->hint_mode.size()) assume = s->hint_mode[gg];
     s->dense_launches += assume ? 1 : 0;
+    // a generation that compacts (no dense hint) on the per-tile record its last run left in this workspace
+    if (assume == 0 && t->use_tile_records && gg < kTileHintGenerations && t->tile_record[gg]) {
+      assume = 3;
+      t->used_tile_hints = true;
+      s->tile_hint_launches += 1;
+    }
     // launches, not generations, alternate between the two status buffers, across traces too: every
     // launch works on the one the launch before it left clean and cleans the other (k_generation)
     hipLaunchKernelGGL(kernel, dim3(blocks_for(n)), dim3(PRT_BLOCK), lds, st, sd, src, src_ld, buf[gg & 1], n,
@@ -1624,6 +1663,7 @@ static int fused_start(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
     hipLaunchKernelGGL(k_fused_init, dim3(64), dim3(256), 0, t->st, (FusedCtrl*)(w + l.fctrl), (GenCtrl*)(w + l.gen),
                        n_slots, (unsigned long long*)(w + l.tiles_a), (int64_t)blocks_for(n), n, t->test_stall);
     t->flip = 0;
+    for (bool& kept : t->tile_record) kept = false;  // (the slots the records are checked against are cleared)
   }
   t->ready_workspace = nullptr;
   // the generation kernels tell the host themselves unless an error can still be raised after the
@@ -1642,6 +1682,16 @@ static int fused_start(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
   // tile checks them on its own rays, so they serve a ray set of another SIZE as well: a design loop that
   // changes its ray count from call to call keeps them)
   t->use_hints = allow_hints && s->hint_n >= 0 && s->hint_keep_absorbed == keep_absorbed && !t->test_stall;
+  // The per-tile records of this ticket's last trace (TileHint) serve the generations that compact: offered with
+  // the other hints, to a trace that publishes from its kernels (the slots the records lean on are then never
+  // cleared between traces), and rested after a miss like them.
+  bool allow_tiles = t->allow_tile_hints && t->use_hints && t->publish_in_kernel;
+  if (allow_tiles && s->tile_hint_holdoff > 0) {
+    s->tile_hint_holdoff -= 1;
+    allow_tiles = false;
+  }
+  t->use_tile_records = allow_tiles;
+  t->used_tile_hints = false;
   t->g = 0;
   t->n_seen = 0;
   t->total_rows = 0;
@@ -1689,9 +1739,11 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
     if (rc) return rc;
   }
   t->launched = false;
-  if (error == PRT_ERR_SPECULATION || error == PRT_ERR_FULL_ROWS) return error;
+  if (error) for (bool& kept : t->tile_record) kept = false;  // (whatever the attempt overwrote before it failed)
+  if (error == PRT_ERR_SPECULATION || error == PRT_ERR_FULL_ROWS || error == PRT_ERR_TILE_HINT) return error;
   // a record block that looked too small to a generation launched on a hint may only have been too small
   // for the hint: the caller repeats without hints before it reports it
+  if (error == PRT_ERR_ROWS_CAP && t->used_tile_hints) return PRT_ERR_TILE_HINT;
   if (error == PRT_ERR_ROWS_CAP && t->use_hints) return PRT_ERR_SPECULATION;
   if (error == PRT_ERR_STALL) return PRT_ERR_STALL;
   if (error) return trace_error(error);
@@ -1701,6 +1753,9 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
   s->hint_keep_absorbed = keep_absorbed;
   s->hint_mode.assign(t->seen_mode, t->seen_mode + t->n_seen);
   if (t->use_hints) s->hint_misses_in_a_row = 0;
+  if (t->used_tile_hints) s->tile_hint_misses_in_a_row = 0;
+  // which generations left (or confirmed) a per-tile record in this workspace: those that compacted
+  for (int g = 0; g < kTileHintGenerations; ++g) t->tile_record[g] = g < t->n_seen && t->seen_mode[g] == 0;
   // the control words are as a next trace of this shape needs them (see the launch loop)
   t->ready_workspace = t->w;
   t->ready_n = t->n;
@@ -1740,6 +1795,7 @@ extern "C" int prt_trace_begin(prt_scene* s, int device, int ticket, const doubl
   t->st = (hipStream_t)stream;
   t->launched = false;
   t->allow_hints = !(flags & PRT_TRACE_NO_HINTS);
+  t->allow_tile_hints = t->allow_hints && !(flags & PRT_TRACE_NO_TILE_RECORDS);
   t->compact = !s->full_rows && !(flags & PRT_TRACE_FULL_ROWS);
   t->active = true;
   if (n == 0 || generation_limit == 0) { reset_stats(s, t, PRT_VARIANT_FUSED); return PRT_OK; }
@@ -1773,8 +1829,15 @@ extern "C" int64_t prt_trace_end(prt_scene* s, int device, int ticket, int64_t* 
   } else {
     for (int attempt = 0;; ++attempt) {
       rc64 = fused_finish(s, c, t, rows_per_generation);
-      if ((rc64 != PRT_ERR_SPECULATION && rc64 != PRT_ERR_FULL_ROWS) || attempt == 3) break;
-      if (rc64 == PRT_ERR_SPECULATION) {
+      if ((rc64 != PRT_ERR_SPECULATION && rc64 != PRT_ERR_FULL_ROWS && rc64 != PRT_ERR_TILE_HINT) || attempt == 4) break;
+      if (rc64 == PRT_ERR_TILE_HINT) {
+        // a generation found other counts in a tile than its last run left on record (other rays, or a scene
+        // that treats them differently): again without the records -- the dense hints stay, they were not refuted
+        s->tile_hint_misses += 1;
+        s->tile_hint_misses_in_a_row = std::min(s->tile_hint_misses_in_a_row + 1, 6);
+        s->tile_hint_holdoff = 1 << s->tile_hint_misses_in_a_row;
+        t->allow_tile_hints = false;
+      } else if (rc64 == PRT_ERR_SPECULATION) {
         // a generation assumed dense was not (the rays or the scene changed since the hints were taken):
         // nothing of this attempt is kept; run again without assumptions, which also renews the hints
         s->speculation_misses += 1;
@@ -1796,7 +1859,8 @@ extern "C" int64_t prt_trace_end(prt_scene* s, int device, int ticket, int64_t* 
       rc = fused_start(s, c, t);
       if (rc) return rc;
     }
-    if (rc64 == PRT_ERR_SPECULATION || rc64 == PRT_ERR_FULL_ROWS) rc64 = fail(PRT_ERR_HIP, "trace kept failing its own assumptions");
+    if (rc64 == PRT_ERR_SPECULATION || rc64 == PRT_ERR_FULL_ROWS || rc64 == PRT_ERR_TILE_HINT)
+      rc64 = fail(PRT_ERR_HIP, "trace kept failing its own assumptions");
     if (rc64 == PRT_ERR_STALL) {  // never observed outside the test hook; see lookback()
       for (int g = 0; g < t->limit; ++g) rows_per_generation[g] = 0;
       rc = settle_timing(t);
@@ -1867,8 +1931,11 @@ extern "C" int64_t prt_trace_batch(prt_scene* s, int device, prt_trace_job* jobs
 }
 
 
-extern "C" int prt_trace_telemetry(const prt_scene* s, int64_t* out8) {
+extern "C" int prt_trace_telemetry(const prt_scene* s, int64_t* out10) {
+  int64_t* out8 = out10;
   if (!s || !out8) return fail(PRT_ERR_ARG, "null argument");
+  out10[8] = s->tile_hint_launches;
+  out10[9] = s->tile_hint_misses;
   out8[0] = s->lookback_fallbacks;
   out8[1] = s->speculation_misses;
   out8[2] = s->dense_launches;

@@ -73,6 +73,10 @@ struct TraceTicket {
   int64_t ready_n = -1;
   int ready_slots = 0, ready_stall = 0;
   int flip = 0;  // which of the two tile-status buffers the next generation launch works on
+  // generations whose per-tile record (TileHint, prt_kernels.hip) in this ticket's workspace is that of the
+  // ticket's last successful trace -- with ready_workspace / ready_n they say when `assume == 3` may be offered
+  bool tile_record[16] = {false};
+  bool allow_tile_hints = true, use_tile_records = false, used_tile_hints = false;
   unsigned long long user = 0;  // identity of this ticket in the workspace registry (0: not drawn yet)
 };
 
@@ -98,6 +102,8 @@ struct prt_scene {
   std::vector<Program> component_programs;
   std::vector<Operand> component_result;        // where each component program leaves its list
   std::vector<DeviceCopy> per_device;
+  int tile_hint_holdoff = 0, tile_hint_misses_in_a_row = 0;  // per-tile records rest after a miss like the dense hints do
+  long long tile_hint_launches = 0, tile_hint_misses = 0;
   bool has_untracable = false;
   bool has_cull_steps = false;                  // the trace program carries I_BOX steps (k_generation<CULL>)
   bool spatial_groups = false;                  // ... grouped by position: components are visited out of list order
