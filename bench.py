@@ -414,6 +414,12 @@ def main():
                                                                   how="sync" if mode == "sync" else "one_stream"),
                          args.side_steps)
     side_resized = side("changing ray count", resized_steps, args.side_steps)
+    # (d) with the dense-mode hints but without the per-tile records of the previous trace (PRT_TRACE_NO_TILE_RECORDS):
+    #     what a trace sees whose rays are lost in other places than last time's -- after the one repeat that finds out
+    side_no_records = side("no tile records", lambda c, t=None: run_steps(
+        c, t, flags=args.flags | engine.TRACE_NO_TILE_RECORDS, how="sync" if mode == "sync" else "one_stream"), args.side_steps)
+    side_no_records_overlap = side("no tile records, overlapped", lambda c, t=None: run_steps(
+        c, t, flags=args.flags | engine.TRACE_NO_TILE_RECORDS), args.side_steps) if mode == "overlap" else None
     # ... and (b) once more issued like the timed region, so that there is a figure to put next to `value`
     side_no_hints_overlap = side("no hints, overlapped", lambda c, t=None: run_steps(
         c, t, flags=args.flags | engine.TRACE_NO_HINTS), args.side_steps) if mode == "overlap" else None
@@ -527,13 +533,13 @@ def main():
                         (f": one {n_job}-ray job, contiguous id shards over {world} GPU(s)" if strong
                          else f": {n_job} rays per GPU (weak scaling)") +
                         f", generation_limit {limit}, rays resident in HBM; the timed step is a REPEATED "
-                        "IDENTICAL trace: dense-mode hints of the previous trace active, first batch sized by it" +
+                        "IDENTICAL trace: dense-mode hints and per-tile records of the previous trace active, first batch sized by it" +
                         {"overlap": f", {depth} traces in flight on {depth} HIP streams (prt_trace_batch = prt_trace_begin / prt_trace_end per trace): the "
                                     "host enqueues ahead and the kernels of different traces overlap on the device",
                          "one_stream": ", one trace kept in flight on the same stream while the previous one's counts are "
                                        "collected (prt_trace_begin / prt_trace_end)",
                          "sync": ", synchronous (prt_trace)"}[mode] +
-                        "; see value_one_stream / value_synchronous / value_no_hints / value_first_trace for the other kinds of step",
+                        "; see value_one_stream / value_synchronous / value_no_tile_records / value_no_hints / value_first_trace for the other kinds of step",
             "issue_mode": mode,
             "issued_by": ("prt_trace_batch (one library call per timed region)" if mode == "overlap" and not args.python_loop
                           else "a Python loop over prt_trace_begin / prt_trace_end" if mode != "sync" else "prt_trace"),
@@ -600,6 +606,14 @@ def main():
         return kind
 
     side_sync, side_no_hints, side_resized = publish(side_sync), publish(side_no_hints), publish(side_resized)
+    side_no_records = publish(side_no_records)
+    if side_no_records:
+        line["value_no_tile_records_one_stream"] = side_no_records["rows_per_s_this_gpu"] * world
+        line["roofline"]["no_tile_records"] = {k: side_no_records[k] for k in ("avg_launch_ms", "frac", "kernel_ms_per_step",
+                                                                               "launches_per_step", "ms_per_step")}
+    if side_no_records_overlap:
+        side_no_records_overlap.pop("_bytes"), side_no_records_overlap.pop("_kernel_ms")
+        line["value_no_tile_records"] = side_no_records_overlap["rows_per_s_this_gpu"] * world  # issued like `value`
     if one_stream:
         line["value_one_stream"] = rows_per_step * world / (one_stream["ms_per_step"] * 1e-3)
     if side_sync:
