@@ -166,3 +166,50 @@ def test_random_bench(seed):
     assert counts == want_counts
     helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"bench seed {seed} unfused")
     ds.close()
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_scene_traced_again_on_its_tile_records(seed):
+    """The fuzz scenes lose rays in every generation: traced a second time with the same buffers, their generations
+    run on the per-tile records of the first (each tile verifies its counts); then some rays change places or are
+    replaced, so that some tiles hold what they held and others do not -- whatever the records are worth then, the
+    frame is the oracle's."""
+    from pyrayt_amd.engine import DeviceScene
+    from pyrayt_amd.scene import SceneSnapshot
+
+    parts, rays, rng, short, odd = build_random_scene(seed)
+    rays = np.ascontiguousarray(rays[:, : int(rng.choice([700, 4096, 20_000]))])
+    n = rays.shape[1]
+    snap = SceneSnapshot(parts)
+    flat = helpers.flat_scene(snap)
+    ds = DeviceScene(snap)
+    buf = torch.from_numpy(rays).to("cuda:0")
+    block = torch.empty((15, n * 6), dtype=torch.float64, device="cuda:0")
+    want, want_counts = c_oracle.trace(flat, rays, 6)
+    for k in range(2):
+        rows, counts = ds.trace(buf, 6, out=block)
+        assert counts == want_counts, (seed, k)
+        helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"seed {seed} pass {k}")
+    from pyrayt_amd import engine
+
+    if not engine.DEFAULT_OPTIONS and not engine.DEFAULT_TRACE_FLAGS and want_counts:
+        told = ds.telemetry()  # the second pass ran every generation on a hint of one kind or the other
+        # (one launch more than recorded generations when the last carried rays hit nothing: that generation runs too)
+        assert len(want_counts) <= told["tile_record_launches"] + told["dense_launches"] <= len(want_counts) + 1, (seed, told)
+        assert told["tile_record_misses"] == 0 and told["speculation_misses"] == 0
+    changed = rays.copy()
+    kind = seed % 3
+    if kind == 0:      # two rays change places (ids stay in order): equal totals, at most two tiles differ
+        a, b = rng.choice(n, 2, replace=False)
+        changed[:12, [a, b]] = changed[:12, [b, a]]
+    elif kind == 1:    # a block of rays replaced by copies of one ray
+        start = int(rng.integers(0, n - 64))
+        changed[:12, start:start + 64] = changed[:12, [int(rng.integers(0, n))]]
+    # (kind 2: nothing changes -- a third pass on the records)
+    want, want_counts = c_oracle.trace(flat, changed, 6)
+    buf.copy_(torch.from_numpy(changed))
+    for k in range(2):
+        rows, counts = ds.trace(buf, 6, out=block)
+        assert counts == want_counts, (seed, "changed", k)
+        helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"seed {seed} changed pass {k}")
+    ds.close()
