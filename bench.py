@@ -22,7 +22,18 @@ instead (secondary figure).  The re-assembly of the result frame (RCCL all-gathe
 kernel inside the library, pyrayt_amd/csrc/prt_gather.hpp) is timed separately after the timed
 region and reported under "gather" and "value_with_gather" -- it is not part of `value`.
 
-The timed steps are issued with 2-3 traces in flight, each ticket of the library on its own HIP stream
+The timed steps ROTATE through four distinct seeded ray sets of the workload (config 2: seeds 1234 ... 1237, all
+resident in HBM before the timed region), so that no step re-traces its predecessor's rays: the per-tile
+compaction records of the previous trace never apply and every step reads its input from HBM.  That is `value`.
+The round-3 headline -- the same ray set traced again and again, dense hints AND per-tile records of the previous
+trace active -- is reported as `value_replay`; `value_synchronous` is one blocking `prt_trace` at a time (what one
+`RayTracer.trace()`, pyrayt/_pyrayt.py:329-339, costs in a running design loop), `value_cold` a fresh scene's
+first trace.  After the timed region the rows of the seed-1234 set are compared with the reference's own summary of
+that run (tests/golden/config2_1m_summary.npz: rows per generation x surface, the ids of the near-axial rays of
+SURVEY Q5, a checksum of the surface column, column sums, 4096 sampled rows) -> "verified"; a false verdict exits
+non-zero.
+
+They are issued with 2-3 traces in flight, each ticket of the library on its own HIP stream
 (prt_trace_batch: the loop over prt_trace_begin / prt_trace_end, run by the library; --python-loop runs it
 from here): the host enqueues ahead and the kernels of different traces overlap on the device.  `value` is that throughput.  The kernel's own launch duration -- what `roofline` prices --
 is measured on one stream, same steps, right behind the timed region (`roofline.measured_on`);
@@ -95,6 +106,9 @@ def parse_args():
     ap.add_argument("--python-loop", action="store_true",
                     help="issue the overlapped steps from a Python loop over prt_trace_begin / prt_trace_end "
                          "(DeviceScene.trace_many's form) instead of one prt_trace_batch call per region")
+    ap.add_argument("--ray-sets", type=int, default=4,
+                    help="distinct seeded ray sets the timed steps rotate through (1 = re-trace the same rays: the "
+                         "value_replay form)")
     ap.add_argument("--side-steps", type=int, default=40,
                     help="steps of each untimed side measurement (synchronous / no hints / changing ray count)")
     return ap.parse_args()
@@ -215,25 +229,35 @@ def main():
     # the workload: this rank's contiguous id range of the job
     n_job = args.rays
     strong = args.scaling == "strong"
-    CountedObject.reset_ids()
-    seed_shift = 0 if strong else rank
-    if args.workload == "config2":
-        parts, rays = scenes.config2(scenes.product_api(), n_job, seed=1234 + seed_shift)
-    elif args.workload == "config4":
-        parts, rays = scenes.config4(scenes.product_api(), n_job // 8)
-    else:
-        parts, rays = scenes.SCENES[args.workload](scenes.product_api(), n_job)
+    seed_shift = 0 if strong else 16 * rank
+    base_seed = {"config2": 1234, "config3": 7, "config5": 11}.get(args.workload)  # (config 4 has no random rays)
+
+    def build(k):
+        """The scene and the k-th ray set of the workload (set 0 is the BASELINE one)."""
+        CountedObject.reset_ids()
+        if args.workload == "config4":
+            return scenes.config4(scenes.product_api(), n_job // 8)
+        return scenes.SCENES[args.workload](scenes.product_api(), n_job, seed=base_seed + seed_shift + k)
+
+    n_sets = max(1, args.ray_sets) if base_seed is not None else 1
+    parts, rays = build(0)
     n_job = rays.shape[1]
-    if strong:  # one job, sharded by contiguous id range (ids are already global)
-        lo, hi = pdist.shard_bounds(n_job, rank=rank, world=world)
-        rays = np.ascontiguousarray(rays[:, lo:hi])
-    else:
-        rays[12] += rank * n_job
+    lo, hi = pdist.shard_bounds(n_job, rank=rank, world=world) if strong else (0, n_job)
+
+    def shard(block):
+        if strong:  # one job, sharded by contiguous id range (ids are already global)
+            return np.ascontiguousarray(block[:, lo:hi])
+        block[12] += rank * n_job
+        return block
+
+    rays = shard(rays)
     n = rays.shape[1]
     snap = SceneSnapshot(parts)
     scene_options = {k: int(v or 1) for k, _, v in (item.partition("=") for item in args.options.split(",") if item)}
     scene = engine.DeviceScene(snap, options=scene_options)
     rays_dev = torch.from_numpy(rays).to(device)
+    # the other ray sets of the rotation: same scene (the snapshot above), other seeds, resident in HBM
+    ray_sets = [rays_dev] + [torch.from_numpy(shard(build(k)[1])).to(device) for k in range(1, n_sets)]
 
     limit = args.generation_limit
     pipelined = not args.no_pipeline
@@ -263,12 +287,16 @@ def main():
     def step(flags=args.flags, rays_in=None):
         return scene.trace(rays_dev if rays_in is None else rays_in, limit, flags=flags, out=block)
 
+    def ray_set(k, rotate=True):
+        return ray_sets[k % len(ray_sets)] if rotate else rays_dev
+
     streams = scene.ticket_streams(device, depth) if mode == "overlap" else None
     torch.cuda.synchronize(device)
 
     class Totals:
         def __init__(self):
             self.kernel_ms = self.launches = self.ray_generations = self.rows_recorded = self.rays_carried = 0.0
+            self.rows_returned = 0  # rows of every step of the region, summed from what the traces returned
 
         def add(self, times=1):
             st = scene.trace_stats()
@@ -278,36 +306,47 @@ def main():
             self.rows_recorded += st["rows"] * times
             self.rays_carried += st["rays_carried"] * times
 
+        def add_set(self, k, times=1):
+            """Statistics of ray set k's trace (taken once, below: an overlapped region cannot ask per trace)."""
+            st = set_stats[k % len(set_stats)]
+            self.launches += st["kernel_launches"] * times
+            self.ray_generations += st["ray_generations"] * times
+            self.rows_recorded += st["rows"] * times
+            self.rays_carried += st["rays_carried"] * times
+
     batches = {}
 
-    def prepared_batch(count, flags=args.flags):
+    def prepared_batch(count, flags=args.flags, rotate=True):
         """The job table of `count` overlapped steps (built once per region size, outside the timed region)."""
-        key = (count, flags)
+        key = (count, flags, rotate)
         if key not in batches:
-            batches[key] = engine.TraceBatch(scene, [rays_dev] * count, limit, depth=depth, outs=blocks[:depth],
-                                             flags=flags | engine.TRACE_NO_TIMING)
+            batches[key] = engine.TraceBatch(scene, [ray_set(k, rotate) for k in range(count)], limit, depth=depth,
+                                             outs=blocks[:depth], flags=flags | engine.TRACE_NO_TIMING)
         return batches[key]
 
-    def run_steps(count, totals=None, flags=args.flags, how=None):
-        """`count` traces back to back, issued as `how` says (default: the bench's mode); returns (rows,
-        counts) of the last one."""
+    def run_steps(count, totals=None, flags=args.flags, how=None, rotate=True):
+        """`count` traces back to back, issued as `how` says (default: the bench's mode), step k on ray set
+        k mod n_sets (rotate=False: all on set 0); returns (rows, counts) of the last one."""
         how = how or mode
         rows = counts = None
         if how == "sync":
-            for _ in range(count):
-                rows, counts = step(flags)
+            for k in range(count):
+                rows, counts = step(flags, ray_set(k, rotate))
                 if totals is not None:
                     totals.add()
+                    totals.rows_returned += int(rows.shape[1])
             return rows, counts
         lanes = depth if how == "overlap" else 2
         if how == "overlap" and not args.python_loop:
             # the whole region as ONE library call (prt_trace_batch: the loop below, run by the library): what a
             # caller with its ray sets up front uses; no Python inside the timed region.  (Same step time as the
             # Python loop, --python-loop, at every shard size: profiles/r3/batch_issue.txt)
-            batch = prepared_batch(count, flags)
+            batch = prepared_batch(count, flags, rotate)
             batch.run()
             if totals is not None:
-                totals.add(count)
+                for k in range(min(count, len(ray_sets))):  # steps k, k + n_sets, ... trace set k
+                    totals.add_set(k if rotate else 0, len(range(k, count, len(ray_sets))))
+                totals.rows_returned += int(batch.totals.sum())
             torch.cuda.synchronize(device)
             return batch.result(-1)
 
@@ -318,7 +357,7 @@ def main():
             flags = flags | engine.TRACE_NO_TIMING
 
         def begin(k):
-            scene.trace_begin(k % lanes, rays_dev, limit, blocks[k % lanes], flags=flags,
+            scene.trace_begin(k % lanes, ray_set(k, rotate), limit, blocks[k % lanes], flags=flags,
                               stream=streams[k % lanes] if how == "overlap" else None)
 
         for k in range(min(lanes - 1, count)):
@@ -327,12 +366,23 @@ def main():
             if k + lanes - 1 < count:
                 begin(k + lanes - 1)
             rows, counts = scene.trace_end(k % lanes)
-            if totals is not None and (how != "overlap" or k == 0):
-                totals.add(count if how == "overlap" else 1)
+            if totals is not None:
+                totals.rows_returned += int(rows.shape[1])
+                if how == "overlap":
+                    totals.add_set(k if rotate else 0)
+                else:
+                    totals.add()
         if how == "overlap":
             torch.cuda.synchronize(device)  # (the caller reads `rows` on the current stream)
         return rows, counts
 
+    # what each ray set's trace does (launches, rays per generation, rows), asked once per set: an overlapped
+    # region cannot ask trace by trace
+    set_stats = []
+    for k in range(len(ray_sets)):
+        step(args.flags, ray_sets[k])
+        step(args.flags, ray_sets[k])  # (the second trace of a set launches exactly its working generations)
+        set_stats.append(scene.trace_stats())
     spinup_steps = 0
     t_spin = time.perf_counter()
     while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
@@ -369,7 +419,7 @@ def main():
         run_steps(args.steps, kernel_region, how="one_stream")
         torch.cuda.synchronize(device)
         one_stream = {"ms_per_step": (time.perf_counter() - k0) / args.steps * 1e3,
-                      "kernel_ms_per_step": kernel_region.kernel_ms / args.steps}
+                      "kernel_ms_per_step": kernel_region.kernel_ms / args.steps, "rows": kernel_region.rows_returned}
         run_steps(2)
     kernel_ms, kernel_launches = kernel_region.kernel_ms, kernel_region.launches
 
@@ -392,22 +442,20 @@ def main():
         took = time.perf_counter() - s0
         return {"ms_per_step": took / count * 1e3, "kernel_ms_per_step": tot.kernel_ms / count,
                 "avg_launch_ms": tot.kernel_ms / tot.launches if tot.launches else 0.0,
-                "launches_per_step": tot.launches / count, "rows_per_s_this_gpu": tot.rows_recorded / took,
+                "launches_per_step": tot.launches / count, "rows_per_s_this_gpu": tot.rows_returned / took,
                 "_bytes": (104.0 * tot.ray_generations + 120.0 * tot.rows_recorded + 104.0 * tot.rays_carried),
                 "_kernel_ms": tot.kernel_ms}
 
     def sync_steps(count, totals=None, flags=args.flags):
-        for _ in range(count):
-            step(flags)
-            if totals is not None:
-                totals.add()
+        run_steps(count, totals, flags=flags, how="sync")
 
     def resized_steps(count, totals=None):
         shorter = rays_dev[:, : max(1, n - 256)]
         for k in range(count):
-            step(args.flags, rays_dev if k % 2 == 0 else shorter)
+            got, _ = step(args.flags, rays_dev if k % 2 == 0 else shorter)
             if totals is not None:
                 totals.add()
+                totals.rows_returned += int(got.shape[1])
 
     side_sync = side("synchronous", sync_steps, args.side_steps)
     side_no_hints = side("no hints", lambda c, t=None: run_steps(c, t, flags=args.flags | engine.TRACE_NO_HINTS,
@@ -423,16 +471,61 @@ def main():
     # ... and (b) once more issued like the timed region, so that there is a figure to put next to `value`
     side_no_hints_overlap = side("no hints, overlapped", lambda c, t=None: run_steps(
         c, t, flags=args.flags | engine.TRACE_NO_HINTS), args.side_steps) if mode == "overlap" else None
-    rows, counts = run_steps(2)  # (leave the scene with the hints of the north-star trace for what follows)
+    # (e) the round-3 headline form: the SAME ray set traced again and again, issued like the timed region -- dense
+    #     hints and per-tile records of the previous trace active, the input possibly still in the Infinity Cache
+    side_replay = side("replay", lambda c, t=None: run_steps(c, t, rotate=False), args.side_steps) \
+        if len(ray_sets) > 1 else None
+    # (f) a fresh scene's first trace: scene compilation, table upload, control-word initialisation, no hints
+    cold = None
+    if args.side_steps > 0:
+        cold_times = []
+        for _ in range(3):
+            torch.cuda.synchronize(device)
+            c0 = time.perf_counter()
+            fresh = engine.DeviceScene(snap, options=scene_options)
+            cold_rows, _ = fresh.trace(rays_dev, limit, flags=args.flags, out=block)
+            torch.cuda.synchronize(device)
+            cold_times.append(time.perf_counter() - c0)
+            cold_count = int(cold_rows.shape[1])
+            fresh.close()
+        cold = {"ms": min(cold_times) * 1e3, "rows_per_s_this_gpu": cold_count / min(cold_times),
+                "what": "DeviceScene(snapshot) + its first trace (no hints, control words initialised), best of 3; "
+                        "kernels already loaded by this process"}
+    rows, counts = run_steps(1, how="sync", rotate=False)  # the BASELINE ray set (seed 1234): verified below
+
+    # --- in-run correctness tie: the rows of the timed workload against the reference's own summary of it -----
+    verified, verify_note = None, "only BASELINE config 2 at 1M rays, generation_limit 10, on one GPU has a reference summary"
+    summary_file = os.path.join(ROOT, "tests", "golden", "config2_1m_summary.npz")
+    if (args.workload == "config2" and world == 1 and n == RAYS_PER_GPU and limit == GENERATION_LIMIT
+            and os.path.exists(summary_file)):
+        want = np.load(summary_file)
+        frame = engine.to_host(rows).T
+        gens, surf = frame[:, 0].astype(np.int64), frame[:, 5].astype(np.int64)
+        checks = {"rows": frame.shape[0] == int(want["rows"])}
+        if checks["rows"]:
+            pairs, pair_counts = np.unique(np.stack((gens, surf)), axis=1, return_counts=True)
+            checks["rows_per_generation_x_surface"] = (np.array_equal(pairs, want["gen_surface_pairs"]) and
+                                                       np.array_equal(pair_counts, want["gen_surface_counts"]))
+            checks["q5_ids"] = np.array_equal(frame[(gens == 1) & (surf == surf.max()), 4].astype(np.int64), want["q5_ids"])
+            checks["surface_checksum"] = int((surf * (gens + 1)).sum()) == int(want["surface_checksum"])
+            checks["column_sums"] = bool(np.allclose(frame.sum(axis=0), want["column_sums"], rtol=1e-9, atol=1e-3))
+            checks["sample_rows_1e-6"] = bool(np.allclose(frame[want["sample_index"]], want["sample_rows"], rtol=0, atol=1e-6))
+        verified = all(checks.values())
+        verify_note = {"against": "tests/golden/config2_1m_summary.npz (written by the genuine reference, "
+                                  "tests/golden/generate_golden.py config2_summary)", "checks": checks}
+        del frame
+    rows, counts = run_steps(2)  # (leave the scene with the hints of the rotation for what follows)
 
     rows_per_step = int(rows.shape[1])
+    rows_timed = float(timed.rows_returned)
     if distributed:
-        agg = torch.tensor([elapsed, float(rows_per_step)], dtype=torch.float64, device=comm_device)
+        agg = torch.tensor([elapsed, float(rows_per_step), rows_timed], dtype=torch.float64, device=comm_device)
         tmax = agg.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
         total_rows_per_step = float(agg[1])
+        rows_timed = float(agg[2])
     else:
         total_rows_per_step = float(rows_per_step)
 
@@ -491,7 +584,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    value = total_rows_per_step * args.steps / elapsed
+    value = rows_timed / elapsed  # rows of every timed step, all ranks / the slowest rank's wall time
     # algorithmic bytes, SURVEY.md section 8d's per-unit figures (13-row state read 104 B, record row
     # 120 B, 13-row next state 104 B; = 328 B per ray-generation when every ray is recorded and goes on),
     # counted exactly: state read per ray alive at generation entry, row per recorded ray, next state
@@ -505,16 +598,30 @@ def main():
     moved_bytes = (STATE_BYTES_FULL * first_generation + state * (ray_generations - first_generation) +
                    ROW_BYTES * rows_recorded + state * rays_carried)
     achieved = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    traffic = None
-    traffic_file = next((f for f in (os.path.join(ROOT, "profiles", r, "traffic.json") for r in ("r3", "r2"))
+    # HBM bytes per launch from the PMC counters: measured by tools/traffic.sh in its own rocprofv3 passes (the
+    # counters cannot be read from inside this process) and committed under profiles/; it counts only if it was
+    # taken from THIS build of the library (tools/traffic.py stamps the file with the library's hash)
+    import hashlib
+
+    with open(engine.LIB_PATH, "rb") as fh:
+        library_sha16 = hashlib.sha256(fh.read()).hexdigest()[:16]
+    traffic, traffic_note = None, None
+    traffic_file = next((f for f in (os.path.join(ROOT, "profiles", r, "traffic.json") for r in ("r4", "r3", "r2"))
                          if os.path.exists(f)), None)
     if traffic_file and args.flags == 0 and n == RAYS_PER_GPU and args.workload == "config2":
         with open(traffic_file) as fh:
             measured = json.load(fh)
-        # per launch like `achieved`: a repeated trace launches exactly its working generations
-        # (the library sizes the first batch from the previous trace), a first trace one more
-        blind = launches > len(counts) * args.steps
-        traffic = measured.get("hbm_bytes_per_launch" if blind else "hbm_bytes_per_working_launch")
+        if measured.get("library_sha16") == library_sha16:
+            # per launch like `achieved`: a repeated trace launches exactly its working generations
+            # (the library sizes the first batch from the previous trace), a first trace one more
+            blind = launches > len(counts) * args.steps
+            traffic = measured.get("hbm_bytes_per_launch" if blind else "hbm_bytes_per_working_launch")
+            traffic_note = (os.path.relpath(traffic_file, ROOT) + f" (library {library_sha16}; rocprofv3 PMC FETCH_SIZE + "
+                            "WRITE_SIZE in separate passes, calibrated on tools/ubench/copy_f64; tools/traffic.sh)")
+        else:
+            traffic_note = (f"none: {os.path.relpath(traffic_file, ROOT)} was measured on library "
+                            f"{measured.get('library_sha16', 'of an unstamped build')}, this run loaded {library_sha16} "
+                            "(run tools/traffic.sh on this build)")
     line = {
         "metric": "ray-surface intersections/sec, 1M-ray biconvex lens",
         "value": value,
@@ -532,14 +639,21 @@ def main():
             "workload": WORKLOADS[args.workload] +
                         (f": one {n_job}-ray job, contiguous id shards over {world} GPU(s)" if strong
                          else f": {n_job} rays per GPU (weak scaling)") +
-                        f", generation_limit {limit}, rays resident in HBM; the timed step is a REPEATED "
-                        "IDENTICAL trace: dense-mode hints and per-tile records of the previous trace active, first batch sized by it" +
+                        f", generation_limit {limit}, rays resident in HBM; " +
+                        (f"the timed steps rotate through {len(ray_sets)} distinct seeded ray sets (seeds {base_seed + seed_shift} ... "
+                         f"{base_seed + seed_shift + len(ray_sets) - 1}): no step re-traces its predecessor's rays; the dense-mode hints "
+                         "of the scene's previous trace apply (they are checked per tile), its per-tile compaction records do not"
+                         if len(ray_sets) > 1 else
+                         "the timed step is a REPEATED IDENTICAL trace: dense-mode hints and per-tile records of the previous "
+                         "trace active, first batch sized by it") +
                         {"overlap": f", {depth} traces in flight on {depth} HIP streams (prt_trace_batch = prt_trace_begin / prt_trace_end per trace): the "
                                     "host enqueues ahead and the kernels of different traces overlap on the device",
                          "one_stream": ", one trace kept in flight on the same stream while the previous one's counts are "
                                        "collected (prt_trace_begin / prt_trace_end)",
                          "sync": ", synchronous (prt_trace)"}[mode] +
-                        "; see value_one_stream / value_synchronous / value_no_tile_records / value_no_hints / value_first_trace for the other kinds of step",
+                        "; see value_replay / value_one_stream / value_synchronous / value_cold / value_no_hints / "
+                        "value_first_trace for the other kinds of step",
+            "ray_sets": len(ray_sets),
             "issue_mode": mode,
             "issued_by": ("prt_trace_batch (one library call per timed region)" if mode == "overlap" and not args.python_loop
                           else "a Python loop over prt_trace_begin / prt_trace_end" if mode != "sync" else "prt_trace"),
@@ -566,8 +680,8 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "frac_of_measured_copy": achieved / COPY_GBS,
             "traffic": traffic,
-            "traffic_source": os.path.relpath(traffic_file, ROOT) + " (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, "
-                              "calibrated; same command, separate passes)" if traffic else None,
+            "traffic_source": traffic_note,
+            "library_sha16": library_sha16,
             "kernel": "k_generation" if not (args.flags & 2) else "k_hit + k_scan + k_shade + k_advance",
             "measured_on": ("one stream, the same steps right behind the timed region (HIP events per trace; with "
                             "traces overlapping on the device an event pair also sees the other trace's kernels)"
@@ -614,8 +728,16 @@ def main():
     if side_no_records_overlap:
         side_no_records_overlap.pop("_bytes"), side_no_records_overlap.pop("_kernel_ms")
         line["value_no_tile_records"] = side_no_records_overlap["rows_per_s_this_gpu"] * world  # issued like `value`
+    line["verified"] = verified
+    line["verification"] = verify_note
+    if side_replay:
+        side_replay.pop("_bytes"), side_replay.pop("_kernel_ms")
+        line["value_replay"] = side_replay["rows_per_s_this_gpu"] * world  # round 3's `value`: the same rays again and again
+    if cold:
+        line["value_cold"] = cold["rows_per_s_this_gpu"] * world
+        line["cold"] = cold
     if one_stream:
-        line["value_one_stream"] = rows_per_step * world / (one_stream["ms_per_step"] * 1e-3)
+        line["value_one_stream"] = one_stream["rows"] * world / (one_stream["ms_per_step"] * args.steps * 1e-3)
     if side_sync:
         line["value_synchronous"] = side_sync["rows_per_s_this_gpu"] * world
         line["synchronous"] = side_sync
@@ -685,6 +807,8 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if verified is False:
+        raise SystemExit("bench.py: the rows of the timed workload do NOT match the reference's summary: " + json.dumps(verify_note))
 
 
 if __name__ == "__main__":

@@ -32,7 +32,10 @@
 extern "C" {
 #endif
 
-#define PRT_VERSION 100 /* 0.1.0 */
+#define PRT_VERSION 200 /* 0.2.0: prt_interact takes the caller-shaded state, PRT_MAT_TABLE / PRT_MAT_HOST,
+                           prt_scene_set_index_tables, prt_gather_hits / prt_scatter_shaded, prt_unique_values,
+                           prt_frame_allreduce.  A caller built against another version must not load this library:
+                           prt_version() is there to be compared with this constant (pyrayt_amd.engine.library does). */
 
 /* ---- ray buffer layout: pyrayt/_pyrayt.py:13-144 (RaySet) -------------------------------
  * A ray set is a row-major (13, n) float64 matrix with leading dimension `ld` (elements
@@ -76,7 +79,19 @@ enum {
   PRT_MAT_ABSORBER = 1,
   PRT_MAT_MIRROR = 2,
   PRT_MAT_CONST_INDEX = 3, /* coef[0] = n */
-  PRT_MAT_SELLMEIER = 4    /* coef = b1, b2, b3, c1, c2, c3 (wavelength in um) */
+  PRT_MAT_SELLMEIER = 4,   /* coef = b1, b2, b3, c1, c2, c3 (wavelength in um) */
+  /* The reference's extension points (pyrayt/materials.py:26-37, :88-99, docs/source/reference/materials.rst:17-19):
+   * a user's Glass subclass supplies index_at(wavelength), a user's TracableMaterial subclass supplies trace(). */
+  PRT_MAT_TABLE = 5,       /* a glass (Glass.trace, materials.py:70-75) whose index_at() is arbitrary host code: the
+                              caller evaluates it on the distinct wavelengths of its rays and hands the library the
+                              sorted (wavelength, index) pairs (prt_scene_set_index_tables); the kernels look a ray's
+                              wavelength up by exact value.  coef[3] = the index for a NaN wavelength; the rest of
+                              coef is owned by the library.  A wavelength that is not in the table is an error
+                              (PRT_ERR_WAVELENGTH), never a guess. */
+  PRT_MAT_HOST = 6         /* a material whose trace() is arbitrary host code: the caller shades the rays that hit it
+                              itself (prt_gather_hits -> its trace() -> prt_scatter_shaded) and prt_interact takes
+                              their post-interaction state as given.  prt_trace cannot serve such a surface: a ray
+                              that hits one there is PRT_ERR_UNTRACABLE. */
 };
 
 /* CSG operations: tinygfx/g3d/csg.py:7-10 (Operation) */
@@ -156,6 +171,14 @@ void prt_scene_destroy(prt_scene* scene);
 int prt_scene_update(prt_scene* scene, const prt_prim* prims, int n_prims, const prt_node* nodes, int n_nodes,
                      const int32_t* roots, int n_roots, const prt_material* mats, int n_mats,
                      const prt_scene_options* options);
+/* Index tables of the scene's PRT_MAT_TABLE materials (Glass.index_at of a user-defined glass,
+ * pyrayt/materials.py:88-99, evaluated by the caller): material m looks wavelengths up in entries
+ * [ranges[2m], ranges[2m] + ranges[2m+1]) of the two HOST arrays (`total` entries each), ascending in wavelength
+ * without duplicates inside a material's range; ranges of other kinds of material are ignored.  Copied; replaces
+ * the previous tables; a TABLE material without entries misses every look-up.  Synchronises the device (a trace
+ * may still be reading the old tables); refused while a trace is in flight. */
+int prt_scene_set_index_tables(prt_scene* scene, const int64_t* ranges, int n_mats, const double* wavelengths,
+                               const double* indices, int64_t total);
 /* rows of the hit list component `root` returns from intersect(): 2 * (#leaves under it) */
 int prt_scene_component_rows(const prt_scene* scene, int root);
 /* what the scene compiled to (no counterpart upstream; host-only, needs no GPU):
@@ -197,14 +220,42 @@ int prt_material_trace(prt_scene* scene, int device, int prim, double* rays, int
  * record row per live ray, set generation+1, and (unless generation+1 == generation_limit)
  * re-launch by ray_offset along the new direction.
  *   rays_in (13,n) ld_in ; t/surf from prt_propagate ; rays_out (13, >= n) ld_out
- *   rows_out (15, >= n) ld_rows ; n_live_out: device int64[1]
+ *   rows_out (15, >= n) ld_rows ; n_live_out: device int64[1] (a negative PRT_ERR_* if the device raised one)
+ *   shaded (13, n) ld_shaded, or NULL: column i holds the state of ray i as the caller's own material.trace()
+ *     left it (_pyrayt.py:408-410 assigns what trace() returns to all 13 rows); read only for rays that hit a
+ *     PRT_MAT_HOST surface -- origin, direction, intensity, wavelength, index and id of the next state are taken
+ *     from it, the generation is set as for any ray (:437) -- and ignored elsewhere
  *   workspace: device scratch of prt_interact_workspace_bytes(n) bytes
  * If every ray is dead nothing is written and *n_live_out = 0 (_pyrayt.py:424-425). */
 int64_t prt_interact_workspace_bytes(int64_t n);
 int prt_interact(prt_scene* scene, int device, const double* rays_in, int64_t n, int64_t ld_in,
                  const double* t, const int64_t* surf, double* rays_out, int64_t ld_out,
                  int generation, int generation_limit, double ray_offset, double* rows_out,
-                 int64_t ld_rows, int64_t* n_live_out, void* workspace, void* stream);
+                 int64_t ld_rows, int64_t* n_live_out, const double* shaded, int64_t ld_shaded,
+                 void* workspace, void* stream);
+
+/* The two halves of a host-shaded interaction (pyrayt/_pyrayt.py:401-410: `surface.material.trace(surface,
+ * next_ray_set[..., surface_mask])` with a user-defined trace()).
+ *   prt_gather_hits     the rays whose nearest hit (surf from prt_propagate) is `surface_id`, in ray order, all 13
+ *                       rows, origins advanced to the hit point (o += d t, :404-407) -> subset_out (13, >= count)
+ *                       ld_subset; index_out (>= count): their columns in `rays`; *count_out: HOST, how many
+ *                       (the call synchronises the stream).  subset_out / index_out may hold n columns at most.
+ *                       workspace: prt_interact_workspace_bytes(n) device bytes.
+ *   prt_scatter_shaded  column j of subset (13, k) -> column index[j] of shaded (13, >= max index + 1): the block
+ *                       prt_interact reads.  Stream-ordered. */
+int prt_gather_hits(int device, const double* rays, int64_t n, int64_t ld, const double* t, const int64_t* surf,
+                    int64_t surface_id, double* subset_out, int64_t ld_subset, int64_t* index_out,
+                    int64_t* count_out, void* workspace, void* stream);
+int prt_scatter_shaded(int device, const double* subset, int64_t k, int64_t ld_subset, const int64_t* index,
+                       double* shaded, int64_t ld_shaded, void* stream);
+
+/* The distinct values of a device array of doubles (the wavelength row of a ray set: what Glass.index_at of a
+ * user-defined glass has to be evaluated on, pyrayt/materials.py:70-75), compared bit for bit, in no particular
+ * order: out (cap) device, *count_out HOST = how many there are (the call synchronises the stream); when that
+ * exceeds cap only the first cap found are in `out`.  workspace: prt_unique_workspace_bytes(cap) device bytes. */
+int64_t prt_unique_workspace_bytes(int64_t cap);
+int prt_unique_values(int device, const double* values, int64_t n, double* out, int64_t cap, int64_t* count_out,
+                      void* workspace, void* stream);
 
 /* ---- ray sources (next to the hot path) --------------------------
  * Source.generate_rays(n) (pyrayt/components.py:481-496): object-space pattern -> 4x4 world
@@ -540,6 +591,7 @@ int prt_primitive_normal(int device, int type, const double* params, const doubl
 #define PRT_ERR_SCENE (-3)
 #define PRT_ERR_ROWS_CAP (-4)
 #define PRT_ERR_UNTRACABLE (-5) /* a ray hit a PRT_MAT_NONE surface (AttributeError upstream) */
+#define PRT_ERR_WAVELENGTH (-6) /* a ray's wavelength is not in the index table of the PRT_MAT_TABLE glass it hit */
 
 #ifdef __cplusplus
 }

@@ -53,7 +53,7 @@ enum { BOX_TEST = 0, BOX_PICK = 1, BOX_JUMP = 2, BOX_LINE = 3 };  // (LINE: rend
 enum { OPER_REGA = 0, OPER_REGB = 1, OPER_LDS = 2 };
 enum { CSG_UNION = 1, CSG_INTERSECT = 2, CSG_DIFFERENCE = 3 };
 enum { PRIM_SPHERE = 0, PRIM_CYLINDER = 1, PRIM_PLANE = 2, PRIM_CUBE = 3, PRIM_PARABOLOID = 4 };
-enum { MAT_NONE = 0, MAT_ABSORBER = 1, MAT_MIRROR = 2, MAT_CONST = 3, MAT_SELLMEIER = 4 };
+enum { MAT_NONE = 0, MAT_ABSORBER = 1, MAT_MIRROR = 2, MAT_CONST = 3, MAT_SELLMEIER = 4, MAT_TABLE = 5, MAT_HOST = 6 };
 
 // One step of the linearised (post-order) component program.  A step is self-contained: a LEAF
 // step carries its primitive's kind, parameters and the three used rows of M^-1, a CSG step its
@@ -514,9 +514,31 @@ __device__ __forceinline__ void world_normal(PrimPtr p, double px, double py, do
 }
 
 // ---- materials --------------------------------------------------------------------------------
+// A user-defined glass (PRT_MAT_TABLE): Glass.index_at (materials.py:88-99) is host code, evaluated by the caller
+// on the distinct wavelengths of its rays; the primitive record carries the device addresses of the material's
+// ascending wavelengths (coef[0], as bits) and their indices (coef[2]), the entry count (coef[1]) and the index
+// of a NaN wavelength (coef[3]).  Exact look-up: a wavelength that is not there is reported, not interpolated.
 template <class PrimPtr>
-__device__ __forceinline__ double glass_index(PrimPtr p, double wavelength) {
+__device__ __forceinline__ double table_index(PrimPtr p, double wavelength, bool& found) {
+  const double* __restrict__ lam = reinterpret_cast<const double*>((unsigned long long)__double_as_longlong(p->coef[0]));
+  const double* __restrict__ idx = reinterpret_cast<const double*>((unsigned long long)__double_as_longlong(p->coef[2]));
+  const int count = (int)p->coef[1];
+  int lo = 0, hi = count;  // first entry that is not below the wavelength
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (lam[mid] < wavelength) lo = mid + 1; else hi = mid;
+  }
+  found = lo < count && lam[lo] == wavelength;
+  double n = found ? idx[lo] : __builtin_nan("");
+  if (wavelength != wavelength) { found = true; n = p->coef[3]; }
+  return n;
+}
+
+template <class PrimPtr>
+__device__ __forceinline__ double glass_index(PrimPtr p, double wavelength, bool& found) {
+  found = true;
   if (p->mat_kind == MAT_CONST) return p->coef[0];  // materials.py:112-118
+  if (p->mat_kind == MAT_TABLE) return table_index(p, wavelength, found);
   const auto k = p->coef;                             // materials.py:136-145
   const double w2 = wavelength * wavelength;
   return prt_sqrt(((1 + (k[0] * w2) / (w2 - k[3])) + (k[1] * w2) / (w2 - k[4])) +
@@ -567,37 +589,40 @@ __device__ __forceinline__ void refract4(double vx, double vy, double vz, double
 }
 
 // material.trace for a ray whose origin (px..pw) already sits on the surface.
-// d (4 comps) and index are updated in place.  Returns false for an untracable material.
+// d (4 comps) and index are updated in place.  Returns 0, or the PRT_ERR_* the ray raises: UNTRACABLE for a
+// surface without a traceable material (and for a caller-shaded one, which only prt_interact serves),
+// WAVELENGTH for a table glass that does not hold the ray's wavelength.
 // (ux, uy, uz) is the incoming direction already divided by norm3(dx,dy,dz) -- the record row's
 // tilt columns.  When dw == 0, norm4(d) is bit-identical to norm3(d) (adding +0 is exact), so
 // the refraction's own normalisation d / |d| (operations.py:125) IS that vector and its
 // square root and divisions are not repeated.
 template <class PrimPtr>
-__device__ __forceinline__ bool shade(PrimPtr p, double px, double py, double pz, double pw, double& dx,
-                                      double& dy, double& dz, double& dw, double wavelength,
-                                      double& index, double tx, double ty, double tz) {
+__device__ __forceinline__ int shade(PrimPtr p, double px, double py, double pz, double pw, double& dx,
+                                     double& dy, double& dz, double& dw, double wavelength,
+                                     double& index, double tx, double ty, double tz) {
   const int kind = p->mat_kind;
-  if (kind == MAT_NONE) return false;
+  if (kind == MAT_NONE || kind == MAT_HOST) return -5;  // PRT_ERR_UNTRACABLE
   if (kind == MAT_ABSORBER) {  // materials.py:47-50
     dx = 0.0; dy = 0.0; dz = 0.0; dw = 0.0;
-    return true;
+    return 0;
   }
   double nx, ny, nz;
   world_normal(p, px, py, pz, pw, nx, ny, nz);
   const double nw = 0.0 * (double)p->normal_scale;
   if (kind == MAT_MIRROR) {
     reflect4(dx, dy, dz, dw, nx, ny, nz, nw);
-    return true;
+    return 0;
   }
   // glass: operations.py:110-162, n_global = 1 always
-  const double n_mat = glass_index(p, wavelength);
+  bool found;
+  const double n_mat = glass_index(p, wavelength, found);
   double vx = tx, vy = ty, vz = tz, vw = dw;  // dw == 0: (+-0) / |d| = +-0
   if (dw != 0.0) {
     const double len = norm4(dx, dy, dz, dw);
     vx = dx / len; vy = dy / len; vz = dz / len; vw = dw / len;
   }
   refract4(vx, vy, vz, vw, nx, ny, nz, nw, index, n_mat, 1.0, dx, dy, dz, dw, index);
-  return true;
+  return found ? 0 : -6;  // PRT_ERR_WAVELENGTH
 }
 
 // ---- per-lane hit lists in LDS -------------------------------------------------------------------

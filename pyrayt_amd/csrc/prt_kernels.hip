@@ -275,7 +275,7 @@ struct Shaded {
   double dx, dy, dz, dw, index;                             // post-interaction direction / index
   double tx, ty, tz;                                        // unit tilt of the incoming ray
   double surface_id;
-  bool ok;                                                  // false: untracable material
+  int err;                                                  // 0, or the PRT_ERR_* this ray raises (see shade())
 };
 
 struct Meta5 {
@@ -304,7 +304,7 @@ __device__ __forceinline__ Shaded interact_compute(const SceneDev& scene, const 
   s.dx = r.dx; s.dy = r.dy; s.dz = r.dz; s.dw = r.dw;
   s.index = s.index_in;
   s.surface_id = -1.0;
-  s.ok = true;
+  s.err = 0;
   // tilt columns: pre-hit direction over its 3-norm (_pyrayt.py:176-177)
   const double tilt = norm3(r.dx, r.dy, r.dz);
   div3(r.dx, r.dy, r.dz, tilt, s.tx, s.ty, s.tz);
@@ -323,7 +323,7 @@ __device__ __forceinline__ Shaded interact_compute(const SceneDev& scene, const 
     const int cur = __shfl(prim, leader);
     if (prim == cur) {
       const DevPrim* __restrict__ p = scene.prims + cur;
-      s.ok = shade(p, s.px, s.py, s.pz, s.pw, s.dx, s.dy, s.dz, s.dw, s.wavelength, s.index,
+      s.err = shade(p, s.px, s.py, s.pz, s.pw, s.dx, s.dy, s.dz, s.dw, s.wavelength, s.index,
                    s.tx, s.ty, s.tz);
       s.surface_id = p->surface_id;
     }
@@ -340,7 +340,7 @@ __device__ __forceinline__ Shaded interact_compute(const SceneDev& scene, const 
       asm volatile("" : "+s"(same));
       if (prim == same) {
         const ConstPrimPtr p = const_prim(scene.prims, cur);
-        s.ok = shade(p, s.px, s.py, s.pz, s.pw, s.dx, s.dy, s.dz, s.dw, s.wavelength, s.index,
+        s.err = shade(p, s.px, s.py, s.pz, s.pw, s.dx, s.dy, s.dz, s.dw, s.wavelength, s.index,
                      s.tx, s.ty, s.tz);
         s.surface_id = p->surface_id;
         pending = false;
@@ -393,7 +393,7 @@ __device__ __forceinline__ void interact_store(const Shaded& s, const Ray8& r, b
   }
 }
 
-__device__ __forceinline__ bool interact_lane(const SceneDev& scene, const double* __restrict__ rays,
+__device__ __forceinline__ int interact_lane(const SceneDev& scene, const double* __restrict__ rays,
                                               int64_t ld, int64_t i, const Ray8& r, double t, int prim,
                                               bool carry, int64_t row, int64_t j,
                                               double* __restrict__ next, int64_t ld_next,
@@ -401,7 +401,7 @@ __device__ __forceinline__ bool interact_lane(const SceneDev& scene, const doubl
                                               double next_generation, int relaunch, double ray_offset) {
   const Shaded s = interact_compute(scene, load_meta(rays, ld, i), r, t, prim);
   interact_store(s, r, carry, row, j, next, ld_next, rows, ld_rows, next_generation, relaunch, ray_offset);
-  return s.ok;
+  return s.err;
 }
 
 // [_st_interact + _RayTraceDataframe.insert]
@@ -411,7 +411,7 @@ k_shade(SceneDev scene, const double* __restrict__ rays, int64_t ld, const Trace
         const int64_t* __restrict__ hit_surf, const int64_t* __restrict__ block_offsets,
         double* __restrict__ next, int64_t ld_next, double* __restrict__ rows, int64_t ld_rows,
         int64_t row_base_fixed, double next_generation, int relaunch, double ray_offset,
-        int keep_absorbed, TraceCtrl* __restrict__ ctrl) {
+        int keep_absorbed, TraceCtrl* __restrict__ ctrl, const double* __restrict__ shaded, int64_t ld_shaded) {
   __shared__ int s_wave[4];
   const int64_t n = ctrl_in ? ctrl_in->n_cur : n_fixed;
   if (ctrl_in && (ctrl_in->error != 0 || ctrl_in->n_live == 0)) return;  // uniform
@@ -436,10 +436,37 @@ k_shade(SceneDev scene, const double* __restrict__ rays, int64_t ld, const Trace
   const int carry_rank = block_rank(carry, s_wave);
   if (!live) return;
 
-  if (!interact_lane(scene, rays, ld, i, r, t, prim, carry, row_base + block_offsets[2 * blockIdx.x] + live_rank,
-                     block_offsets[2 * blockIdx.x + 1] + carry_rank, next, ld_next, rows, ld_rows,
-                     next_generation, relaunch, ray_offset))
-    atomicExch(&ctrl->error, PRT_ERR_UNTRACABLE);
+  const int64_t row = row_base + block_offsets[2 * blockIdx.x] + live_rank;
+  const int64_t j = block_offsets[2 * blockIdx.x + 1] + carry_rank;
+  if (shaded != nullptr && scene.prims[prim].mat_kind == MAT_HOST) {
+    // A surface whose material.trace() is the caller's own code (_pyrayt.py:408-410): column i of `shaded` is
+    // what it returned for this ray -- all 13 rows are taken over (:408 assigns the whole column), the record
+    // row keeps the pre-hit metadata and ends at the origin trace() left (:172, :181), the generation is set
+    // as for every ray (:437) and the re-launch runs along the direction trace() left (:449).
+    const Meta5 m = load_meta(rays, ld, i);
+    Shaded s;
+    s.generation = m.generation; s.intensity = m.intensity; s.wavelength = m.wavelength;
+    s.index_in = m.index; s.id = m.id;
+    s.px = shaded[0 * ld_shaded + i]; s.py = shaded[1 * ld_shaded + i]; s.pz = shaded[2 * ld_shaded + i];
+    s.pw = shaded[3 * ld_shaded + i];
+    s.dx = shaded[4 * ld_shaded + i]; s.dy = shaded[5 * ld_shaded + i]; s.dz = shaded[6 * ld_shaded + i];
+    s.dw = shaded[7 * ld_shaded + i];
+    s.index = shaded[11 * ld_shaded + i];
+    s.surface_id = scene.prims[prim].surface_id;
+    s.err = 0;
+    const double tilt = norm3(r.dx, r.dy, r.dz);
+    div3(r.dx, r.dy, r.dz, tilt, s.tx, s.ty, s.tz);
+    interact_store(s, r, carry, row, j, next, ld_next, rows, ld_rows, next_generation, relaunch, ray_offset);
+    if (carry) {  // the metadata trace() may have changed as well
+      next[9 * ld_next + j] = shaded[9 * ld_shaded + i];
+      next[10 * ld_next + j] = shaded[10 * ld_shaded + i];
+      next[12 * ld_next + j] = shaded[12 * ld_shaded + i];
+    }
+    return;
+  }
+  const int err = interact_lane(scene, rays, ld, i, r, t, prim, carry, row, j, next, ld_next, rows, ld_rows,
+                                next_generation, relaunch, ray_offset);
+  if (err) atomicExch(&ctrl->error, err);
 }
 
 // end of a generation: roll the control block forward
@@ -890,7 +917,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   // the lane's own LDS slots -- the hit lists are dead by now -- instead of being held in
   // registers across the fp64-heavy shading.
   Shaded sh;
-  sh.ok = true;
+  sh.err = 0;
   STAMP(4);
   if (live) {
     Meta5 meta = {0, 0, 0, 0, 0};  // the shading reads wavelength and index only; the rest stays parked
@@ -996,7 +1023,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
                                     ld_rows, next_generation, relaunch, ray_offset))
     atomicExch(&ctrl->error, PRT_ERR_FULL_ROWS);
 #endif
-  if (!sh.ok) raise_error(&ctrl->error, PRT_ERR_UNTRACABLE);
+  if (sh.err) raise_error(&ctrl->error, sh.err);
   STAMP(7);
 }
 
@@ -1291,7 +1318,7 @@ extern "C" int prt_material_trace(prt_scene* s, int device, int prim, double* ra
   int rc = on_device(s, device, &c);
   if (rc) return rc;
   if (prim < 0 || prim >= (int)s->prims.size()) return fail(PRT_ERR_ARG, "bad primitive index");
-  if (s->dev_prims[prim].mat_kind == MAT_NONE)
+  if (s->dev_prims[prim].mat_kind == MAT_NONE || s->dev_prims[prim].mat_kind == MAT_HOST)
     return fail(PRT_ERR_UNTRACABLE, "surface " + std::to_string(s->prims[prim].surface_id) +
                                         " has a material without trace()");
   if (k < 0 || ld < k || (k && !rays)) return fail(PRT_ERR_ARG, "bad buffers");
@@ -1358,14 +1385,15 @@ __global__ void k_interact_finish(const TraceCtrl* ctrl, int64_t* n_live_out) {
 extern "C" int prt_interact(prt_scene* s, int device, const double* rays_in, int64_t n,
                             int64_t ld_in, const double* t, const int64_t* surf, double* rays_out,
                             int64_t ld_out, int generation, int generation_limit, double ray_offset,
-                            double* rows_out, int64_t ld_rows, int64_t* n_live_out, void* workspace,
-                            void* stream) {
+                            double* rows_out, int64_t ld_rows, int64_t* n_live_out, const double* shaded,
+                            int64_t ld_shaded, void* workspace, void* stream) {
   DeviceCopy* c;
   int rc = on_device(s, device, &c);
   if (rc) return rc;
   if (n < 0 || ld_in < n || ld_out < n || ld_rows < n || !n_live_out || !workspace ||
       (n && (!rays_in || !t || !surf || !rays_out || !rows_out)))
     return fail(PRT_ERR_ARG, "bad buffers");
+  if (shaded && ld_shaded < n) return fail(PRT_ERR_ARG, "shaded block narrower than the ray set");
   hipStream_t st = (hipStream_t)stream;
   const InteractLayout l = interact_layout(n);
   char* w = (char*)workspace;
@@ -1382,12 +1410,14 @@ extern "C" int prt_interact(prt_scene* s, int device, const double* rays_in, int
     hipLaunchKernelGGL(k_shade, dim3(blocks_for(n)), dim3(PRT_BLOCK), 0, st, sd, rays_in, ld_in,
                        (const TraceCtrl*)ctrl, n, t, (const int32_t*)nullptr, surf,
                        (const int64_t*)offsets, rays_out, ld_out, rows_out, ld_rows, (int64_t)0,
-                       (double)(generation + 1), relaunch, ray_offset, 1, ctrl);
+                       (double)(generation + 1), relaunch, ray_offset, 1, ctrl, shaded, ld_shaded);
   }
   hipLaunchKernelGGL(k_interact_finish, dim3(1), dim3(1), 0, st, (const TraceCtrl*)ctrl, n_live_out);
   HIP_TRY(hipGetLastError());
   return PRT_OK;
 }
+
+#include "prt_host_shade.hpp"
 
 // workspace of prt_trace:
 //   ctrl | fused ctrl | generation slots | rows_per_generation (device) | tile words A | B
@@ -1430,7 +1460,11 @@ extern "C" int64_t prt_trace_workspace_bytes(int64_t n) {
 static int64_t trace_error(int error) {
   if (error == PRT_ERR_ROWS_CAP) return fail(PRT_ERR_ROWS_CAP, "rows_cap too small");
   if (error == PRT_ERR_UNTRACABLE)
-    return fail(PRT_ERR_UNTRACABLE, "a ray hit a surface whose material has no trace()");
+    return fail(PRT_ERR_UNTRACABLE, "a ray hit a surface whose material has no trace() (or one shaded by the caller: "
+                                    "PRT_MAT_HOST surfaces are served by prt_propagate / prt_gather_hits / prt_interact)");
+  if (error == PRT_ERR_WAVELENGTH)
+    return fail(PRT_ERR_WAVELENGTH, "a ray's wavelength is not in the index table of the glass it hit "
+                                    "(prt_scene_set_index_tables)");
   if (error == PRT_ERR_STALL) return PRT_ERR_STALL;
   return fail(error, "device error during trace");
 }
@@ -1496,7 +1530,7 @@ static int64_t trace_unfused(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_
                        (const TraceCtrl*)ctrl, (int64_t)0, (const double*)hit_t,
                        (const int32_t*)hit_prim, (const int64_t*)nullptr, (const int64_t*)offsets,
                        dst, n, t->rows_out, t->rows_cap, (int64_t)0, (double)(g + 1), relaunch,
-                       t->ray_offset, keep_absorbed, ctrl);
+                       t->ray_offset, keep_absorbed, ctrl, (const double*)nullptr, (int64_t)0);
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, st, ctrl, gen_rows, g);
     HIP_TRY(hipEventRecord(t->ev1, st));
     // the host needs the new ray count to size the next launch
@@ -1755,7 +1789,10 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
   if (t->use_hints) s->hint_misses_in_a_row = 0;
   if (t->used_tile_hints) s->tile_hint_misses_in_a_row = 0;
   // which generations left (or confirmed) a per-tile record in this workspace: those that compacted
-  for (int g = 0; g < kTileHintGenerations; ++g) t->tile_record[g] = g < t->n_seen && t->seen_mode[g] == 0;
+  // (a trace that published through k_fused_reinit had its generation slots -- the ray count and totals the records
+  // are checked against -- cleared behind it: its records are not offered)
+  for (int g = 0; g < kTileHintGenerations; ++g)
+    t->tile_record[g] = t->publish_in_kernel && g < t->n_seen && t->seen_mode[g] == 0;
   // the control words are as a next trace of this shape needs them (see the launch loop)
   t->ready_workspace = t->w;
   t->ready_n = t->n;

@@ -82,6 +82,7 @@ struct TraceTicket {
 
 struct DeviceCopy {
   DevPrim* prims = nullptr;
+  double* tables = nullptr;                     // index tables of the PRT_MAT_TABLE materials: wavelengths | indices
   DevInstr* trace_code = nullptr;               // all components, each reduced to its candidate hit
   int32_t* trace_component_first = nullptr;     // [2 * components] step ranges of trace_code (k-lanes kernels)
   DevInstr* render_code = nullptr;              // same with the renderers' selection rule
@@ -104,7 +105,12 @@ struct prt_scene {
   std::vector<DeviceCopy> per_device;
   int tile_hint_holdoff = 0, tile_hint_misses_in_a_row = 0;  // per-tile records rest after a miss like the dense hints do
   long long tile_hint_launches = 0, tile_hint_misses = 0;
-  bool has_untracable = false;
+  bool has_untracable = false;                  // a shading error can be raised at store time (a surface without a
+                                                // traceable material, a caller-shaded one, a table glass that may miss
+                                                // a wavelength): such traces publish behind the batch (k_fused_reinit)
+  // prt_scene_set_index_tables: per material (first, count) into the two arrays below
+  std::vector<int64_t> table_ranges;
+  std::vector<double> table_wavelengths, table_indices;
   bool has_cull_steps = false;                  // the trace program carries I_BOX steps (k_generation<CULL>)
   bool spatial_groups = false;                  // ... grouped by position: components are visited out of list order
   int stats_device = -1, stats_ticket = 0;      // whose statistics prt_trace_stats reports: the trace ended last
@@ -891,7 +897,7 @@ extern "C" int prt_scene_create(const prt_prim* prims, int n_prims, const prt_no
       return fail(PRT_ERR_SCENE, "primitive with unknown type or material index");
     }
     const prt_material& m = s->mats[p.material];
-    if (m.kind < PRT_MAT_NONE || m.kind > PRT_MAT_SELLMEIER) {
+    if (m.kind < PRT_MAT_NONE || m.kind > PRT_MAT_HOST) {
       delete s;
       return fail(PRT_ERR_SCENE, "unknown material kind");
     }
@@ -904,7 +910,12 @@ extern "C" int prt_scene_create(const prt_prim* prims, int n_prims, const prt_no
     d.type = p.type;
     d.mat_kind = m.kind;
     d.normal_scale = p.normal_scale < 0 ? -1 : 1;
-    if (m.kind == PRT_MAT_NONE) s->has_untracable = true;
+    if (m.kind == PRT_MAT_NONE || m.kind == PRT_MAT_HOST || m.kind == PRT_MAT_TABLE) s->has_untracable = true;
+    if (m.kind == PRT_MAT_TABLE) {  // no entries until prt_scene_set_index_tables: every look-up misses
+      const double nan_index = m.coef[3];
+      std::memset(d.coef, 0, sizeof(d.coef));
+      d.coef[3] = nan_index;
+    }
     s->dev_prims.push_back(d);
   }
   compile_trace_program(s);
@@ -938,6 +949,7 @@ extern "C" int prt_scene_create(const prt_prim* prims, int n_prims, const prt_no
 // give back whatever a device copy holds (the device is current)
 static void release_device_copy(DeviceCopy& c) {
   (void)hipFree(c.prims);
+  (void)hipFree(c.tables);
   (void)hipFree(c.trace_code);
   (void)hipFree(c.trace_component_first);
   (void)hipFree(c.render_code);
@@ -963,6 +975,68 @@ extern "C" void prt_scene_destroy(prt_scene* s) {
     release_device_copy(c);
   }
   delete s;
+}
+
+// Put the scene's index tables on a device copy (the device is current and idle) and point the records of the
+// primitives with a table glass at them: coef[0] / coef[2] = device addresses of the material's wavelengths /
+// indices (as bits), coef[1] = how many; the copy's primitive table is rewritten from s->dev_prims.
+static int apply_tables(prt_scene* s, DeviceCopy& c) {
+  const size_t total = s->table_wavelengths.size();
+  bool any = false;
+  for (const DevPrim& d : s->dev_prims) any = any || d.mat_kind == MAT_TABLE;
+  if (!any) return PRT_OK;
+  (void)hipFree(c.tables);
+  c.tables = nullptr;
+  HIP_TRY(hipMalloc((void**)&c.tables, std::max<size_t>(1, 2 * total) * sizeof(double)));
+  if (total) {
+    HIP_TRY(hipMemcpy(c.tables, s->table_wavelengths.data(), total * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c.tables + total, s->table_indices.data(), total * sizeof(double), hipMemcpyHostToDevice));
+  }
+  std::vector<DevPrim> patched(s->dev_prims);
+  for (size_t p = 0; p < patched.size(); ++p) {
+    DevPrim& d = patched[p];
+    if (d.mat_kind != MAT_TABLE) continue;
+    const size_t m = (size_t)s->prims[p].material;
+    int64_t first = 0, count = 0;
+    if (2 * m + 1 < s->table_ranges.size()) { first = s->table_ranges[2 * m]; count = s->table_ranges[2 * m + 1]; }
+    const unsigned long long lam = (unsigned long long)(c.tables + first), idx = (unsigned long long)(c.tables + total + first);
+    std::memcpy(&d.coef[0], &lam, sizeof(double));
+    std::memcpy(&d.coef[2], &idx, sizeof(double));
+    d.coef[1] = (double)count;
+  }
+  HIP_TRY(hipMemcpy(c.prims, patched.data(), patched.size() * sizeof(DevPrim), hipMemcpyHostToDevice));
+  return PRT_OK;
+}
+
+extern "C" int prt_scene_set_index_tables(prt_scene* s, const int64_t* ranges, int n_mats, const double* wavelengths,
+                                          const double* indices, int64_t total) {
+  if (!s) return fail(PRT_ERR_ARG, "scene is null");
+  if (n_mats != (int)s->mats.size() || !ranges || total < 0 || (total && (!wavelengths || !indices)))
+    return fail(PRT_ERR_ARG, "ranges must hold (first, count) for every material of the scene");
+  for (const DeviceCopy& c : s->per_device)
+    for (const TraceTicket& tk : c.ticket)
+      if (tk.active) return fail(PRT_ERR_ARG, "a trace of this scene is in flight (prt_trace_end it first)");
+  for (int m = 0; m < n_mats; ++m) {
+    if (s->mats[m].kind != PRT_MAT_TABLE) continue;
+    const int64_t first = ranges[2 * m], count = ranges[2 * m + 1];
+    if (first < 0 || count < 0 || first + count > total || count >= (1ll << 31))
+      return fail(PRT_ERR_ARG, "index table range out of bounds");
+    for (int64_t k = first + 1; k < first + count; ++k)
+      if (!(wavelengths[k - 1] < wavelengths[k]))
+        return fail(PRT_ERR_ARG, "index table wavelengths must be strictly ascending (and not NaN) inside a material's range");
+  }
+  s->table_ranges.assign(ranges, ranges + 2 * (size_t)n_mats);
+  s->table_wavelengths.assign(wavelengths, wavelengths + total);
+  s->table_indices.assign(indices, indices + total);
+  for (size_t d = 0; d < s->per_device.size(); ++d) {
+    DeviceCopy& c = s->per_device[d];
+    if (!c.ready) continue;
+    HIP_TRY(hipSetDevice((int)d));
+    HIP_TRY(hipDeviceSynchronize());  // the last trace may still be draining: it reads the old tables
+    int rc = apply_tables(s, c);
+    if (rc) return rc;
+  }
+  return PRT_OK;
 }
 
 // The same scene with other numbers in it (a part moved, a radius or a glass changed): recompile on
@@ -1025,6 +1099,18 @@ extern "C" int prt_scene_update(prt_scene* s, const prt_prim* prims, int n_prims
   s->component_programs.swap(t->component_programs);
   s->component_result.swap(t->component_result);
   prt_scene_destroy(t);  // (never reached a device: host memory only)
+  // (the primitive records were overwritten: the table glasses get their table addresses back; a material list
+  // of another shape leaves them without entries until the caller sets the tables again)
+  if (s->table_ranges.size() != 2 * s->mats.size()) {
+    s->table_ranges.clear(); s->table_wavelengths.clear(); s->table_indices.clear();
+  }
+  for (size_t d = 0; d < s->per_device.size(); ++d) {
+    DeviceCopy& c = s->per_device[d];
+    if (!c.ready) continue;
+    HIP_TRY(hipSetDevice((int)d));
+    int rc_tables = apply_tables(s, c);
+    if (rc_tables) return rc_tables;
+  }
   return PRT_OK;
 }
 
@@ -1097,6 +1183,8 @@ static int on_device(prt_scene* s, int device, DeviceCopy** out) {
     }
     int rc_lds = raise_lds_limits();
     if (rc_lds) return rc_lds;
+    rc = apply_tables(s, c);
+    if (rc) return rc;
     c.ready = true;
   }
   *out = &c;

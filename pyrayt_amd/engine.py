@@ -58,6 +58,13 @@ def options_record(options=None):
 
 ERR_ROWS_CAP = -4
 ERR_UNTRACABLE = -5
+ERR_WAVELENGTH = -6
+PRT_VERSION = 200  # include/prt.h: the ABI this binding was written for
+UNIQUE_CAP = 4096  # distinct wavelengths looked for on the device before the host sorts the whole row
+
+
+class WavelengthNotInTable(LookupError):
+    """A ray's wavelength is not in the index table of the user-defined glass it hit (PRT_ERR_WAVELENGTH)."""
 
 _lib = None
 
@@ -83,7 +90,12 @@ def _declare(lib):
         "prt_material_trace": (c_int, [c_p, c_int, c_int, c_p, c_i64, c_i64, c_p]),
         "prt_interact_workspace_bytes": (c_i64, [c_i64]),
         "prt_interact": (c_int, [c_p, c_int, c_p, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_int, c_int,
-                                 c_d, c_p, c_i64, c_p, c_p, c_p]),
+                                 c_d, c_p, c_i64, c_p, c_p, c_i64, c_p, c_p]),
+        "prt_scene_set_index_tables": (c_int, [c_p, c_p, c_int, c_p, c_p, c_i64]),
+        "prt_gather_hits": (c_int, [c_int, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p]),
+        "prt_scatter_shaded": (c_int, [c_int, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
+        "prt_unique_workspace_bytes": (c_i64, [c_i64]),
+        "prt_unique_values": (c_int, [c_int, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p]),
         "prt_trace_workspace_bytes": (c_i64, [c_i64]),
         "prt_trace": (c_i64, [c_p, c_int, c_p, c_i64, c_i64, c_int, c_d, c_p, c_i64, c_p, c_p,
                               c_int, c_p]),
@@ -130,7 +142,8 @@ def _declare(lib):
 EXPORTED_SYMBOLS = (
     "prt_version", "prt_last_error", "prt_device_count", "prt_scene_create", "prt_scene_destroy", "prt_scene_update",
     "prt_scene_component_rows", "prt_scene_info", "prt_intersect", "prt_propagate", "prt_world_normals",
-    "prt_material_trace", "prt_interact_workspace_bytes", "prt_interact",
+    "prt_material_trace", "prt_interact_workspace_bytes", "prt_interact", "prt_scene_set_index_tables",
+    "prt_gather_hits", "prt_scatter_shaded", "prt_unique_workspace_bytes", "prt_unique_values",
     "prt_trace_workspace_bytes", "prt_trace", "prt_trace_begin", "prt_trace_end", "prt_trace_batch", "prt_trace_stats", "prt_trace_telemetry", "prt_generate_rays",
     "prt_camera_rays", "prt_render_hits", "prt_gooch_shade", "prt_gooch_mix", "prt_render",
     "prt_edge_workspace_bytes", "prt_edge_canvas", "prt_reflect", "prt_refract", "prt_binomial_root",
@@ -151,7 +164,13 @@ def library():
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (or `make -C pyrayt_amd/csrc`). pyrayt_amd has no CPU fallback."
             )
-        _lib = _declare(ctypes.CDLL(LIB_PATH))
+        lib = _declare(ctypes.CDLL(LIB_PATH))
+        # (the ABI changed incompatibly between versions -- argument lists grew, output blocks widened: a stale
+        # libprt_hip.so must fail here, loudly, not corrupt memory later)
+        if lib.prt_version() != PRT_VERSION:
+            raise EngineUnavailable(f"{LIB_PATH} is ABI version {lib.prt_version()}, this binding needs {PRT_VERSION}: "
+                                    "rebuild it (make -C pyrayt_amd/csrc)")
+        _lib = lib
     return _lib
 
 
@@ -161,6 +180,8 @@ def _check(code):
         if code == ERR_UNTRACABLE:
             # the reference fails with AttributeError: the default GoochMaterial has no trace()
             raise AttributeError(msg or "a ray hit a surface whose material cannot be traced")
+        if code == ERR_WAVELENGTH:
+            raise WavelengthNotInTable(msg or "a ray's wavelength is not in the index table of the glass it hit")
         if code == -1:
             raise ValueError(msg)
         raise RuntimeError(f"libprt_hip error {code}: {msg}")
@@ -213,6 +234,7 @@ class DeviceScene:
         self.snapshot = snapshot
         self._handle = ctypes.c_void_p()
         self._pending = [None] * TRACE_TICKETS
+        self._tables = None  # (wavelengths, [indices per table material]) as last handed to the library
         self.trace_flags = DEFAULT_TRACE_FLAGS if trace_flags is None else int(trace_flags)
         prims = np.ascontiguousarray(snapshot.prims)
         nodes = np.ascontiguousarray(snapshot.nodes)
@@ -239,8 +261,71 @@ class DeviceScene:
         if rc == 1:
             return False
         _check(rc)
+        if [slot for slot, _ in getattr(snapshot, "table_materials", ())] != [slot for slot, _ in self._table_materials]:
+            self._tables = None  # (other materials hold tables now: they are set again before the next trace)
         self.snapshot = snapshot
         return True
+
+    # --- user-defined glasses (PRT_MAT_TABLE) ------------------------------------------------------------
+    def ensure_tables(self, wavelengths):
+        """Make sure the index tables of the scene's user-defined glasses (``Glass`` subclasses with their own
+        ``index_at``, pyrayt/materials.py:88-99) cover ``wavelengths``: ``index_at`` of every such material is
+        evaluated -- on the host, it is the user's code -- on the union of ``wavelengths`` and what the tables
+        already hold, and handed to the library (``prt_scene_set_index_tables``) if anything differs from what
+        it has (new wavelengths, or a material whose coefficients the caller changed since).  Cheap when nothing
+        changed: a few ``index_at`` calls on a handful of wavelengths, no device work."""
+        mats = self._table_materials
+        if not mats:
+            return
+        from . import materials as matl
+
+        wanted = np.asarray(wavelengths, dtype=float).ravel()
+        wanted = wanted[~np.isnan(wanted)]  # (a NaN wavelength is served by prt_material.coef[3])
+        if self._tables is not None:
+            wanted = np.concatenate([self._tables[0], wanted])
+        lam = np.unique(wanted)  # ascending, by value
+        indices = [matl.table_indices(material, lam) for _, material in mats]
+        if self._tables is not None and np.array_equal(lam, self._tables[0]) and all(
+                np.array_equal(a, b, equal_nan=True) for a, b in zip(indices, self._tables[1])):
+            return
+        n_mats = len(self.snapshot.materials)
+        ranges = np.zeros((n_mats, 2), dtype=np.int64)
+        for k, (slot, _) in enumerate(mats):
+            ranges[slot] = (k * len(lam), len(lam))
+        all_lam = np.ascontiguousarray(np.tile(lam, len(mats)))
+        all_idx = np.ascontiguousarray(np.concatenate(indices)) if indices else np.zeros(0)
+        _check(library().prt_scene_set_index_tables(self.handle, ranges.ctypes.data, n_mats, all_lam.ctypes.data,
+                                                    all_idx.ctypes.data, len(all_lam)))
+        self._tables = (lam, indices)
+
+    def distinct_wavelengths(self, rays):
+        """The distinct wavelengths of a device (13, n) ray set, as a host array: found on the device
+        (``prt_unique_values``, nothing but the few values crosses PCIe); a ray set with more than UNIQUE_CAP of
+        them -- a continuous spectrum -- has its wavelength row sorted on the host instead."""
+        torch = _torch()
+        lib = library()
+        n, dev = rays.shape[1], rays.device
+        if n == 0:
+            return np.zeros(0)
+        out = torch.empty(UNIQUE_CAP, dtype=torch.float64, device=dev)
+        work = torch.empty(int(lib.prt_unique_workspace_bytes(UNIQUE_CAP)), dtype=torch.uint8, device=dev)
+        count = ctypes.c_int64(0)
+        row = rays[10]
+        _check(lib.prt_unique_values(dev.index or 0, row.data_ptr(), n, out.data_ptr(), UNIQUE_CAP,
+                                     ctypes.byref(count), work.data_ptr(), _stream_ptr(torch, dev)))
+        if count.value <= UNIQUE_CAP:
+            return to_host(out[:count.value]).copy()
+        return np.unique(to_host(row.contiguous()))
+
+    @property
+    def _table_materials(self):
+        """(material slot, material) of the scene's user-defined glasses (a snapshot of plain arrays has none)."""
+        return getattr(self.snapshot, "table_materials", ())
+
+    @property
+    def _host_surfaces(self):
+        """(primitive index, surface) of the surfaces whose material.trace() is user code."""
+        return getattr(self.snapshot, "host_surfaces", ())
 
     @classmethod
     def from_components(cls, components, options=None):
@@ -304,6 +389,12 @@ class DeviceScene:
             cap = int(rows_cap) if rows_cap is not None else self._rows_cap(torch, n, limit, dev)
         work = self._workspace(torch, n, dev)
         counts = (ctypes.c_int64 * limit)()
+        if self._host_surfaces:
+            raise TypeError("this scene has a material with a user-defined trace(): use trace_stepwise() "
+                            "(RayTracer.trace() does)")
+        if self._table_materials and self._tables is None:
+            self.ensure_tables(self.distinct_wavelengths(rays))  # a user-defined glass, first trace
+        rescanned = False
         while True:
             rows = out if out is not None else torch.empty((RECORD_COLS, cap), dtype=torch.float64, device=dev)
             total = lib.prt_trace(
@@ -313,6 +404,12 @@ class DeviceScene:
             )
             if total == ERR_ROWS_CAP and cap < n * limit and out is None:
                 cap = min(n * limit, cap * 4)  # only when HBM was too tight for the full block
+                continue
+            if total == ERR_WAVELENGTH and not rescanned:
+                # rays with wavelengths the tables were not built for (another ray set than last time): the
+                # kernels never guess an index -- evaluate index_at on what these rays carry and trace again
+                rescanned = True
+                self.ensure_tables(self.distinct_wavelengths(rays))
                 continue
             _check(total)
             break
@@ -337,6 +434,9 @@ class DeviceScene:
         overlap on the device."""
         if not 0 <= int(ticket) < TRACE_TICKETS:
             raise ValueError(f"ticket out of range (0..{TRACE_TICKETS - 1})")
+        # (lifetime rule for callers that pass a stream: trace_end returns when the COUNTS are on the host, the
+        # rows are only ordered on that stream -- before `rays`, `out` or anything else the trace touches goes
+        # back to the allocator of another stream, make that stream wait: other.wait_stream(stream))
         # the same tensors as this ticket's previous trace (a loop re-tracing into its own blocks): the call's
         # arguments are as they were (checking and converting them again costs as much as the call itself)
         cached = self._begin_cache[ticket] if hasattr(self, "_begin_cache") else None
@@ -347,6 +447,8 @@ class DeviceScene:
             args = cached[1]
         else:
             torch = _torch()
+            if self._host_surfaces:
+                raise TypeError("this scene has a material with a user-defined trace(): use trace_stepwise()")
             assert rays.is_cuda and rays.dtype == torch.float64 and rays.dim() == 2
             assert rays.shape[0] == RAY_ROWS and rays.stride(1) == 1
             assert out.is_cuda and out.dtype == torch.float64 and out.dim() == 2 and out.device == rays.device
@@ -391,18 +493,24 @@ class DeviceScene:
         """Trace a sequence of ray sets with `depth` traces in flight, each ticket on its own HIP stream:
         the host enqueues ahead and the kernels of different traces overlap on the device (a generation's
         workgroups leave the chip partly idle while they start up and drain; 1M-ray traces: 0.18 -> 0.15 ms
-        each).  Yields (rows, counts) per ray set, in order; `rows` is a view of one of `depth` record
-        blocks and stays valid until `depth` more results have been taken.  Frames equal ``trace()``'s."""
+        each).  Yields (rows, counts) per ray set, in order.  `rows` is a view of one of `depth` + 1 record
+        blocks used in turn: it stays valid while the NEXT result is taken (a caller may hold frame k and
+        compare it with frame k + 1) and is overwritten when the one after that is asked for -- copy what has
+        to live longer.  Frames equal ``trace()``'s."""
         torch = _torch()
         depth = max(1, min(int(depth), TRACE_TICKETS))
         limit = int(generation_limit)
-        pending, blocks, streams = [], [None] * depth, None
+        pending, blocks, streams = [], [None] * (depth + 1), []
         try:
             yield from self._trace_many(torch, ray_sets, limit, depth, ray_offset, flags, pending, blocks, streams)
         finally:
             for lane in pending:  # a caller that stops early: collect what is in flight, the tickets are free again
                 try:
-                    self.trace_end(lane)
+                    rows, _ = self.trace_end(lane)
+                    # (prt_trace_end returns once the counts are on the host, possibly while the last kernel still
+                    # stores rows: the caller's stream -- on which the blocks and ray sets will be freed and reused
+                    # -- must wait for the ticket's stream first)
+                    torch.cuda.current_stream(rows.device).wait_stream(streams[lane])
                 except Exception:  # noqa: BLE001
                     pass
 
@@ -411,13 +519,15 @@ class DeviceScene:
             lane = k % depth
             if len(pending) == depth:  # the ticket about to be reused: collect its trace first
                 yield self._collect(torch, pending.pop(0), streams)
+            # depth + 1 blocks in turn: the block of the result just handed out is not the one recorded into next
+            slot = k % len(blocks)
             need = (RECORD_COLS, max(rays.shape[1], 1) * limit)
-            if blocks[lane] is None or blocks[lane].shape[1] < need[1] or blocks[lane].device != rays.device:
-                blocks[lane] = torch.empty(need, dtype=torch.float64, device=rays.device)
-            if streams is None:
-                streams = self.ticket_streams(rays.device, depth)
+            if blocks[slot] is None or blocks[slot].shape[1] < need[1] or blocks[slot].device != rays.device:
+                blocks[slot] = torch.empty(need, dtype=torch.float64, device=rays.device)
+            if not streams:
+                streams.extend(self.ticket_streams(rays.device, depth))
             streams[lane].wait_stream(torch.cuda.current_stream(rays.device))  # whatever produced this ray set
-            self.trace_begin(lane, rays, limit, blocks[lane], ray_offset=ray_offset, flags=flags, stream=streams[lane])
+            self.trace_begin(lane, rays, limit, blocks[slot], ray_offset=ray_offset, flags=flags, stream=streams[lane])
             pending.append(lane)
         while pending:
             yield self._collect(torch, pending.pop(0), streams)
@@ -513,14 +623,18 @@ class DeviceScene:
                                            _stream_ptr(torch, rays.device)))
         return t, surf
 
-    def interact(self, rays, t, surf, generation, generation_limit, ray_offset=DEFAULT_RAY_OFFSET):
-        """Returns (rows (15,k), next rays (13,k)); k == 0 when every ray is dead."""
+    def interact(self, rays, t, surf, generation, generation_limit, ray_offset=DEFAULT_RAY_OFFSET, shaded=None,
+                 rows_out=None):
+        """Returns (rows (15,k), next rays (13,k)); k == 0 when every ray is dead.
+        shaded: CUDA (13, n) block holding, for the rays that hit a surface with a user-defined ``trace()``, what
+        that ``trace()`` returned (``scatter_shaded``); rows_out: a (15, >= n) view to record into."""
         torch = _torch()
         lib = library()
         n = rays.shape[1]
         dev = rays.device
         nxt = torch.empty((RAY_ROWS, n), dtype=torch.float64, device=dev)
-        rows = torch.empty((RECORD_COLS, n), dtype=torch.float64, device=dev)
+        rows = rows_out if rows_out is not None else torch.empty((RECORD_COLS, n), dtype=torch.float64, device=dev)
+        assert rows.shape[0] == RECORD_COLS and rows.shape[1] >= n and rows.stride(1) in (0, 1)
         n_live = torch.zeros(1, dtype=torch.int64, device=dev)
         if n:
             work = torch.empty(int(lib.prt_interact_workspace_bytes(n)), dtype=torch.uint8, device=dev)
@@ -528,11 +642,93 @@ class DeviceScene:
                                     t.data_ptr(), surf.data_ptr(), nxt.data_ptr(), nxt.stride(0),
                                     int(generation), int(generation_limit), float(ray_offset),
                                     rows.data_ptr(), rows.stride(0), n_live.data_ptr(),
+                                    shaded.data_ptr() if shaded is not None else None,
+                                    shaded.stride(0) if shaded is not None else 0,
                                     work.data_ptr(), _stream_ptr(torch, dev)))
         k = int(n_live.item())
         if k < 0:
             _check(k)
         return rows[:, :k], nxt[:, :k]
+
+    # --- materials with a user-defined trace() (PRT_MAT_HOST) -------------------------------------------------
+    def gather_hits(self, rays, t, surf, surface_id):
+        """The rays whose nearest hit is ``surface_id``, in ray order, origins advanced to the hit point: what
+        upstream hands to ``surface.material.trace`` (pyrayt/_pyrayt.py:401-410).  Returns (subset (13,k) CUDA,
+        index (k) CUDA int64: their columns in ``rays``)."""
+        torch = _torch()
+        lib = library()
+        n, dev = rays.shape[1], rays.device
+        subset = torch.empty((RAY_ROWS, n), dtype=torch.float64, device=dev)
+        index = torch.empty(n, dtype=torch.int64, device=dev)
+        count = ctypes.c_int64(0)
+        if n:
+            work = torch.empty(int(lib.prt_interact_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+            _check(lib.prt_gather_hits(dev.index or 0, rays.data_ptr(), n, rays.stride(0), t.data_ptr(), surf.data_ptr(),
+                                       int(surface_id), subset.data_ptr(), subset.stride(0), index.data_ptr(),
+                                       ctypes.byref(count), work.data_ptr(), _stream_ptr(torch, dev)))
+        return subset[:, :count.value], index[:count.value]
+
+    def scatter_shaded(self, subset, index, shaded):
+        """Columns of ``subset`` (13,k) to columns ``index`` of ``shaded`` (13,n), the block ``interact`` reads."""
+        torch = _torch()
+        k = subset.shape[1]
+        if k:
+            assert subset.stride(1) == 1 and shaded.stride(1) == 1
+            _check(library().prt_scatter_shaded(shaded.device.index or 0, subset.data_ptr(), k, subset.stride(0),
+                                                index.data_ptr(), shaded.data_ptr(), shaded.stride(0),
+                                                _stream_ptr(torch, shaded.device)))
+        return shaded
+
+    def trace_stepwise(self, rays, generation_limit, ray_offset=DEFAULT_RAY_OFFSET):
+        """The generation loop with the host in it, for scenes in which a surface's ``material.trace()`` is user
+        code (pyrayt/materials.py:26-37, docs/source/reference/materials.rst:17-19).  Per generation:
+        nearest hits on the device (``prt_propagate``); for every surface with such a material, in look-up-table
+        order like upstream's loop (pyrayt/_pyrayt.py:401-410), the rays that hit it are gathered on the device,
+        brought to the host as a ``RaySet`` with their origins on the surface, handed to
+        ``surface.material.trace(surface, ray_subset)`` and what it returns goes back; then INTERACT on the device
+        (``prt_interact``), which shades every other surface itself and takes those rays as given.
+        Same result as ``trace()``: (rows (15, total) CUDA, rows per generation)."""
+        torch = _torch()
+        from .rayset import RaySet
+
+        assert rays.is_cuda and rays.dtype == torch.float64 and rays.dim() == 2 and rays.shape[0] == RAY_ROWS
+        n, dev, limit = rays.shape[1], rays.device, int(generation_limit)
+        if n == 0 or limit <= 0:
+            return torch.empty((RECORD_COLS, 0), dtype=torch.float64, device=dev), []
+        if self._table_materials and self._tables is None:
+            self.ensure_tables(self.distinct_wavelengths(rays))
+        rows = torch.empty((RECORD_COLS, n * limit), dtype=torch.float64, device=dev)
+        current = rays if rays.stride(1) == 1 else rays.contiguous()
+        counts, base = [], 0
+        for generation in range(limit):
+            n_cur = current.shape[1]
+            if n_cur == 0:
+                break
+            t, surf = self.propagate(current)
+            shaded = None
+            for _, surface in self._host_surfaces:
+                subset, index = self.gather_hits(current, t, surf, surface.get_id())
+                if subset.shape[1] == 0:  # (upstream: `if np.any(surface_mask)`)
+                    continue
+                handed = to_host(subset).copy().view(RaySet)
+                answer = np.asarray(surface.material.trace(surface, handed), dtype=float)
+                if answer.shape != handed.shape:
+                    # (upstream assigns the answer to next_ray_set[..., surface_mask]: numpy broadcasting rules)
+                    answer = np.broadcast_to(answer, handed.shape)
+                if shaded is None:  # (only the columns of host-shaded rays are ever read)
+                    shaded = torch.empty((RAY_ROWS, n_cur), dtype=torch.float64, device=dev)
+                self.scatter_shaded(torch.from_numpy(np.ascontiguousarray(answer)).to(dev), index, shaded)
+                if self._table_materials:  # a trace() that changes wavelengths: the glasses must know them
+                    self.ensure_tables(np.unique(answer[10]))
+            got, nxt = self.interact(current, t, surf, generation, limit, ray_offset, shaded=shaded,
+                                     rows_out=rows[:, base:])
+            k = got.shape[1]
+            if k == 0:  # every ray is dead: nothing is recorded for this generation (_pyrayt.py:424-425)
+                break
+            counts.append(k)
+            base += k
+            current = nxt
+        return rows[:, :base], counts
 
     def intersect(self, root, rays8):
         """rays8: CUDA (8+, n) tensor.  Returns (hits (m,n) float64, ids (m,n) int64)."""
@@ -843,6 +1039,7 @@ def material_trace(material, surface, ray_set):
     ds = DeviceScene(snap)
     try:
         dev = _to_device(np.asarray(ray_set), RAY_ROWS)
+        ds.ensure_tables(np.unique(np.asarray(ray_set, dtype=float)[10]))  # (a user-defined glass: its index_at, evaluated here)
         ds.material_trace(0, dev)
         ray_set[...] = dev.cpu().numpy()
         return ray_set

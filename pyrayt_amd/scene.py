@@ -42,18 +42,28 @@ class SceneSnapshot:
     """Flat arrays describing ``components`` + the surface look-up table."""
 
     def __init__(self, components, material_override=None):
+        """material_override: shade every surface with this material's own arithmetic instead of its
+        ``material`` attribute (``Material.trace(surface, ray_set)`` called directly, possibly through
+        ``super().trace`` from a user's ``trace()``: a ``trace`` override is not looked at then)."""
         if not hasattr(components, "__iter__"):
             components = (components,)
         self.components = tuple(components)
         prims, nodes, roots, mats = [], [], [], []
         self._material_slots = {}
         self.surfaces = []  # leaf surfaces in look-up-table order (_pyrayt.py:257-260)
+        self.table_materials = []  # (material slot, material) of every user-defined glass (PRT_MAT_TABLE)
+        self.host_surfaces = []    # (primitive index, surface) whose material.trace() is user code (PRT_MAT_HOST)
 
         def material_slot(material):
             key = id(material)
             if key not in self._material_slots:
-                kind = getattr(material, "kind", matl.NONE) if material is not BLACK else matl.NONE
-                coef = material.packed_coefficients() if kind != matl.NONE else [0.0] * 6
+                kind = matl.NONE if material is BLACK else matl.device_kind(
+                    material, shading_only=material_override is not None)
+                coef = [0.0] * 6
+                if kind in (matl.ABSORBER, matl.MIRROR, matl.CONST_INDEX, matl.SELLMEIER):
+                    coef = material.packed_coefficients()
+                elif kind == matl.TABLE:
+                    self.table_materials.append((len(mats), material))
                 self._material_slots[key] = len(mats)
                 mats.append((kind, 0, coef))
             return self._material_slots[key]
@@ -80,6 +90,8 @@ class SceneSnapshot:
                     )
                 )
                 self.surfaces.append(obj)
+                if mats[prims[-1][1]][0] == matl.HOST:
+                    self.host_surfaces.append((len(prims) - 1, obj))
                 nodes.append((NODE_LEAF, -1, -1, len(prims) - 1, [0.0] * 6))
                 return len(nodes) - 1
             raise TypeError(f"{obj!r} is neither a TracerSurface nor a CSGSurface")

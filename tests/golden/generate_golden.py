@@ -664,7 +664,7 @@ def render_ray_vectors(seeds=range(12)):
 
 def main():
     which = set(sys.argv[1:]) or {"scenes", "primitives", "csg", "shading", "sources", "summary", "render", "operations", "raw",
-                                  "adversarial", "stale", "render_rays"}
+                                  "adversarial", "stale", "render_rays", "custom"}
     print(f"numpy {np.__version__} pandas {pd.__version__} (reference locks numpy 1.20.2 / pandas 1.2.4)")
     if "scenes" in which:
         scene_fixture("config1", 100, 1000)
@@ -680,6 +680,10 @@ def main():
         for name in ("adv_lens", "adv_stop", "adv_prism", "adv_condenser", "adv_still", "adv_short_a", "adv_short_b",
                      "adv_short_c", "adv_bench_a", "adv_bench_b", "adv_bench_c"):
             scene_fixture(name, 6, allow_sensitive=True)
+    if "custom" in which:  # user-defined materials (tests/scenes.py user_materials): Glass.index_at / TracableMaterial.trace
+        scene_fixture("custom_cauchy", 10, 2048)
+        scene_fixture("custom_retro", 6, 10)
+        scene_fixture("custom_mixed", 10, 2048)
     if "stale" in which:  # upstream's cached cull box of a right-nested tree moved after construction
         scene_fixture("stale_box", 6, 3000, allow_sensitive=True)
     if "primitives" in which:

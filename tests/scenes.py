@@ -168,6 +168,94 @@ def config5(api, n, seed=11):
 
 
 # ---------------------------------------------------------------------------------------------
+# user-defined materials: the reference's documented extension points
+# (docs/source/reference/materials.rst:17-19, pyrayt/materials.py:26-37, :88-99), written the way a user of
+# either package writes them -- against the api's own base classes
+# ---------------------------------------------------------------------------------------------
+def user_materials(api):
+    """Four material classes a user might define: a Cauchy-dispersion glass (only ``index_at``), a
+    retro-reflector (only ``trace``), a lossy Cauchy glass whose ``trace`` attenuates and then refracts through
+    ``super().trace`` and a wavelength-shifting mirror that uses the surface's normals and ``cg.reflect``."""
+    matl, cg = api.materials, api.cg
+
+    class CauchyGlass(matl.Glass):
+        def __init__(self, a, b):
+            super().__init__()
+            self.a, self.b = a, b
+
+        def index_at(self, wavelength):
+            return self.a + self.b / wavelength ** 2
+
+    class RetroReflector(matl.TracableMaterial):
+        def trace(self, surface, ray_set):
+            ray_set.rays[1] *= -1
+            return ray_set
+
+    class LossyGlass(CauchyGlass):
+        def __init__(self, a, b, transmission):
+            super().__init__(a, b)
+            self.transmission = transmission
+
+        def trace(self, surface, ray_set):
+            ray_set.intensity = ray_set.intensity * self.transmission
+            return super().trace(surface, ray_set)
+
+    class ShiftingMirror(matl.TracableMaterial):
+        def __init__(self, shift):
+            super().__init__()
+            self.shift = shift
+
+        def trace(self, surface, ray_set):
+            normals = surface.get_world_normals(ray_set.rays[0])
+            ray_set.rays[1] = cg.reflect(ray_set.rays[1], normals)
+            ray_set.wavelength = ray_set.wavelength + self.shift
+            ray_set.intensity = ray_set.intensity * 0.5
+            return ray_set
+
+    return SimpleNamespace(CauchyGlass=CauchyGlass, RetroReflector=RetroReflector, LossyGlass=LossyGlass,
+                           ShiftingMirror=ShiftingMirror)
+
+
+def custom_cauchy(api, n, seed=1234, wavelengths=(0.45, 0.55, 0.633, 0.7)):
+    """Config 2's lens in a user-defined Cauchy glass (a ``Glass`` subclass that only supplies ``index_at``),
+    rays of several wavelengths interleaved."""
+    glass = user_materials(api).CauchyGlass(1.5046, 0.0042)
+    lens = api.components.biconvex_lens(2, 2, 0.25, aperture=1, material=glass)
+    focus = lensmakers_equation(2, -2, 1.5, 0.25)
+    baffle = api.components.baffle((1, 1)).move_x(1)
+    rays = cone_rays(n, (-focus, 0.0, 0.0), 6.0, seed)
+    rays[10] = np.asarray(wavelengths)[np.arange(n) % len(wavelengths)]
+    return [lens, baffle], rays
+
+
+def custom_retro(api, n=10):
+    """test_core.py:54-66's two facing mirrors with the second one replaced by a user-defined retro-reflector
+    (a ``TracableMaterial`` subclass that only supplies ``trace``: d -> -d).  Tilted rays, so that reflecting
+    and reversing differ."""
+    cg, m = api.cg, api.materials.mirror
+    src = api.components.LineOfRays().rotate_z(8)
+    first = cg.XYPlane(8, 8, material=m).rotate_y(-90).move_x(3)
+    second = cg.XYPlane(8, 8, material=user_materials(api).RetroReflector()).rotate_y(90).move_x(-3)
+    return [first, second], np.array(src.generate_rays(n))
+
+
+def custom_mixed(api, n, seed=77):
+    """Every kind of material in one system: a lens in a lossy user glass (``trace`` override that calls
+    ``super().trace``), a wavelength-shifting user mirror at 45 degrees, a lens in a user Cauchy glass behind it
+    (which therefore meets wavelengths no source emitted), a built-in BK7 window and an absorbing detector."""
+    user = user_materials(api)
+    c, cg, matl = api.components, api.cg, api.materials
+    lossy = c.biconvex_lens(3, 3, 0.3, aperture=1.2, material=user.LossyGlass(1.49, 0.0035, 0.96))
+    mirror = cg.XYPlane(3, 3, material=user.ShiftingMirror(0.021)).rotate_y(90).rotate_z(-45).move_x(2)
+    cauchy = c.biconvex_lens(4, 4, 0.25, aperture=1.5, material=user.CauchyGlass(1.52, 0.0048)).rotate_z(90).move(2, 1.5, 0)
+    window = cg.Cuboid.from_length(1.0, material=matl.glass["BK7"]).scale(2.0, 0.2, 2.0).move(2, 2.6, 0)
+    det = c.baffle((4, 4)).rotate_z(90).move(2, 3.5, 0)
+    rays = cone_rays(n, (-3.0, 0.0, 0.0), 5.0, seed)
+    rays[10] = np.asarray((0.48, 0.59, 0.66))[np.arange(n) % 3]
+    return [lossy, mirror, cauchy, window, det], rays
+
+
+# ---------------------------------------------------------------------------------------------
 # systems the reference's own tests pin
 # ---------------------------------------------------------------------------------------------
 def two_mirrors(api, n=10):
@@ -764,6 +852,9 @@ SCENES = {
     "adv_bench_a": adv_bench_a,
     "adv_bench_b": adv_bench_b,
     "adv_bench_c": adv_bench_c,
+    "custom_cauchy": custom_cauchy,
+    "custom_retro": custom_retro,
+    "custom_mixed": custom_mixed,
 }
 
 

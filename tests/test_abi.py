@@ -38,7 +38,10 @@ def test_library_exports_every_declared_symbol(lib_path):
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} is declared in prt.h but not exported"
     lib.prt_version.restype = ctypes.c_int
-    assert lib.prt_version() == 100
+    from pyrayt_amd import engine
+
+    header_version = int(re.search(r"#define PRT_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert lib.prt_version() == header_version == engine.PRT_VERSION
     # every header citation points at a reference file that SURVEY.md lists
     text = open(HEADER).read()
     for path in re.findall(r"(pyrayt/[\w/]+\.py|tinygfx/[\w/]+\.py)", text):
@@ -65,6 +68,92 @@ def test_scene_create_validates_without_a_gpu(lib_path):
     bad.prims["type"][0] = 9
     with pytest.raises(RuntimeError, match="unknown type"):
         engine.DeviceScene(bad)
+
+
+def test_a_library_of_another_abi_version_is_refused(lib_path, monkeypatch):
+    """include/prt.h changes incompatibly between versions (argument lists grow, output blocks widen): the
+    binding compares prt_version() with the version it was written for and refuses a stale build."""
+    from pyrayt_amd import engine
+
+    monkeypatch.setattr(engine, "_lib", None)
+    monkeypatch.setattr(engine, "PRT_VERSION", engine.PRT_VERSION + 1)
+    with pytest.raises(engine.EngineUnavailable, match="ABI version"):
+        engine.library()
+    monkeypatch.setattr(engine, "PRT_VERSION", engine.PRT_VERSION - 1)
+    assert engine.library() is not None
+
+
+def test_user_defined_materials_are_classified_like_upstream_dispatches_them():
+    """pyrayt/_pyrayt.py:408 calls surface.material.trace whatever the material is; which PRT_MAT_* kind serves
+    an object is decided by where its trace / index_at are defined (pyrayt_amd.materials.device_kind)."""
+    import scenes
+    from pyrayt_amd import materials as m
+    from pyrayt_amd.g3d.materials import gooch
+
+    user = scenes.user_materials(scenes.product_api())
+
+    class MyBK7(m.SellmeierRefractor):  # numbers only: keeps the closed form
+        pass
+
+    class Odd(m.BasicRefractor):  # redefines index_at: a table
+        def index_at(self, wavelength):
+            return 2.0
+
+    class Duck:  # not even a TracableMaterial: upstream would call its trace() all the same
+        def trace(self, surface, ray_set):
+            return ray_set
+
+    kinds = [(m.absorber, m.ABSORBER), (m.mirror, m.MIRROR), (m.glass["ideal"], m.CONST_INDEX),
+             (m.glass["SF5"], m.SELLMEIER), (MyBK7(1, 2, 3), m.SELLMEIER), (Odd(1.5), m.TABLE),
+             (user.CauchyGlass(1.5, 0.004), m.TABLE), (user.RetroReflector(), m.HOST),
+             (user.LossyGlass(1.5, 0.004, 0.9), m.HOST), (user.ShiftingMirror(0.02), m.HOST), (Duck(), m.HOST),
+             (gooch.BLACK, m.NONE), (object(), m.NONE)]
+    for material, want in kinds:
+        assert m.device_kind(material) == want, material
+    # what super().trace() of a user's trace() reaches: the material's own shading arithmetic
+    assert m.device_kind(user.LossyGlass(1.5, 0.004, 0.9), shading_only=True) == m.TABLE
+    assert m.device_kind(user.RetroReflector(), shading_only=True) == m.NONE
+    # constructors as upstream's (materials.py:12-24): base_material first, defaults per class
+    assert user.CauchyGlass(1.5, 0.004)._base_material is gooch.BLUE
+    assert user.RetroReflector()._base_material is gooch.BLACK
+    assert m.TracableMaterial.__init__.__code__.co_varnames[:2] == ("self", "base_material")
+    assert np.array_equal(m.table_indices(Odd(1.5), [0.4, 0.5]), [2.0, 2.0])
+
+
+def test_snapshot_and_index_tables_without_a_gpu(lib_path):
+    """The snapshot marks user-defined glasses (tables) and user-shaded surfaces; prt_scene_set_index_tables is
+    host code until a device copy exists and validates what it is given."""
+    import scenes
+    from pyrayt_amd import engine
+    from pyrayt_amd import materials as m
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    CountedObject.reset_ids()
+    parts, _ = scenes.custom_mixed(scenes.product_api(), 16)
+    snap = SceneSnapshot(parts)
+    kinds = snap.materials["kind"].tolist()
+    assert kinds == [m.HOST, m.HOST, m.TABLE, m.SELLMEIER, m.ABSORBER]
+    assert [slot for slot, _ in snap.table_materials] == [2]
+    assert [p for p, _ in snap.host_surfaces] == [0, 1, 2, 3]  # the lossy lens's three surfaces, the shifting mirror
+    scene = engine.DeviceScene(snap)
+    scene.ensure_tables([0.6, 0.5, 0.6, np.nan])
+    lam, idx = scene._tables
+    assert np.array_equal(lam, [0.5, 0.6]) and np.array_equal(idx[0], 1.52 + 0.0048 / lam ** 2)
+    scene.ensure_tables([0.55])  # the union, re-evaluated
+    assert np.array_equal(scene._tables[0], [0.5, 0.55, 0.6])
+    lib = engine.library()
+    ranges = np.zeros((5, 2), dtype=np.int64)
+    ranges[2] = (0, 2)
+    lam = np.array([0.6, 0.5])
+    rc = lib.prt_scene_set_index_tables(scene.handle, ranges.ctypes.data, 5, lam.ctypes.data, lam.ctypes.data, 2)
+    assert rc == -1 and b"ascending" in lib.prt_last_error()
+    rc = lib.prt_scene_set_index_tables(scene.handle, ranges.ctypes.data, 4, lam.ctypes.data, lam.ctypes.data, 2)
+    assert rc == -1
+    ranges[2] = (1, 2)
+    rc = lib.prt_scene_set_index_tables(scene.handle, ranges.ctypes.data, 5, lam.ctypes.data, lam.ctypes.data, 2)
+    assert rc == -1 and b"bounds" in lib.prt_last_error()
+    scene.close()
 
 
 def test_no_cpu_fallback():

@@ -1,0 +1,279 @@
+"""User-defined materials on the HIP path: the reference's two extension points
+(docs/source/reference/materials.rst:17-19; pyrayt/materials.py:26-37 ``TracableMaterial.trace``, :88-99
+``Glass.index_at``; called from pyrayt/_pyrayt.py:401-410).
+
+The fixtures (tests/golden/scene_custom_*.npz) are what the genuine reference produced for the scenes of
+tests/scenes.py ``custom_*``, whose material classes are written against the api's own base classes -- the same
+source text defines them on both sides.  Bar: surface ids, generation and ray id exact, everything else 1e-6.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import helpers
+import scenes
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from pyrayt_amd import RaySet, RayTracer, engine, materials  # noqa: E402
+from pyrayt_amd.g3d.objects import CountedObject  # noqa: E402
+from pyrayt_amd.scene import SceneSnapshot  # noqa: E402
+
+CUSTOM = {"custom_cauchy": (2048,), "custom_retro": (10,), "custom_mixed": (2048,)}
+
+
+def build(name):
+    CountedObject.reset_ids()
+    parts, rays = scenes.SCENES[name](scenes.product_api(), *CUSTOM[name])
+    return parts, rays
+
+
+class PresetSource:
+    """A source the engine knows nothing about (a user's own Source subclass): rays come from the host."""
+
+    wavelength = 0.633
+
+    def __init__(self, rays):
+        self._rays = rays
+
+    def generate_rays(self, n):
+        return self._rays.copy().view(RaySet)
+
+
+@pytest.mark.parametrize("name", list(CUSTOM))
+def test_raytracer_with_user_materials_matches_reference(name):
+    fx = helpers.load(f"scene_{name}.npz")
+    parts, rays = build(name)
+    assert np.array_equal(rays, fx["rays0"])
+    tracer = RayTracer(PresetSource(rays), parts, rays_per_source=rays.shape[1], generation_limit=int(fx["generation_limit"]))
+    frame = tracer.trace()
+    helpers.assert_frames_match(frame.to_numpy(dtype=float), fx["frame"], what=name)
+    # again: the scene is kept, the tables are re-evaluated, nothing changes
+    helpers.assert_frames_match(tracer.trace().to_numpy(dtype=float), fx["frame"], what=f"{name} again")
+
+
+def test_user_glass_runs_on_the_fused_path():
+    """A Glass subclass with its own index_at is PRT_MAT_TABLE: one fused kernel per generation, no host in the loop."""
+    fx = helpers.load("scene_custom_cauchy.npz")
+    parts, rays = build("custom_cauchy")
+    snap = SceneSnapshot(parts)
+    assert [materials.TABLE] == sorted(set(snap.materials["kind"][snap.prims["material"]].tolist()) - {materials.ABSORBER})
+    assert len(snap.table_materials) == 1 and not snap.host_surfaces
+    ds = engine.DeviceScene(snap)
+    dev = torch.from_numpy(rays).cuda()
+    for flags in (0, engine.TRACE_UNFUSED, engine.TRACE_KEEP_ABSORBED, engine.TRACE_NO_HINTS):
+        rows, counts = ds.trace(dev, 10, flags=flags)
+        helpers.assert_frames_match(rows.cpu().numpy().T, fx["frame"], what=f"cauchy flags {flags}")
+    rows, counts = ds.trace(dev, 10)
+    st = ds.trace_stats()
+    assert st["variant"] == 1 and st["kernel_launches"] == len(counts) == 3
+    lam, idx = ds._tables
+    assert np.array_equal(lam, [0.45, 0.55, 0.633, 0.7]) and np.allclose(idx[0], 1.5046 + 0.0042 / lam ** 2, rtol=0, atol=0)
+    ds.close()
+
+
+def test_built_in_scenes_launch_what_they_launched_before():
+    """Scenes with only built-in materials are untouched by the extension: no tables, no host surfaces, the
+    fused path with one launch per generation, counts published from the kernels."""
+    CountedObject.reset_ids()
+    parts, rays = scenes.config2(scenes.product_api(), 4096)
+    snap = SceneSnapshot(parts)
+    assert not snap.table_materials and not snap.host_surfaces
+    ds = engine.DeviceScene(snap)
+    dev = torch.from_numpy(rays).cuda()
+    ds.trace(dev, 10)
+    rows, counts = ds.trace(dev, 10)
+    st = ds.trace_stats()
+    assert st["variant"] == 1 and st["kernel_launches"] == 3 and len(counts) == 3
+    assert ds._tables is None
+    ds.close()
+
+
+def test_wavelengths_the_tables_do_not_hold_are_found_not_guessed():
+    """The kernels look wavelengths up exactly.  DeviceScene.trace() rescans a ray set whose wavelengths the
+    tables were not built for; the asynchronous entry points, which cannot, report the miss."""
+    parts, rays = build("custom_cauchy")
+    ds = engine.DeviceScene(SceneSnapshot(parts))
+    dev = torch.from_numpy(rays).cuda()
+    rows, _ = ds.trace(dev, 10)
+    base = rows.cpu().numpy().T
+    other = rays.copy()
+    other[10] = np.where(np.arange(other.shape[1]) % 2 == 0, 0.52, 0.61)  # neither is in the table
+    dev_other = torch.from_numpy(other).cuda()
+    out = torch.empty((15, other.shape[1] * 10), dtype=torch.float64, device="cuda")
+    ds.trace_begin(0, dev_other, 10, out)
+    with pytest.raises(engine.WavelengthNotInTable):
+        ds.trace_end(0)
+    rows, counts = ds.trace(dev_other, 10)  # rescans, extends the tables, traces again
+    assert sorted(ds._tables[0].tolist()) == [0.45, 0.52, 0.55, 0.61, 0.633, 0.7]
+    got = rows.cpu().numpy().T
+    assert got.shape == base.shape and np.array_equal(got[:, 5], base[:, 5])
+    # the index the rays travel in inside the lens is index_at of THEIR wavelength
+    inside = got[got[:, 0] == 1]
+    assert np.allclose(inside[:, 3], 1.5046 + 0.0042 / inside[:, 2] ** 2, rtol=0, atol=1e-12)
+    # and the first ray set still traces as before (its wavelengths stayed in the table)
+    rows, _ = ds.trace(dev, 10)
+    assert np.array_equal(rows.cpu().numpy().T, base)
+    ds.close()
+
+
+def test_a_glass_whose_coefficients_change_between_traces_is_picked_up():
+    parts, rays = build("custom_cauchy")
+    glass = parts[0].surface_ids[0][1].material
+    tracer = RayTracer(PresetSource(rays), parts, rays_per_source=rays.shape[1])
+    first = tracer.trace().to_numpy(dtype=float)
+    glass.b = 0.009
+    second = tracer.trace().to_numpy(dtype=float)
+    inside = second[second[:, 0] == 1]
+    assert np.allclose(inside[:, 3], 1.5046 + 0.009 / inside[:, 2] ** 2, rtol=0, atol=1e-12)
+    assert not np.allclose(first[:, 3], second[:, 3])
+    glass.b = 0.0042
+    assert np.array_equal(tracer.trace().to_numpy(dtype=float), first)
+
+
+def test_user_glass_from_device_sources_and_sharded_ids():
+    """Device-side sources: the tables come from the sources' wavelengths, no ray ever visits the host."""
+    CountedObject.reset_ids()
+    api = scenes.product_api()
+    user = scenes.user_materials(api)
+    lens = api.components.biconvex_lens(2, 2, 0.25, aperture=1, material=user.CauchyGlass(1.5, 0.004))
+    srcs = [api.components.ConeOfRays(5, wavelength=w).move_x(-2.0) for w in (0.45, 0.6)]
+    baffle = api.components.baffle((1, 1)).move_x(1)
+    on_device = RayTracer(srcs, [lens, baffle], rays_per_source=500).trace().to_numpy(dtype=float)
+    host = RayTracer(srcs, [lens, baffle], rays_per_source=500)
+    host.device_sources = False
+    helpers.assert_frames_match(on_device, host.trace().to_numpy(dtype=float), what="device vs host sources")
+    inside = on_device[on_device[:, 0] == 1]
+    assert len(inside) and np.allclose(inside[:, 3], 1.5 + 0.004 / inside[:, 2] ** 2, rtol=0, atol=1e-12)
+
+
+def test_material_trace_of_user_materials_direct_calls():
+    """Material.trace(surface, ray_set) called directly (upstream's own tests do, test_pyrayt_materials.py:15-21):
+    a user glass shades through the engine with ITS index_at; a user trace() is simply the user's code."""
+    api = scenes.product_api()
+    user = scenes.user_materials(api)
+    surf = api.cg.Sphere(1.0, material=user.CauchyGlass(1.5, 0.004))
+    rs = RaySet(6)
+    rs.rays[0, :3] = np.array([[-1.0, 0, 0]] * 6).T
+    rs.rays[1, 0] = 1.0
+    rs.rays[1, 1] = np.linspace(-0.2, 0.2, 6)
+    rs.rays[1, :3] /= np.linalg.norm(rs.rays[1, :3], axis=0)
+    rs.wavelength = np.array([0.4, 0.5, 0.6, 0.4, 0.5, 0.6])
+    want_index = 1.5 + 0.004 / np.asarray(rs.wavelength) ** 2
+    reference_like = api.cg.refract(np.array(rs.rays[1]), surf.get_world_normals(rs.rays[0]), np.ones(6), want_index)
+    out = surf.material.trace(surf, rs)
+    assert out is rs and np.allclose(rs.index, want_index) and np.allclose(rs.rays[1], reference_like[0], atol=1e-12)
+    lossy = user.LossyGlass(1.5, 0.004, 0.5)
+    rs2 = RaySet(6)
+    rs2[:] = rs
+    rs2.index = 1.0
+    rs2.rays[1] = 0
+    rs2.rays[1, 0] = 1.0
+    lossy.trace(surf, rs2)
+    assert np.allclose(rs2.intensity, 50.0) and np.allclose(rs2.index, want_index)
+
+
+def test_gather_and_scatter_are_upstreams_masked_assignment():
+    rng = np.random.default_rng(3)
+    n = 5000
+    rays = scenes.random_rays(n, seed=12)
+    t = rng.uniform(0.1, 5.0, n)
+    surf = rng.integers(-1, 4, n).astype(np.int64)
+    ds = engine.DeviceScene(SceneSnapshot(build("custom_retro")[0]))
+    d_rays, d_t, d_surf = torch.from_numpy(rays).cuda(), torch.from_numpy(t).cuda(), torch.from_numpy(surf).cuda()
+    shaded = torch.full((13, n), -7.0, dtype=torch.float64, device="cuda")
+    for sid in (2, 0, 9):
+        subset, index = ds.gather_hits(d_rays, d_t, d_surf, sid)
+        mask = surf == sid
+        want = rays[:, mask].copy()
+        want[0:4] += want[4:8] * t[mask]
+        assert np.array_equal(index.cpu().numpy(), np.flatnonzero(mask))
+        assert np.array_equal(subset.cpu().numpy(), want)
+        ds.scatter_shaded((subset * 2).contiguous(), index, shaded)
+    got = shaded.cpu().numpy()
+    for sid in (2, 0):
+        mask = surf == sid
+        want = rays[:, mask].copy()
+        want[0:4] += want[4:8] * t[mask]
+        assert np.array_equal(got[:, mask], 2 * want)
+    assert np.all(got[:, ~np.isin(surf, (0, 2))] == -7.0)
+    ds.close()
+
+
+@pytest.mark.parametrize("distinct,n", [(1, 100_000), (7, 100_000), (3000, 200_000), (5000, 50_000), (50_000, 50_000)])
+def test_distinct_values_on_the_device(distinct, n):
+    rng = np.random.default_rng(distinct)
+    pool = rng.uniform(0.3, 1.2, distinct)
+    if distinct >= 7:
+        pool[:3] = (0.0, -0.0, np.inf)
+    values = pool[rng.integers(0, distinct, n)]
+    values[:distinct] = pool  # every one of them occurs
+    lib = engine.library()
+    cap = engine.UNIQUE_CAP
+    d_values = torch.from_numpy(values).cuda()
+    out = torch.zeros(cap, dtype=torch.float64, device="cuda")
+    work = torch.empty(int(lib.prt_unique_workspace_bytes(cap)), dtype=torch.uint8, device="cuda")
+    count = ctypes.c_int64(0)
+    engine._check(lib.prt_unique_values(0, d_values.data_ptr(), n, out.data_ptr(), cap, ctypes.byref(count),
+                                        work.data_ptr(), None))
+    want = np.unique(values.view(np.uint64))  # bit patterns: +0 and -0 are two values
+    if len(want) <= cap:
+        assert count.value == len(want)
+        assert np.array_equal(np.sort(out[:count.value].cpu().numpy().view(np.uint64)), want)
+    else:
+        assert count.value > cap
+    # the binding's view of it: by value, whatever the count
+    rays = torch.zeros((13, n), dtype=torch.float64, device="cuda")
+    rays[10] = d_values
+    ds = engine.DeviceScene(SceneSnapshot(build("custom_retro")[0]))
+    assert np.array_equal(np.unique(ds.distinct_wavelengths(rays)), np.unique(values))
+    ds.close()
+
+
+def test_interact_takes_host_shaded_rays_as_given():
+    """prt_interact with a `shaded` block: rays on a PRT_MAT_HOST surface get all 13 rows from it (generation
+    excepted), the record row keeps the pre-hit metadata, everything else is shaded by the kernels."""
+    fx = helpers.load("scene_custom_retro.npz")
+    parts, rays = build("custom_retro")
+    snap = SceneSnapshot(parts)
+    assert [p for p, _ in snap.host_surfaces] == [1]
+    ds = engine.DeviceScene(snap)
+    with pytest.raises(TypeError):
+        ds.trace(torch.from_numpy(rays).cuda(), 6)
+    cur = torch.from_numpy(rays).cuda()
+    for g in range(3):
+        t, surf = ds.propagate(cur)
+        assert np.array_equal(surf.cpu().numpy(), fx[f"surf_{g}"])
+        if g % 2 == 0:  # the built-in mirror: no block needed
+            rows, nxt = ds.interact(cur, t, surf, g, 6)
+        else:
+            with pytest.raises(AttributeError):  # nobody shaded the rays on the user's surface
+                ds.interact(cur, t, surf, g, 6)
+            subset, index = ds.gather_hits(cur, t, surf, snap.host_surfaces[0][1].get_id())
+            answer = subset.clone()
+            answer[4:8] *= -1
+            answer[9] = 42.0
+            shaded = ds.scatter_shaded(answer, index, torch.empty_like(cur))
+            rows, nxt = ds.interact(cur, t, surf, g, 6, shaded=shaded)
+            assert np.all(nxt[9].cpu().numpy() == 42.0) and np.all(rows[1].cpu().numpy() == 100.0)
+            nxt[9] = 100.0
+        assert np.allclose(nxt.cpu().numpy(), fx[f"next_{g}"], rtol=0, atol=helpers.ATOL)
+        cur = nxt.contiguous()
+    ds.close()
+
+
+def test_c_abi_rejects_a_host_surface_in_the_fused_trace():
+    parts, rays = build("custom_retro")
+    ds = engine.DeviceScene(SceneSnapshot(parts))
+    dev = torch.from_numpy(rays).cuda()
+    lib = engine.library()
+    rows = torch.empty((15, 60), dtype=torch.float64, device="cuda")
+    work = torch.empty(int(lib.prt_trace_workspace_bytes(10)), dtype=torch.uint8, device="cuda")
+    counts = (ctypes.c_int64 * 6)()
+    for flags in (0, engine.TRACE_UNFUSED):
+        rc = lib.prt_trace(ds.handle, 0, dev.data_ptr(), 10, dev.stride(0), 6, 1e-6, rows.data_ptr(), 60, counts,
+                           work.data_ptr(), flags, None)
+        assert rc == engine.ERR_UNTRACABLE and b"PRT_MAT_HOST" in lib.prt_last_error()
+    ds.close()

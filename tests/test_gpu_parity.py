@@ -46,7 +46,7 @@ def test_library_loads_on_gpu():
     from pyrayt_amd import engine
 
     lib = engine.library()
-    assert lib.prt_version() == 100
+    assert lib.prt_version() == engine.PRT_VERSION
     assert lib.prt_device_count() >= 1
 
 
@@ -1018,6 +1018,13 @@ def test_trace_many_overlaps_traces_and_keeps_their_frames():
         for k, ((rows, counts), (ref_rows, ref_counts)) in enumerate(zip(got, want)):
             assert counts == ref_counts, (depth, k)
             assert np.array_equal(rows, ref_rows, equal_nan=True), (depth, k)
+        # the lifetime the docstring states: a result may be HELD while the next one is taken (a design loop
+        # comparing frame k with frame k + 1) -- the view handed out is not the block recorded into next
+        held = None
+        for k, (rows, counts) in enumerate(ds.trace_many(iter(sets), limit, depth=depth)):
+            if held is not None:
+                assert np.array_equal(held.cpu().numpy(), want[k - 1][0], equal_nan=True), (depth, k, "held frame changed")
+            held = rows
     ds.close()
 
 
