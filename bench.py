@@ -189,8 +189,11 @@ def main():
     # ticket stream would share a queue with another and serialise with it.  Small shards gain from a fourth trace
     # in flight (profiles/r3/streams.txt: 125k rays 24.7 -> 23.1 us per step), so this process asks for eight queues
     # -- before the runtime is loaded; a setting the user made stays.
+    # (pyrayt_amd.engine does that when it is imported before torch -- a plain script gets it too; here explicitly, for
+    # the record the line carries)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import numpy as np
+    from pyrayt_amd import engine  # before torch: see engine._ask_for_hardware_queues
     import torch
 
     import scenes

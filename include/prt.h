@@ -34,7 +34,7 @@ extern "C" {
 
 #define PRT_VERSION 200 /* 0.2.0: prt_interact takes the caller-shaded state, PRT_MAT_TABLE / PRT_MAT_HOST,
                            prt_scene_set_index_tables, prt_gather_hits / prt_scatter_shaded, prt_unique_values,
-                           prt_frame_allreduce.  A caller built against another version must not load this library:
+                           prt_frame_stats_sharded / prt_frame_pivots / prt_frame_finish.  A caller built against another version must not load this library:
                            prt_version() is there to be compared with this constant (pyrayt_amd.engine.library does). */
 
 /* ---- ray buffer layout: pyrayt/_pyrayt.py:13-144 (RaySet) -------------------------------
@@ -433,6 +433,22 @@ int64_t prt_frame_stats_workspace_bytes(int n_groups);
 int prt_frame_stats(int device, const double* rows, int64_t ld, int64_t n_rows, double surface,
                     double generation, double rays_per_source, int n_groups, double* out, void* workspace,
                     void* stream);
+/* The same statistics of a frame that is spread over the ranks of a communicator -- a sharded trace whose rows were
+ * NOT re-assembled (each rank holds the rows of its own id range): every rank reduces its own rows and the
+ * (n_groups, 9) sums of each pass are added across the ranks with one ncclAllReduce (the second pass runs about the
+ * whole frame's means, which every rank then holds).  Every rank receives the statistics of the whole frame; what
+ * crosses xGMI is 72 bytes per group and pass instead of the frame (315 MB into every GPU for the north-star job).
+ * Stream-ordered; same `out` and `workspace` as prt_frame_stats.  Row order plays no part: any partition of the
+ * rows gives the same sums (up to the rounding of the additions). */
+int prt_frame_stats_sharded(prt_comm* comm, const double* rows, int64_t ld, int64_t n_rows, double surface,
+                            double generation, double rays_per_source, int n_groups, double* out, void* workspace,
+                            void* stream);
+/* The steps between and behind the two passes on their own, for sums added across ranks by another transport
+ * (prt_frame_reduce on every rank -> add -> prt_frame_pivots -> prt_frame_reduce about them -> add ->
+ * prt_frame_finish): pivots_out (n_groups, 3) = per group the means (y1, z1, axis intercept) of a first pass's sums;
+ * out (n_groups, 8) = the statistics from a second pass's sums and the pivots it ran about.  All device pointers. */
+int prt_frame_pivots(int device, const double* sums, int n_groups, double* pivots_out, void* stream);
+int prt_frame_finish(int device, const double* sums, const double* pivots, int n_groups, double* out, void* stream);
 
 /* statistics of the trace of this scene that ended last (prt_trace / prt_trace_end; for bench.py's roofline):
  * out[0] = generations that found rays, out[1] = sum over generations of rays alive at entry,

@@ -8,6 +8,7 @@ refract shading, dead-ray compaction and record writing -- as hand-written HIP k
 gfx950 behind the C-ABI of ``include/prt.h``.  There is no CPU fallback: tracing without the
 HIP library or without a GPU raises.
 """
+from . import _runtime  # first: asks the HIP runtime for eight hardware queues before torch loads it
 from . import g3d
 from . import materials
 from . import components

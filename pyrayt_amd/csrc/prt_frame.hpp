@@ -188,20 +188,68 @@ extern "C" int64_t prt_frame_stats_workspace_bytes(int n_groups) {
   return n_groups < 1 ? 0 : (int64_t)n_groups * (FRAME_STATS + 3) * (int64_t)sizeof(double);
 }
 
-extern "C" int prt_frame_stats(int device, const double* rows, int64_t ld, int64_t n_rows, double surface,
-                               double generation, double rays_per_source, int n_groups, double* out,
-                               void* workspace, void* stream) {
+// The statistics of a frame whose rows are spread over the ranks of a communicator (a trace with gather "none":
+// every rank holds the rows of its own id range).  The sums of a pass are additive over any partition of the
+// rows, so every rank reduces its own rows and the (n_groups, 9) sums are added across ranks -- one small
+// all-reduce per pass, the second about the pivots of the WHOLE frame's first pass, which every rank then holds.
+// Nothing of the frame itself moves (the alternative, re-assembling it, brings 315 MB into every GPU for the
+// north-star job).  comm == nullptr: the single-rank statistics.
+static int frame_stats_impl(prt_comm* comm, int device, const double* rows, int64_t ld, int64_t n_rows, double surface,
+                            double generation, double rays_per_source, int n_groups, double* out, void* workspace,
+                            hipStream_t st) {
   if (!workspace || !out || n_groups < 1) return fail(PRT_ERR_ARG, "bad buffers");
   double* sums = (double*)workspace;
   double* pivots = sums + (size_t)n_groups * FRAME_STATS;
-  hipStream_t st = (hipStream_t)stream;
+  const size_t n_sums = (size_t)n_groups * FRAME_STATS;
   int rc = prt_frame_reduce(device, rows, ld, n_rows, surface, generation, rays_per_source, n_groups, nullptr, sums, st);
   if (rc) return rc;
+  if (comm) RCCL_TRY(g_rccl.AllReduce(sums, sums, n_sums, ncclDouble, ncclSum, comm->comm, st));
   const dim3 grid((n_groups + PRT_BLOCK - 1) / PRT_BLOCK);
   hipLaunchKernelGGL(k_frame_pivots, grid, dim3(PRT_BLOCK), 0, st, sums, n_groups, pivots);
   rc = prt_frame_reduce(device, rows, ld, n_rows, surface, generation, rays_per_source, n_groups, pivots, sums, st);
   if (rc) return rc;
+  if (comm) RCCL_TRY(g_rccl.AllReduce(sums, sums, n_sums, ncclDouble, ncclSum, comm->comm, st));
   hipLaunchKernelGGL(k_frame_finish, grid, dim3(PRT_BLOCK), 0, st, sums, pivots, n_groups, out);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}
+
+extern "C" int prt_frame_stats(int device, const double* rows, int64_t ld, int64_t n_rows, double surface,
+                               double generation, double rays_per_source, int n_groups, double* out,
+                               void* workspace, void* stream) {
+  return frame_stats_impl(nullptr, device, rows, ld, n_rows, surface, generation, rays_per_source, n_groups, out,
+                          workspace, (hipStream_t)stream);
+}
+
+extern "C" int prt_frame_stats_sharded(prt_comm* comm, const double* rows, int64_t ld, int64_t n_rows, double surface,
+                                       double generation, double rays_per_source, int n_groups, double* out,
+                                       void* workspace, void* stream) {
+  if (!comm) return fail(PRT_ERR_ARG, "communicator is null");
+  return frame_stats_impl(comm, comm->device, rows, ld, n_rows, surface, generation, rays_per_source, n_groups, out,
+                          workspace, (hipStream_t)stream);
+}
+
+// The two small steps between and behind the passes on their own, for sums that are added across ranks by another
+// transport (torch.distributed over gloo in the tests; MPI): prt_frame_reduce -> add -> prt_frame_pivots ->
+// prt_frame_reduce about them -> add -> prt_frame_finish.  sums (n_groups, 9), pivots (n_groups, 3), out
+// (n_groups, 8): device.
+extern "C" int prt_frame_pivots(int device, const double* sums, int n_groups, double* pivots_out, void* stream) {
+  if (!sums || !pivots_out || n_groups < 1) return fail(PRT_ERR_ARG, "bad buffers");
+  int rc = ops_device(device);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_frame_pivots, dim3((n_groups + PRT_BLOCK - 1) / PRT_BLOCK), dim3(PRT_BLOCK), 0,
+                     (hipStream_t)stream, sums, n_groups, pivots_out);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}
+
+extern "C" int prt_frame_finish(int device, const double* sums, const double* pivots, int n_groups, double* out,
+                                void* stream) {
+  if (!sums || !pivots || !out || n_groups < 1) return fail(PRT_ERR_ARG, "bad buffers");
+  int rc = ops_device(device);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_frame_finish, dim3((n_groups + PRT_BLOCK - 1) / PRT_BLOCK), dim3(PRT_BLOCK), 0,
+                     (hipStream_t)stream, sums, pivots, n_groups, out);
   HIP_TRY(hipGetLastError());
   return PRT_OK;
 }

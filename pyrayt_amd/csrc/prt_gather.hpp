@@ -23,6 +23,7 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -43,10 +44,11 @@ static int rccl_load() {
   api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
   api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
   api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
+  api.AllReduce = (decltype(api.AllReduce))dlsym(h, "ncclAllReduce");
   api.GroupStart = (decltype(api.GroupStart))dlsym(h, "ncclGroupStart");
   api.GroupEnd = (decltype(api.GroupEnd))dlsym(h, "ncclGroupEnd");
   api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
-  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GroupStart ||
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.AllReduce || !api.GroupStart ||
       !api.GroupEnd || !api.GetErrorString)
     return fail(PRT_ERR_HIP, "librccl lacks an expected symbol");
   g_rccl = api;

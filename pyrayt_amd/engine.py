@@ -6,6 +6,7 @@ functions in this module raise -- there is deliberately no CPU fallback.
 """
 import ctypes
 import os
+import warnings
 
 import numpy as np
 
@@ -13,6 +14,9 @@ from . import scene as _scene
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PRT_LIB", os.path.join(_HERE, "csrc", "libprt_hip.so"))
+
+
+from ._runtime import HW_QUEUES  # (set when the package is imported, before anything loads the HIP runtime)
 
 RAY_ROWS = 13
 RECORD_COLS = 15
@@ -131,6 +135,9 @@ def _declare(lib):
         "prt_frame_reduce": (c_int, [c_int, c_p, c_i64, c_i64, c_d, c_d, c_d, c_int, c_p, c_p, c_p]),
         "prt_frame_stats_workspace_bytes": (c_i64, [c_int]),
         "prt_frame_stats": (c_int, [c_int, c_p, c_i64, c_i64, c_d, c_d, c_d, c_int, c_p, c_p, c_p]),
+        "prt_frame_stats_sharded": (c_int, [c_p, c_p, c_i64, c_i64, c_d, c_d, c_d, c_int, c_p, c_p, c_p]),
+        "prt_frame_pivots": (c_int, [c_int, c_p, c_int, c_p, c_p]),
+        "prt_frame_finish": (c_int, [c_int, c_p, c_p, c_int, c_p, c_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = the library does not match prt.h
@@ -151,7 +158,7 @@ EXPORTED_SYMBOLS = (
     "prt_primitive_normal", "prt_comm_unique_id", "prt_comm_create", "prt_comm_destroy",
     "prt_allgather_counts", "prt_allgather_workspace_bytes", "prt_allgather_rows",
     "prt_place_workspace_bytes", "prt_place_rows", "prt_frame_reduce", "prt_frame_stats_workspace_bytes",
-    "prt_frame_stats",
+    "prt_frame_stats", "prt_frame_stats_sharded", "prt_frame_pivots", "prt_frame_finish",
 )
 
 
@@ -557,6 +564,12 @@ class DeviceScene:
         runtime maps streams onto a handful of hardware queues -- four by default -- and two streams that
         land on one queue run their kernels one after the other, so a program should not keep making new ones)."""
         torch = _torch()
+        limit = 4 if HW_QUEUES == "late" else int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
+        if depth + 1 > limit and not getattr(DeviceScene, "_warned_queues", False):
+            DeviceScene._warned_queues = True
+            warnings.warn(f"{depth} traces in flight need {depth + 1} hardware queues (one is the null stream's) but the HIP "
+                          f"runtime has {limit}: streams that share a queue serialise.  Import pyrayt_amd before torch (it "
+                          "then sets GPU_MAX_HW_QUEUES=8) or set the variable yourself.", RuntimeWarning, stacklevel=3)
         made = getattr(self, "_ticket_streams", None)
         if made is None or made[0] != device:
             made = self._ticket_streams = (device, [])

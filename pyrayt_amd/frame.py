@@ -64,7 +64,7 @@ class DeviceFrame:
         return DeviceFrame(self.rows[:, mask])
 
     # --- reductions the notebook does on the frame -------------------------------------------------
-    def group_stats(self, surface=None, generation=None, rays_per_source=None, n_groups=None):
+    def group_stats(self, surface=None, generation=None, rays_per_source=None, n_groups=None, group=None, comm=None):
         """Per-source statistics of the rows that hit ``surface`` and / or belong to ``generation``
         (``examples/lens_design.ipynb`` cells 11-16: ``results.loc[results['surface'] == id]``
         grouped by ``source_id = id // rays_per_source``, ``_pyrayt.py:349-354``).
@@ -75,13 +75,26 @@ class DeviceFrame:
         estimate), ``wavelength`` and ``intensity`` (means).  One library call (``prt_frame_stats``): the
         HIP reduction kernel runs twice, the second pass about the first pass's per-group means so that
         the second moments are well conditioned, and the final arithmetic happens on the device too.
-        Without ``rays_per_source`` everything is one group."""
+        Without ``rays_per_source`` everything is one group.
+
+        ``group`` (a ``torch.distributed`` group) or ``comm`` (a ``pyrayt_amd.distributed.LibraryComm``): this
+        frame holds one rank's rows of a sharded trace (``RayTracer(..., gather="none")``) and the statistics
+        wanted are those of the WHOLE frame.  Every rank reduces its own rows; the per-group sums -- nine doubles a
+        group -- are added across the ranks (RCCL all-reduce inside the library with ``comm``; ``torch.distributed``
+        with a group of another backend), once per pass.  Every rank gets the full statistics and the rows stay
+        where they are: the alternative, re-assembling the frame, moves 315 MB into every GPU for a 1M-ray trace.
+        Collective: every rank of the group calls it, with the same arguments (``n_groups`` included, or None)."""
+        sharded = group is not None or comm is not None
         if rays_per_source:
             if n_groups is None:
-                n_groups = int(float(self["id"].max()) // rays_per_source) + 1 if len(self) else 1
+                top = float(self["id"].max()) if len(self) else -1.0
+                if sharded:
+                    top = _all_reduce_max(top, group, comm, self.rows.device)
+                n_groups = max(1, int(top // rays_per_source) + 1)
         else:
             n_groups = 1
-        stats = self._stats(surface, generation, rays_per_source, n_groups)
+        stats = (self._stats_sharded(surface, generation, rays_per_source, n_groups, group, comm) if sharded
+                 else self._stats(surface, generation, rays_per_source, n_groups))
         frame = pd.DataFrame({
             "count": stats[:, 0].astype(np.int64), "y": stats[:, 1], "z": stats[:, 2], "rms_radius": stats[:, 3],
             "focus": stats[:, 4], "focus_std": stats[:, 5], "wavelength": stats[:, 6], "intensity": stats[:, 7],
@@ -110,6 +123,69 @@ class DeviceFrame:
             float(rays_per_source or 0), n_groups, out.data_ptr(), work.data_ptr(), engine._stream_ptr(torch, dev)))
         return out.cpu().numpy()
 
+    def _reduce_pass(self, surface, generation, rays_per_source, n_groups, pivots):
+        """One pass of ``prt_frame_reduce`` over this frame's rows: the (n_groups, 9) sums, on the device."""
+        import torch
+
+        from . import engine
+
+        rows = self.rows if self.rows.stride(1) == 1 else self.rows.contiguous()
+        dev = rows.device
+        sums = torch.empty((n_groups, 9), dtype=torch.float64, device=dev)
+        nan = float("nan")
+        engine._check(engine.library().prt_frame_reduce(
+            dev.index or 0, rows.data_ptr(), max(rows.stride(0), 1), rows.shape[1],
+            nan if surface is None else float(surface), nan if generation is None else float(generation),
+            float(rays_per_source or 0), n_groups, pivots.data_ptr() if pivots is not None else None,
+            sums.data_ptr(), engine._stream_ptr(torch, dev)))
+        return sums
+
+    def _stats_sharded(self, surface, generation, rays_per_source, n_groups, group, comm):
+        """The whole frame's statistics from this rank's rows (see ``group_stats``)."""
+        import torch
+
+        from . import engine
+
+        lib = engine.library()
+        nan = float("nan")
+        if comm is not None:  # one library call: both passes, two ncclAllReduce of (n_groups, 9) doubles
+            rows = self.rows if self.rows.stride(1) == 1 else self.rows.contiguous()
+            dev = rows.device
+            out = torch.empty((n_groups, 8), dtype=torch.float64, device=dev)
+            work = torch.empty(int(lib.prt_frame_stats_workspace_bytes(n_groups)), dtype=torch.uint8, device=dev)
+            engine._check(lib.prt_frame_stats_sharded(
+                comm._handle, rows.data_ptr(), max(rows.stride(0), 1), rows.shape[1],
+                nan if surface is None else float(surface), nan if generation is None else float(generation),
+                float(rays_per_source or 0), n_groups, out.data_ptr(), work.data_ptr(), engine._stream_ptr(torch, dev)))
+            return out.cpu().numpy()
+        # another transport adds the sums: the passes and the two small steps are separate library calls
+        sums = _all_reduce_sum(self._reduce_pass(surface, generation, rays_per_source, n_groups, None), group)
+        pivots = self._pivots(sums, n_groups)
+        sums = _all_reduce_sum(self._reduce_pass(surface, generation, rays_per_source, n_groups, pivots), group)
+        return self._finish(sums, pivots, n_groups).cpu().numpy()
+
+    def _pivots(self, sums, n_groups):
+        """``prt_frame_pivots``: per group the means a second pass accumulates about, (n_groups, 3) on the device."""
+        import torch
+
+        from . import engine
+
+        pivots = torch.empty((n_groups, 3), dtype=torch.float64, device=sums.device)
+        engine._check(engine.library().prt_frame_pivots(sums.device.index or 0, sums.data_ptr(), n_groups, pivots.data_ptr(),
+                                                        engine._stream_ptr(torch, sums.device)))
+        return pivots
+
+    def _finish(self, sums, pivots, n_groups):
+        """``prt_frame_finish``: a second pass's sums and its pivots -> the (n_groups, 8) statistics, on the device."""
+        import torch
+
+        from . import engine
+
+        out = torch.empty((n_groups, 8), dtype=torch.float64, device=sums.device)
+        engine._check(engine.library().prt_frame_finish(sums.device.index or 0, sums.data_ptr(), pivots.data_ptr(), n_groups,
+                                                        out.data_ptr(), engine._stream_ptr(torch, sums.device)))
+        return out
+
     def spot(self, plane=("y1", "z1")):
         """(centroid, rms radius) of the end points in a transverse plane."""
         if tuple(plane) == ("y1", "z1") and getattr(self.rows, "is_cuda", False) and len(self):
@@ -137,3 +213,29 @@ class DeviceFrame:
         if values.shape[0] == 0:
             return pd.DataFrame(columns=COLUMNS, dtype="float64")
         return pd.DataFrame(values, columns=COLUMNS, copy=False)
+
+
+def _all_reduce_sum(tensor, group):
+    """Sum of a small device tensor over the ranks of a torch.distributed group (through the host for a backend
+    that does not take device tensors)."""
+    import torch.distributed as dist
+
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(tensor, group=group)
+        return tensor
+    host = tensor.cpu()
+    dist.all_reduce(host, group=group)
+    return host.to(tensor.device)
+
+
+def _all_reduce_max(value, group, comm, device):
+    """Largest of a host number over the ranks (the highest ray id: how many source groups there are)."""
+    import torch
+    import torch.distributed as dist
+
+    if group is None:  # a bare library communicator: the count is the caller's to give
+        raise ValueError("group_stats over a LibraryComm needs n_groups (or pass the torch.distributed group as well)")
+    on = device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    box = torch.tensor([value], dtype=torch.float64, device=on)
+    dist.all_reduce(box, op=dist.ReduceOp.MAX, group=group)
+    return float(box[0])

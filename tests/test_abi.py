@@ -195,3 +195,22 @@ def test_generation_kernel_keeps_its_register_allocation(lib_path):
     for name, res in kernels.items():
         assert res["private_segment_fixed_size"] == 0, (name, res)
         assert res["vgpr_spill_count"] == 0 and res["vgpr_count"] <= 96, (name, res)
+
+
+def test_package_asks_for_hardware_queues_before_the_runtime_loads():
+    """GPU_MAX_HW_QUEUES has to be in the environment before torch loads the HIP runtime: importing pyrayt_amd
+    first sets it (a fourth trace in flight then gets a queue of its own); a user's setting stays; importing
+    torch first is noticed, and asking for more traces in flight than the runtime has queues warns."""
+    import sys
+
+    def run(code, env_extra=None):
+        env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+        env.update(env_extra or {})
+        done = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+        assert done.returncode == 0, done.stderr[-1500:]
+        return done.stdout.split()
+
+    show = "import pyrayt_amd.engine as e, os; print(e.HW_QUEUES, os.environ.get('GPU_MAX_HW_QUEUES'))"
+    assert run(show) == ["set", "8"]
+    assert run("import torch; " + show) == ["late", "None"]
+    assert run(show, {"GPU_MAX_HW_QUEUES": "2"}) == ["user", "2"]

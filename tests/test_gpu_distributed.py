@@ -167,14 +167,13 @@ def _rccl_worker(rank, world, port, name, n, mode, result_dir):
 @pytest.mark.parametrize("name,n,mode", [("config2", 20011, "all"), ("config3", 9001, "root"),
                                          ("stopped_lens", 6007, "all")])
 def test_rccl_allgather_rows_across_real_devices(tmp_path, name, n, mode):
-    """The first execution of prt_allgather_rows with more than one rank: min(devices, 4) ranks, one
-    device each, assembled frame bit-identical to the single-rank frame on every rank ("all") or on
+    """The first execution of prt_allgather_rows with more than one rank: one rank per device of the box, assembled frame bit-identical to the single-rank frame on every rank ("all") or on
     rank 0 ("root")."""
     import torch.multiprocessing as mp
 
     from pyrayt_amd import engine
 
-    world = min(torch.cuda.device_count(), 4)
+    world = torch.cuda.device_count()  # every device of the box: the BASELINE curve ends at 8
     ctx = mp.start_processes(_rccl_worker, args=(world, _free_port(), name, n, mode, str(tmp_path)), nprocs=world,
                              join=False, start_method="spawn")
     deadline = time.time() + 300  # (a rank that dies leaves the others waiting in a collective: do not hang the suite)
@@ -234,3 +233,159 @@ def test_bench_launches_its_own_ranks_sharing_one_gpu():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     assert line["config"]["rays_per_gpu"] == 50000
     assert "ms" in line["gather"], line["gather"]
+
+
+# ---- sharded result sink: statistics of the whole frame from the rows every rank kept ----------------------------
+def _stats_of(frame, detector, rays_per_source, **how):
+    return frame.group_stats(surface=detector, rays_per_source=rays_per_source, **how)[
+        ["count", "y", "z", "rms_radius", "focus", "focus_std", "wavelength", "intensity"]].to_numpy(dtype=float)
+
+
+def _stats_worker(rank, world, port, name, n, rays_per_source, result_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyrayt_amd import distributed as pdist
+        from pyrayt_amd import engine
+        from pyrayt_amd.frame import DeviceFrame
+
+        torch.cuda.set_device(0)
+        snap, rays = _scene_and_rays(name, n)
+        group = pdist.resolve_group(None)
+        lo, hi = pdist.shard_bounds(rays.shape[1], group)
+        scene = engine.DeviceScene(snap)
+        rows, counts = scene.trace(torch.from_numpy(np.ascontiguousarray(rays[:, lo:hi])).to("cuda:0"), LIMIT)
+        detector = float(snap.prims["surface_id"][-1])
+        got = _stats_of(DeviceFrame(rows, counts), detector, rays_per_source, group=group)  # the rows stay where they are
+        np.save(os.path.join(result_dir, f"stats_{rank}.npy"), got)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,n,rays_per_source,world", [("config2", 20011, 2500, 2), ("config3", 9001, None, 3),
+                                                          ("config2", 40000, 5000, 8)])
+def test_sharded_group_stats_on_the_gpu(tmp_path, name, n, rays_per_source, world):
+    """2, 3 and 8 ranks sharing the one GPU (gloo adds the sums): every rank gets the single-rank statistics."""
+    import torch.multiprocessing as mp
+
+    from pyrayt_amd import engine
+    from pyrayt_amd.frame import DeviceFrame
+
+    mp.start_processes(_stats_worker, args=(world, _free_port(), name, n, rays_per_source, str(tmp_path)), nprocs=world,
+                       join=True, start_method="spawn")
+    snap, rays = _scene_and_rays(name, n)
+    rows, counts = engine.DeviceScene(snap).trace(torch.from_numpy(rays).to("cuda:0"), LIMIT)
+    want = _stats_of(DeviceFrame(rows, counts), float(snap.prims["surface_id"][-1]), rays_per_source)
+    assert np.isfinite(want[:, 1]).any()
+    for rank in range(world):
+        got = np.load(tmp_path / f"stats_{rank}.npy")
+        assert got.shape == want.shape and np.array_equal(got[:, 0], want[:, 0])
+        assert np.allclose(got, want, rtol=0, atol=1e-12, equal_nan=True), (rank, np.nanmax(np.abs(got - want)))
+
+
+def test_sharded_group_stats_over_a_one_rank_rccl_communicator():
+    """prt_frame_stats_sharded itself (two ncclAllReduce inside the library) with the one rank a 1-GPU box allows."""
+    from pyrayt_amd import distributed as pdist
+    from pyrayt_amd import engine
+    from pyrayt_amd.frame import DeviceFrame
+
+    snap, rays = _scene_and_rays("config2", 30000)
+    rows, counts = engine.DeviceScene(snap).trace(torch.from_numpy(rays).to("cuda:0"), LIMIT)
+    frame = DeviceFrame(rows, counts)
+    detector = float(snap.prims["surface_id"][-1])
+    comm = pdist.LibraryComm(0, 1, 0, pdist.LibraryComm.unique_id())
+    try:
+        want = _stats_of(frame, detector, 3000)
+        got = _stats_of(frame, detector, 3000, comm=comm, n_groups=10)
+        assert np.array_equal(got, want, equal_nan=True)
+        with pytest.raises(ValueError):
+            frame.group_stats(surface=detector, rays_per_source=3000, comm=comm)  # how many groups is the caller's to say
+    finally:
+        comm.close()
+
+
+def _rccl_stats_worker(rank, world, port, name, n, rays_per_source, result_dir):
+    import datetime
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    device = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(seconds=120))
+    try:
+        from pyrayt_amd import distributed as pdist
+        from pyrayt_amd import engine
+        from pyrayt_amd.frame import DeviceFrame
+
+        snap, rays = _scene_and_rays(name, n)
+        group = pdist.resolve_group(None)
+        lo, hi = pdist.shard_bounds(rays.shape[1], group)
+        rows, counts = engine.DeviceScene(snap).trace(torch.from_numpy(np.ascontiguousarray(rays[:, lo:hi])).to(device), LIMIT)
+        detector = float(snap.prims["surface_id"][-1])
+        comm = pdist.LibraryComm.from_group(group, device)
+        try:
+            got = _stats_of(DeviceFrame(rows, counts), detector, rays_per_source, group=group, comm=comm)
+        finally:
+            comm.close()
+        np.save(os.path.join(result_dir, f"stats_{rank}.npy"), got)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two or more GPUs (one RCCL rank per device)")
+def test_rccl_sharded_group_stats_across_real_devices(tmp_path):
+    """prt_frame_stats_sharded over every device of the box (one rank each): all ranks get the single-rank statistics."""
+    import torch.multiprocessing as mp
+
+    from pyrayt_amd import engine
+    from pyrayt_amd.frame import DeviceFrame
+
+    world = torch.cuda.device_count()
+    name, n, rays_per_source = "config2", 40000, 5000
+    ctx = mp.start_processes(_rccl_stats_worker, args=(world, _free_port(), name, n, rays_per_source, str(tmp_path)),
+                             nprocs=world, join=False, start_method="spawn")
+    deadline = time.time() + 300
+    while not ctx.join(timeout=5):
+        if time.time() > deadline:
+            for proc in ctx.processes:
+                proc.terminate()
+            pytest.fail("the RCCL ranks did not finish within 300 s")
+    snap, rays = _scene_and_rays(name, n)
+    rows, counts = engine.DeviceScene(snap).trace(torch.from_numpy(rays).to("cuda:0"), LIMIT)
+    want = _stats_of(DeviceFrame(rows, counts), float(snap.prims["surface_id"][-1]), rays_per_source)
+    for rank in range(world):
+        got = np.load(tmp_path / f"stats_{rank}.npy")
+        assert np.allclose(got, want, rtol=0, atol=1e-12, equal_nan=True), rank
+
+
+# ---- the BASELINE partitions at world 8 with real HIP traces: eight ranks sharing the one GPU ---------------------
+@pytest.mark.parametrize("name,n,mode", [("config4", 8 * 512, "all"), ("config5", 16001, "all")])
+def test_baseline_partitions_at_world_eight_sharing_one_gpu(tmp_path, name, n, mode):
+    """BASELINE config 4 (8 wavelengths, one per rank: contiguous id shards give exactly that) and config 5
+    (generation_limit 10) over 8 ranks; the blocks travel over gloo, prt_place_rows orders them on the device."""
+    import torch.multiprocessing as mp
+
+    from pyrayt_amd import engine
+
+    world = 8
+    per_call = n // 8 if name == "config4" else n
+    mp.start_processes(_worker, args=(world, _free_port(), name, per_call, mode, str(tmp_path)), nprocs=world,
+                       join=True, start_method="spawn")
+    snap, rays = _scene_and_rays(name, per_call)
+    if name == "config4":
+        from pyrayt_amd import distributed as pdist
+
+        for rank in range(world):
+            lo, hi = pdist.shard_bounds(rays.shape[1], rank=rank, world=world)
+            assert np.all(rays[10, lo:hi] == np.linspace(0.44, 0.75, 8)[rank])  # one source / wavelength per rank
+    rows, counts = engine.DeviceScene(snap).trace(torch.from_numpy(rays).to("cuda:0"), LIMIT)
+    want = rows.cpu().numpy()
+    for rank in range(world):
+        assert np.load(tmp_path / f"counts_{rank}.npy").tolist() == counts
+        assert np.array_equal(np.load(tmp_path / f"rows_{rank}.npy"), want, equal_nan=True)
