@@ -150,7 +150,9 @@ typedef struct prt_scene_options {
   int32_t list_order_groups; /* 1: the cull-step hierarchy groups components in list order only (the
                            round-2 form); 0: by position in space when that is tighter */
   int32_t one_direction;     /* 1: a grouped trace program is stored once, not also in mirror image */
-  int32_t reserved[6];
+  int32_t no_intervals;      /* 1: chain steps whose nodes are all INTERSECT run the general CSG node algebra instead of
+                                the interval form (an intersection of the leaves' [enter, exit] intervals) */
+  int32_t reserved[5];
 } prt_scene_options;
 
 /* Build a scene from a snapshot.  roots[] lists the node index of every top-level component

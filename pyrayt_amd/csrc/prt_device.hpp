@@ -87,7 +87,8 @@ struct DevChain {
   int32_t op1, op2;      // CSG_*
   int32_t prim[3];
   int32_t implied1, implied2;  // cull box implied by the survivors (see csg_keep)
-  int32_t pad[2];
+  int32_t shared_rows;         // the leaves' M^-1 agree bit for bit in their linear part (see SharedRows)
+  int32_t intervals;           // every node INTERSECT with an implied box: the interval form applies (chain_candidate)
   double box1[6], box2[6];     // upstream cull boxes of the two nodes (csg.py:126-128)
   double leaf[3][18];          // params[0..5], M^-1 rows 0..2 [6..17]
 };
@@ -129,6 +130,20 @@ struct Ray8 {
 // of the ray and is written out at every site: holding its value across the hit phase instead costs the
 // generation kernel its register allocation -- the lane mask lives in SGPRs, of which the kernel has none
 // to spare -- while the compiler is free to share it between neighbouring sites as it is.)
+#ifndef PRT_CHAIN_SHARED
+#define PRT_CHAIN_SHARED 0     // chain steps: leaves that share the linear part of M^-1 share its partial sums (A/B: 1; costs the
+                               // generation kernel its register allocation: 12-28 B of scratch per lane)
+#endif
+#ifndef PRT_GRAZE_MARGIN
+#define PRT_GRAZE_MARGIN 0     // implied cull boxes: a grazing axis takes the exact test only near a face of the box (A/B: 1;
+                               // measured: config 3 -1.5 %, config 2 +0.8 % with 20 B of scratch per lane: not adopted)
+#endif
+#ifndef PRT_SEGMENT_CULL
+#define PRT_SEGMENT_CULL 1     // component cull steps: the segment-box test in front of may_reach (A/B: 0)
+#endif
+#ifndef PRT_CHAIN_INTERVALS
+#define PRT_CHAIN_INTERVALS 1  // chain steps: INTERSECT-only chains as interval intersections (A/B: 0)
+#endif
 #define kWellFormedLen2Lo 0.81
 __device__ __forceinline__ bool well_formed(const Ray8& r) {
   if (!r.gated) return false;
@@ -402,6 +417,18 @@ __device__ __forceinline__ void primitive_pair(int type, const double* __restric
 
 // ---- TracerSurface.intersect: world -> object, primitive test, ascending pair -----------------
 // `type`, q = params[6] and m = rows 0..2 of M^-1 (12 values) come from the step record.
+// the primitive test on an object-space ray, reduced to the ascending pair
+__device__ __forceinline__ void object_pair(int type, const double* __restrict__ q, double ox, double oy, double oz,
+                                            double dx, double dy, double dz, double& t0, double& t1) {
+  double h0, h1;
+  primitive_pair(type, q, ox, oy, oz, dx, dy, dz, h0, h1);
+  if (!no_lane(__builtin_isunordered(h0, h1))) {  // (0 / 0 of a zero direction: one compare for the pair)
+    h0 = nan_to_inf(h0);
+    h1 = nan_to_inf(h1);
+  }
+  t0 = fmin(h0, h1);  // NaN-free here: v_min / v_max order the pair like np.sort (signed zeros compare equal)
+  t1 = fmax(h0, h1);
+}
 __device__ __forceinline__ void surface_pair(int type, const double* __restrict__ q,
                                              const double* __restrict__ m, const Ray8& r,
                                              double& t0, double& t1) {
@@ -411,14 +438,31 @@ __device__ __forceinline__ void surface_pair(int type, const double* __restrict_
   const double dx = row_dot(m, 0, r.dx, r.dy, r.dz, r.dw);
   const double dy = row_dot(m, 1, r.dx, r.dy, r.dz, r.dw);
   const double dz = row_dot(m, 2, r.dx, r.dy, r.dz, r.dw);
-  double h0, h1;
-  primitive_pair(type, q, ox, oy, oz, dx, dy, dz, h0, h1);
-  if (!no_lane(__builtin_isunordered(h0, h1))) {  // (0 / 0 of a zero direction: one compare for the pair)
-    h0 = nan_to_inf(h0);
-    h1 = nan_to_inf(h1);
+  object_pair(type, q, ox, oy, oz, dx, dy, dz, t0, t1);
+}
+
+// The leaves of a part share the linear part of their world -> object matrices when the part was moved as a whole
+// (every lens factory: components.py:73-198 builds the faces along the axis and rotates the finished CSG): the
+// first three terms of every row_dot are then the same numbers for all of them.  `Shared` holds those partial
+// sums -- the very fma chain row_dot runs, stopped before the translation term -- and a leaf finishes each with
+// its own fourth term: bit for bit what surface_pair computes, at 6 instead of 24 operations per further leaf.
+struct SharedRows {
+  double o[3], d[3];
+};
+__device__ __forceinline__ SharedRows shared_rows(const double* __restrict__ m, const Ray8& r) {
+  SharedRows s;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    s.o[k] = fma(m[4 * k + 2], r.oz, fma(m[4 * k + 1], r.oy, m[4 * k + 0] * r.ox));
+    s.d[k] = fma(m[4 * k + 2], r.dz, fma(m[4 * k + 1], r.dy, m[4 * k + 0] * r.dx));
   }
-  t0 = fmin(h0, h1);  // NaN-free here: v_min / v_max order the pair like np.sort (signed zeros compare equal)
-  t1 = fmax(h0, h1);
+  return s;
+}
+__device__ __forceinline__ void surface_pair_shared(int type, const double* __restrict__ q,
+                                                    const double* __restrict__ m, const SharedRows& s, const Ray8& r,
+                                                    double& t0, double& t1) {
+  object_pair(type, q, fma(m[3], r.ow, s.o[0]), fma(m[7], r.ow, s.o[1]), fma(m[11], r.ow, s.o[2]),
+              fma(m[3], r.dw, s.d[0]), fma(m[7], r.dw, s.d[1]), fma(m[11], r.dw, s.d[2]), t0, t1);
 }
 
 // ---- primitive.normal in object space (primitives.py Sphere :273-296, Paraboloid :401-419,
@@ -764,6 +808,76 @@ __device__ __forceinline__ void first_positive_else_first(const Operand& o, cons
 // coincident -- tangent rays, a Plane's double hit (t,t) -- take the exact six-division test.
 // UNION nodes always take it (their upstream box can be smaller than the solid).
 
+// The cull box of a node whose box is implied by its survivors (see above): `any` -- the node has survivors, the
+// smallest `lo` and the largest `hi`.  Returns upstream's "touched" (csg.py:126-128) for this ray.
+__device__ __forceinline__ bool implied_touch(const double* __restrict__ aabb, const Ray8& ray, bool any, double lo,
+                                              double hi) {
+  bool touched = true;
+  // (a ray that is not well formed -- a short direction may send a leaf into one of upstream's degenerate
+  // branches without being parallel to anything, and what survives then need not lie in the solid; with
+  // w other than 1 / 0 the object-space ray is not the image of the world ray the box was tested
+  // against -- gets the exact test, like a thin chord.  Found by the short-direction and odd-w fuzz families.)
+  const bool robust = any && well_formed(ray) && lo > -PRT_INF && (hi - lo) > 1e-6 * ((1.0 + fabs(lo)) + fabs(hi));
+  count_paths(ray.paths, 2, any);
+  count_paths(ray.paths, 3, any && !robust);
+  if (any && !robust) touched = box_touched(aabb, ray);
+  // The chord argument covers the axes the ray really moves along: with |d| >= 1e-4 a slab crossing
+  // is off by at most ~1e-12 / |d| <= 1e-8 (rounding, and the 1e-12 by which the compiler lets the
+  // upstream box fall short of the solid's bounds), far below the robust margin.  An axis with
+  // |d| <= 1e-8 has no crossing at all: there upstream's test is the bare comparison lo <= o <= hi
+  // (primitives.py:531-565), which a ray running along a face one ulp outside the box fails however
+  // long its chord through the (object-space) solid is -- found by the adversarial fixtures
+  // (tests/scenes.py adv_lens).  In between (1e-8 < |d| < 1e-4) the exact test decides.
+  const double ax = fabs(ray.dx), ay = fabs(ray.dy), az = fabs(ray.dz);
+  if (__ballot(ax < 1e-4 || ay < 1e-4 || az < 1e-4) != 0ull) {
+    const bool px = ax <= 1e-8, py = ay <= 1e-8, pz = az <= 1e-8;
+    const bool outside = (px && !(ray.ox >= aabb[0] && ray.ox <= aabb[1])) ||
+                         (py && !(ray.oy >= aabb[2] && ray.oy <= aabb[3])) ||
+                         (pz && !(ray.oz >= aabb[4] && ray.oz <= aabb[5]));
+    // (no crossing on any axis -- a zero-direction ray, e.g. an absorbed one carried along: upstream's
+    // box test then returns (-inf, +inf) or (+inf, +inf), never a finite entry, and csg.py:126-128
+    // drops the ray wherever it sits; a paraboloid child would still report the finite -c / 1 of its
+    // linear branch, primitives.py:361 -- found by fuzz seed 8061 of a 12 000-seed run)
+    touched = touched && !outside && !(px && py && pz);
+    // A grazing axis (1e-8 < |d_k| < 1e-4) can only spoil the chord argument if the chord comes close to a face of
+    // the box along it: upstream's slab parameters (lo_k - o_k) / d_k, (hi_k - o_k) / d_k are then huge numbers
+    // with absolute errors to match, but as long as the ray's k coordinate stays inside [lo_k + e, hi_k - e] over
+    // the whole chord [lo, hi] they bracket the chord by e / |d_k| >= 1e4 e on both sides -- their rounding,
+    // 3e-16 |lo_k - o_k| / |d_k|, is eleven orders below that for e = 1e-6 (1 + |lo_k| + |hi_k| + |o_k|) -- and
+    // axis k does not take part in `enter < leave` at all.  Collimated beams are full of such axes (a ray a few
+    // micro-radians off the optical axis), and nearly all of them run well inside the part's box: only a chord
+    // that comes within e of a face (the rim of an aperture) takes the exact test.
+    const bool grazing = (!px && ax < 1e-4) || (!py && ay < 1e-4) || (!pz && az < 1e-4);
+    if (__ballot(grazing && any && robust) != 0ull) {
+      bool near_face = false;
+      {
+        const double at_lo = fma(lo, ray.dx, ray.ox), at_hi = fma(hi, ray.dx, ray.ox);
+        const double e = 1e-6 * (((1.0 + fabs(aabb[0])) + fabs(aabb[1])) + fabs(ray.ox));
+        near_face = !px && ax < 1e-4 && !(fmin(at_lo, at_hi) >= aabb[0] + e && fmax(at_lo, at_hi) <= aabb[1] - e);
+      }
+      {
+        const double at_lo = fma(lo, ray.dy, ray.oy), at_hi = fma(hi, ray.dy, ray.oy);
+        const double e = 1e-6 * (((1.0 + fabs(aabb[2])) + fabs(aabb[3])) + fabs(ray.oy));
+        near_face = near_face || (!py && ay < 1e-4 && !(fmin(at_lo, at_hi) >= aabb[2] + e && fmax(at_lo, at_hi) <= aabb[3] - e));
+      }
+      {
+        const double at_lo = fma(lo, ray.dz, ray.oz), at_hi = fma(hi, ray.dz, ray.oz);
+        const double e = 1e-6 * (((1.0 + fabs(aabb[4])) + fabs(aabb[5])) + fabs(ray.oz));
+        near_face = near_face || (!pz && az < 1e-4 && !(fmin(at_lo, at_hi) >= aabb[4] + e && fmax(at_lo, at_hi) <= aabb[5] - e));
+      }
+#if !PRT_GRAZE_MARGIN
+      near_face = grazing;  // (A/B: every grazing axis takes the exact test, the round-3 rule)
+#endif
+      const bool exact = near_face && any && robust;  // (a NaN anywhere: not clear of the face, exact test)
+      if (__ballot(exact) != 0ull) {
+        count_paths(ray.paths, 3, exact);
+        if (exact) touched = touched && box_touched(aabb, ray);
+      }
+    }
+  }
+  return touched;
+}
+
 // keep flags of one node (the part of csg_node below that needs no list storage): c(i,j), the
 // parities, the keep rule per operation and the (lazily evaluated) cull box.  Neither list has to
 // be sorted or compacted for this: every quantity is a count of entries of the *other* list that
@@ -817,39 +931,7 @@ __device__ __forceinline__ void csg_keep(int op, const double (&lv)[ML], const d
       lo = fmin(lo, keep_r[j] ? rv[j] : PRT_INF);
       hi = fmax(hi, keep_r[j] ? rv[j] : -PRT_INF);
     }
-    const bool any = hi >= lo;  // false when nothing survived (lo = +inf, hi = -inf)
-    // (a ray that is not well formed -- a short direction may send a leaf into one of upstream's degenerate
-    // branches without being parallel to anything, and what survives then need not lie in the solid; with
-    // w other than 1 / 0 the object-space ray is not the image of the world ray the box was tested
-    // against -- gets the exact test, like a thin chord.  Found by the short-direction and odd-w fuzz families.)
-    const bool robust = any && well_formed(ray) && lo > -PRT_INF && (hi - lo) > 1e-6 * ((1.0 + fabs(lo)) + fabs(hi));
-    count_paths(ray.paths, 2, any);
-    count_paths(ray.paths, 3, any && !robust);
-    if (any && !robust) touched = box_touched(aabb, ray);
-    // The chord argument covers the axes the ray really moves along: with |d| >= 1e-4 a slab crossing
-    // is off by at most ~1e-12 / |d| <= 1e-8 (rounding, and the 1e-12 by which the compiler lets the
-    // upstream box fall short of the solid's bounds), far below the robust margin.  An axis with
-    // |d| <= 1e-8 has no crossing at all: there upstream's test is the bare comparison lo <= o <= hi
-    // (primitives.py:531-565), which a ray running along a face one ulp outside the box fails however
-    // long its chord through the (object-space) solid is -- found by the adversarial fixtures
-    // (tests/scenes.py adv_lens).  In between (1e-8 < |d| < 1e-4) the exact test decides.
-    const double ax = fabs(ray.dx), ay = fabs(ray.dy), az = fabs(ray.dz);
-    if (__ballot(ax < 1e-4 || ay < 1e-4 || az < 1e-4) != 0ull) {
-      const bool px = ax <= 1e-8, py = ay <= 1e-8, pz = az <= 1e-8;
-      const bool outside = (px && !(ray.ox >= aabb[0] && ray.ox <= aabb[1])) ||
-                           (py && !(ray.oy >= aabb[2] && ray.oy <= aabb[3])) ||
-                           (pz && !(ray.oz >= aabb[4] && ray.oz <= aabb[5]));
-      // (no crossing on any axis -- a zero-direction ray, e.g. an absorbed one carried along: upstream's
-      // box test then returns (-inf, +inf) or (+inf, +inf), never a finite entry, and csg.py:126-128
-      // drops the ray wherever it sits; a paraboloid child would still report the finite -c / 1 of its
-      // linear branch, primitives.py:361 -- found by fuzz seed 8061 of a 12 000-seed run)
-      touched = touched && !outside && !(px && py && pz);
-      const bool grazing = (!px && ax < 1e-4) || (!py && ay < 1e-4) || (!pz && az < 1e-4);
-      if (__ballot(grazing && any && robust) != 0ull) {
-        count_paths(ray.paths, 3, grazing && any && robust);
-        if (grazing && any && robust) touched = touched && box_touched(aabb, ray);
-      }
-    }
+    touched = implied_touch(aabb, ray, hi >= lo, lo, hi);  // (hi >= lo: false when nothing survived: lo = +inf, hi = -inf)
   }
 #pragma unroll
   for (int i = 0; i < ML; ++i) keep_l[i] = keep_l[i] && touched;
@@ -998,6 +1080,26 @@ __device__ __forceinline__ bool may_reach(const double* __restrict__ box, const 
   return !never && !(t_in - slack > t_out + slack);
 }
 
+// The same question asked more cheaply and more coarsely, in front of may_reach: does the axis-aligned box of the
+// SEGMENT the ray covers over (0, best_t] meet the component's box at all?  Along axis k the segment runs from o_k to
+// p_k = o_k + best_t d_k (monotonically), a hit at a parameter in (0, best_t] lies between the two, and every such
+// hit is a point of the component's (padded) box: no overlap on some axis means no such hit.  Five instructions per
+// axis and no division against may_reach's twenty with a reciprocal; it only ever answers "no" when may_reach would
+// (the segment's box contains the segment), so asking it first changes no result.  In an optical train it settles
+// most steps: parts behind the ray, and parts beyond its nearest hit so far, differ along the axis alone.
+// (best_t = inf: p_k is +-inf, or NaN for d_k = 0, which v_min / v_max drop: the "segment" is then the half line,
+// resp. the point o_k.)
+__device__ __forceinline__ bool segment_meets(const double* __restrict__ box, const Ray8& r, double best_t) {
+  const double o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
+  bool apart = false;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double p = fma(best_t, d[k], o[k]);
+    apart = apart || fmax(o[k], p) < box[2 * k] || fmin(o[k], p) > box[2 * k + 1];
+  }
+  return !apart;
+}
+
 // ---- chain steps (I_CHAIN) ----------------------------------------------------------------------
 // The component's candidate for the running nearest hit, computed entirely in registers.  The first
 // node's survivors are not compacted: a dropped entry stays in place as +inf (see csg_keep), and the
@@ -1008,15 +1110,67 @@ __device__ __forceinline__ bool may_reach(const double* __restrict__ box, const 
 template <int T0, int T1, int T2, bool FIXED = false>
 __device__ __forceinline__ void chain_candidate(const DevChain* __restrict__ ch, const Ray8& ray,
                                                 double& best_t, int& best_prim) {
-  double lv[2], rv[2];
-  surface_pair(T0, ch->leaf[0], ch->leaf[0] + 6, ray, lv[0], lv[1]);
-  surface_pair(T1, ch->leaf[1], ch->leaf[1] + 6, ray, rv[0], rv[1]);
+  double lv[2], rv[2], r2[2] = {PRT_INF, PRT_INF};
+  const bool shared = PRT_CHAIN_SHARED && ch->shared_rows != 0;  // (uniform)
+  SharedRows rows;
+  if (shared) {
+    rows = shared_rows(ch->leaf[0] + 6, ray);
+    surface_pair_shared(T0, ch->leaf[0], ch->leaf[0] + 6, rows, ray, lv[0], lv[1]);
+    surface_pair_shared(T1, ch->leaf[1], ch->leaf[1] + 6, rows, ray, rv[0], rv[1]);
+  } else {
+    surface_pair(T0, ch->leaf[0], ch->leaf[0] + 6, ray, lv[0], lv[1]);
+    surface_pair(T1, ch->leaf[1], ch->leaf[1] + 6, ray, rv[0], rv[1]);
+  }
+  const int id0 = ch->prim[0], id1 = ch->prim[1];
+  bool have_third = false;
+  // ---- the interval form ------------------------------------------------------------------------------------
+  // Every leaf reports ONE interval [enter, exit] of the ray inside its solid.  array_csg's INTERSECT of two
+  // such lists keeps, for values in general position, exactly the later of the two enters and the earlier of the
+  // two exits when the former comes first, and nothing otherwise -- the intersection of the intervals -- and a
+  // chain of INTERSECT nodes nests that.  Ties between entries of different leaves resolve by the stable merge
+  // (csg.py:13-61: left operand first): of two equal enters the RIGHT one is the depth-2 entry that is kept, of
+  // two equal exits the LEFT one (the parities of csg_keep say the same), which is what `>=` / `<` below select.
+  // An enter that equals an exit (lo == hi: a chord of zero length, which the merge order may or may not keep) is
+  // not decided here: a wave holding such a lane takes the general path below, with the pairs it already has.
+  // The cull boxes go through implied_touch exactly as in csg_keep.
+  if (PRT_CHAIN_INTERVALS && !FIXED && ch->intervals != 0) {  // (uniform)
+    const bool b_in = rv[0] >= lv[0], b_out = rv[1] < lv[1];
+    double lo = b_in ? rv[0] : lv[0], hi = b_out ? rv[1] : lv[1];
+    int id_lo = b_in ? id1 : id0, id_hi = b_out ? id1 : id0;
+    bool undecided = lo == hi && hi < PRT_INF;
+    bool some = lo < hi;
+    some = some && implied_touch(ch->box1, ray, some, lo, hi);
+    if (T2 >= 0) {
+      // (a chord that ends behind the ray leaves nothing positive for the third leaf to cut: see below)
+      if (__ballot((some && hi > 0) || undecided) == 0ull) return;
+      if (shared) surface_pair_shared(T2 < 0 ? 0 : T2, ch->leaf[2], ch->leaf[2] + 6, rows, ray, r2[0], r2[1]);
+      else surface_pair(T2 < 0 ? 0 : T2, ch->leaf[2], ch->leaf[2] + 6, ray, r2[0], r2[1]);
+      have_third = true;
+      const int id2 = ch->prim[2];
+      const bool c_in = r2[0] >= lo, c_out = r2[1] < hi;
+      lo = c_in ? r2[0] : lo; hi = c_out ? r2[1] : hi;
+      id_lo = c_in ? id2 : id_lo; id_hi = c_out ? id2 : id_hi;
+      undecided = undecided || (some && lo == hi && hi < PRT_INF);
+      some = some && lo < hi;
+      some = some && implied_touch(ch->box2, ray, some, lo, hi);
+    }
+    if (__ballot(undecided) == 0ull) {
+      const bool first = some && lo > 0;  // (lo < hi: finite)
+      const bool second = some && hi > 0 && hi < PRT_INF;
+      const double t = first ? lo : (second ? hi : PRT_INF);
+      const int prim = first ? id_lo : (second ? id_hi : -1);
+      if (beats(ray, t, prim, best_t, best_prim)) {
+        best_t = t;
+        best_prim = prim;
+      }
+      return;
+    }
+  }
   bool keep_l[2], keep_r[2], c1[2][2];
   // (FIXED: experiment -- both operations INTERSECT and both boxes implied, known at compile time)
   const int op1 = FIXED ? (int)CSG_INTERSECT : ch->op1, op2 = FIXED ? (int)CSG_INTERSECT : ch->op2;
   const bool implied1 = FIXED ? true : ch->implied1 != 0, implied2 = FIXED ? true : ch->implied2 != 0;
   csg_keep<2, 2>(op1, lv, rv, ch->box1, ray, implied1, keep_l, keep_r, c1);
-  const int id0 = ch->prim[0], id1 = ch->prim[1];
   double t;
   int prim;
   if (T2 < 0) {
@@ -1036,8 +1190,10 @@ __device__ __forceinline__ void chain_candidate(const DevChain* __restrict__ ch,
     }
     positive = positive || (behind & 1) || !well_formed(ray);
     if (op2 != CSG_UNION && __ballot(positive) == 0ull) return;
-    double r2[2];
-    surface_pair(T2 < 0 ? 0 : T2, ch->leaf[2], ch->leaf[2] + 6, ray, r2[0], r2[1]);
+    if (!have_third) {  // (the interval form may have evaluated it already)
+      if (shared) surface_pair_shared(T2 < 0 ? 0 : T2, ch->leaf[2], ch->leaf[2] + 6, rows, ray, r2[0], r2[1]);
+      else surface_pair(T2 < 0 ? 0 : T2, ch->leaf[2], ch->leaf[2] + 6, ray, r2[0], r2[1]);
+    }
     bool keep4[4], keep2[2], c2[4][2];
     csg_keep<4, 2>(op2, l4, r2, ch->box2, ray, implied2, keep4, keep2, c2);
     const int id2 = ch->prim[2];
@@ -1237,6 +1393,15 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
         continue;
       }
       bool wanted = false;
+#if PRT_SEGMENT_CULL
+      // (the coarse test first: a wave none of whose segments comes near the box is done with five instructions
+      // per axis; only a wave that does come near pays for the exact one)
+#pragma unroll
+      for (int k = 0; k < R; ++k)
+        wanted = wanted || !well_formed(ray[k]) || segment_meets(step.data, ray[k], best_t[k]);
+      if (__ballot(wanted) == 0ull) { pc += step.a0; continue; }
+      wanted = false;
+#endif
 #pragma unroll
       for (int k = 0; k < R; ++k)
         wanted = wanted || !well_formed(ray[k]) || may_reach(step.data, ray[k], best_t[k]);

@@ -300,7 +300,8 @@ def test_sharded_group_stats_over_a_one_rank_rccl_communicator():
     try:
         want = _stats_of(frame, detector, 3000)
         got = _stats_of(frame, detector, 3000, comm=comm, n_groups=10)
-        assert np.array_equal(got, want, equal_nan=True)
+        # (the reduction adds with atomics: two runs agree to rounding, not bit for bit)
+        assert np.array_equal(got[:, 0], want[:, 0]) and np.allclose(got, want, rtol=0, atol=1e-12, equal_nan=True)
         with pytest.raises(ValueError):
             frame.group_stats(surface=detector, rays_per_source=3000, comm=comm)  # how many groups is the caller's to say
     finally:

@@ -65,7 +65,7 @@ def test_trace_matches_reference(name, flags):
 
 
 @pytest.mark.parametrize("name", SCENE_FIXTURES)
-@pytest.mark.parametrize("knob", ["no_chain", "no_cull", "cull_min", "no_implied", "list_order_groups"])
+@pytest.mark.parametrize("knob", ["no_chain", "no_cull", "cull_min", "no_implied", "list_order_groups", "no_intervals"])
 def test_trace_matches_reference_on_every_program_form(name, knob):
     """The same goldens with the scene compiled to the other program forms (prt_scene_options): the step
     interpreter instead of chain steps, no component cull steps, cull steps from two components on, every
