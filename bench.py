@@ -673,6 +673,9 @@ def main():
             "trace_flags": args.flags,
             "scene_options": scene_options,
             "spinup_steps_untimed": spinup_steps,
+            # repeats the library made on its own since the scene was created (a missed dense hint, a per-tile record
+            # that did not hold, the look-back fallback): each is a trace run twice
+            "telemetry": scene.telemetry(),
             "parallelism": f"ray data-parallel x{world} (contiguous id shards), no collective in the timed region",
         },
         "roofline": {

@@ -1642,6 +1642,8 @@ static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
     // ray count on the device and checks the assumption tile by tile)
     int assume = 0;
     if (t->use_hints && gg < (int)s->hint_mode.size()) assume = s->hint_mode[gg];
+    // (a generation whose dense hint was refuted lately keeps compacting for a while: see hint_rest)
+    if (assume && gg < (int)s->hint_rest.size() && s->hint_rest[gg] > 0) assume = 0;
     s->dense_launches += assume ? 1 : 0;
     // a generation that compacts (no dense hint) on the per-tile record its last run left in this workspace
     if (assume == 0 && t->use_tile_records && gg < kTileHintGenerations && t->tile_record[gg]) {
@@ -1707,6 +1709,7 @@ static int fused_start(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
   // Hints from the previous trace of this scene with this many rays (PRT_TRACE_NO_HINTS turns them off).
   // After a miss the hints rest for 2, 4, 8 ... 64 traces (a caller that alternates between ray sets of
   // different shapes must not pay a repeat every time).
+  for (int& rest : s->hint_rest) rest -= rest > 0 ? 1 : 0;  // (counted in traces of this scene)
   bool allow_hints = t->allow_hints;
   if (allow_hints && s->hint_holdoff > 0) {
     s->hint_holdoff -= 1;
@@ -1719,7 +1722,10 @@ static int fused_start(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
   // The per-tile records of this ticket's last trace (TileHint) serve the generations that compact: offered with
   // the other hints, to a trace that publishes from its kernels (the slots the records lean on are then never
   // cleared between traces), and rested after a miss like them.
-  bool allow_tiles = t->allow_tile_hints && t->use_hints && t->publish_in_kernel;
+  // ... and only to a trace of the very buffer the records were taken from: another ray set loses its rays in other
+  // tiles, every offer would be a miss and a repeat (a caller that refills one buffer with new rays is still offered
+  // them -- and every tile checks)
+  bool allow_tiles = t->allow_tile_hints && t->use_hints && t->publish_in_kernel && t->record_rays == t->rays;
   if (allow_tiles && s->tile_hint_holdoff > 0) {
     s->tile_hint_holdoff -= 1;
     allow_tiles = false;
@@ -1785,6 +1791,26 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
   s->last_generations = (int)t->stats[0];
   s->hint_n = t->n;
   s->hint_keep_absorbed = keep_absorbed;
+  if (!s->missed_mode.empty()) {
+    // This trace is the repeat of an attempt whose dense hints did not hold: the generations that were offered a
+    // hint and turned out otherwise are the ones whose rays are lost differently from trace to trace (a ray set
+    // that loses a near-axial ray in one generation where the previous one lost none).  Such a generation is not
+    // offered its dense hint for the next 32, 64 ... 4096 traces (it compacts, by look-back or on its per-tile
+    // record); the hints of the other generations were not refuted and stay in use -- a loop that alternates
+    // between such ray sets pays one repeat per rest, not one every other trace.
+    bool found = false;
+    if (s->hint_rest.size() < s->missed_mode.size()) { s->hint_rest.resize(s->missed_mode.size(), 0); s->hint_rest_span.resize(s->missed_mode.size(), 0); }
+    for (size_t g = 0; g < s->missed_mode.size(); ++g) {
+      const char now = g < (size_t)t->n_seen ? t->seen_mode[g] : 0;
+      if (s->missed_mode[g] != 0 && s->missed_mode[g] != now) {
+        s->hint_rest_span[g] = s->hint_rest_span[g] ? std::min(s->hint_rest_span[g] * 2, 4096) : 32;
+        s->hint_rest[g] = s->hint_rest_span[g];
+        found = true;
+      }
+    }
+    if (found) { s->hint_holdoff = 0; s->hint_misses_in_a_row = 0; }  // (the culprit rests by itself)
+    s->missed_mode.clear();
+  }
   s->hint_mode.assign(t->seen_mode, t->seen_mode + t->n_seen);
   if (t->use_hints) s->hint_misses_in_a_row = 0;
   if (t->used_tile_hints) s->tile_hint_misses_in_a_row = 0;
@@ -1793,6 +1819,7 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
   // are checked against -- cleared behind it: its records are not offered)
   for (int g = 0; g < kTileHintGenerations; ++g)
     t->tile_record[g] = t->publish_in_kernel && g < t->n_seen && t->seen_mode[g] == 0;
+  t->record_rays = t->rays;
   // the control words are as a next trace of this shape needs them (see the launch loop)
   t->ready_workspace = t->w;
   t->ready_n = t->n;
@@ -1878,6 +1905,7 @@ extern "C" int64_t prt_trace_end(prt_scene* s, int device, int ticket, int64_t* 
         // a generation assumed dense was not (the rays or the scene changed since the hints were taken):
         // nothing of this attempt is kept; run again without assumptions, which also renews the hints
         s->speculation_misses += 1;
+        s->missed_mode = s->hint_mode;  // (which generations were offered what: compared with the repeat's outcome)
         s->hint_misses_in_a_row = std::min(s->hint_misses_in_a_row + 1, 6);
         s->hint_holdoff = 1 << s->hint_misses_in_a_row;
         s->hint_n = -1;

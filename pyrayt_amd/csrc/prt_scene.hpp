@@ -76,6 +76,7 @@ struct TraceTicket {
   // generations whose per-tile record (TileHint, prt_kernels.hip) in this ticket's workspace is that of the
   // ticket's last successful trace -- with ready_workspace / ready_n they say when `assume == 3` may be offered
   bool tile_record[16] = {false};
+  const double* record_rays = nullptr;  // the ray buffer of the trace those records are from
   bool allow_tile_hints = true, use_tile_records = false, used_tile_hints = false;
   unsigned long long user = 0;  // identity of this ticket in the workspace registry (0: not drawn yet)
 };
@@ -128,6 +129,8 @@ struct prt_scene {
   // implied cull box that had survivors, ... of which took upstream's exact box test
   long long path_counts[4] = {0, 0, 0, 0};
   int hint_holdoff = 0;         // traces still to run without hints after a miss (doubles with every miss in a row)
+  std::vector<char> missed_mode;            // the hint modes of an attempt that missed, until its repeat has been looked at
+  std::vector<int> hint_rest, hint_rest_span;  // per generation: traces for which its dense hint is not offered / the span of its last rest
   int hint_misses_in_a_row = 0;
 };
 

@@ -7,6 +7,7 @@ functions in this module raise -- there is deliberately no CPU fallback.
 import ctypes
 import os
 import warnings
+import weakref
 
 import numpy as np
 
@@ -444,14 +445,22 @@ class DeviceScene:
         # (lifetime rule for callers that pass a stream: trace_end returns when the COUNTS are on the host, the
         # rows are only ordered on that stream -- before `rays`, `out` or anything else the trace touches goes
         # back to the allocator of another stream, make that stream wait: other.wait_stream(stream))
-        # the same tensors as this ticket's previous trace (a loop re-tracing into its own blocks): the call's
-        # arguments are as they were (checking and converting them again costs as much as the call itself)
-        cached = self._begin_cache[ticket] if hasattr(self, "_begin_cache") else None
-        key = (rays, out, generation_limit, ray_offset, flags, stream)
-        if cached is not None and cached[0][0] is rays and cached[0][1] is out and cached[0][2:5] == key[2:5] \
-                and cached[0][5] is stream and cached[2] == (rays.data_ptr(), out.data_ptr()) \
-                and cached[3] is self._ticket_work[ticket]:  # (a larger trace since then replaced the workspace)
-            args = cached[1]
+        # Tensors this ticket has traced before (a loop re-tracing into its own blocks, or rotating through a few
+        # ray sets): the call's arguments are as they were -- checking and converting them again costs as much as
+        # the call itself (about 15 us, which is most of a 125k-ray step).  A handful of entries per ticket, keyed
+        # by the tensor objects and validated by their addresses (an id can be reused, an address in use cannot).
+        caches = self._begin_cache if hasattr(self, "_begin_cache") else None
+        if caches is None or not isinstance(caches[ticket], dict):
+            if caches is None:
+                caches = self._begin_cache = [None] * TRACE_TICKETS
+            caches[ticket] = {}
+        entries = caches[ticket]
+        key = (id(rays), id(out), generation_limit, ray_offset, flags, id(stream))
+        cached = entries.get(key)
+        if cached is not None and cached[0]() is rays and cached[1]() is out and cached[2] is stream \
+                and cached[4] == (rays.data_ptr(), out.data_ptr()) \
+                and cached[5] is self._ticket_work[ticket]:  # (a larger trace since then replaced the workspace)
+            args = cached[3]
         else:
             torch = _torch()
             if self._host_surfaces:
@@ -465,9 +474,10 @@ class DeviceScene:
             args = (self.handle, dev.index or 0, int(ticket), rays.data_ptr(), n, rays.stride(0), limit,
                     float(ray_offset), out.data_ptr(), out.shape[1], work.data_ptr(), int(flags) | self.trace_flags,
                     None if stream is None else ctypes.c_void_p(stream.cuda_stream))
-            if not hasattr(self, "_begin_cache"):
-                self._begin_cache = [None] * TRACE_TICKETS
-            self._begin_cache[ticket] = (key, args, (rays.data_ptr(), out.data_ptr()), work)
+            if len(entries) >= 16:  # (a loop over ever new tensors)
+                entries.clear()
+            # (weak references: the cache must not keep a caller's ray sets and record blocks alive)
+            entries[key] = (weakref.ref(rays), weakref.ref(out), stream, args, (rays.data_ptr(), out.data_ptr()), work)
         if args[12] is None:  # the current stream, whatever it is now
             torch = _torch()
             args = args[:12] + (_stream_ptr(torch, rays.device),)

@@ -40,6 +40,13 @@ python3 tools/slow_paths.py 2>&1 | grep -v amdgpu.ids > $out/slow_paths.txt
   echo; echo "# tools/cull_scaling.py --shuffle (lenses listed in random order, beams from both ends)"; python3 tools/cull_scaling.py --shuffle --counts 8 32 2>&1 | grep -v amdgpu.ids; } > $out/cull_scaling.txt
 python3 tools/hit_ab.py 2>&1 | grep -v amdgpu.ids > $out/hit_variants.txt
 { python3 tools/aux_bench.py; python3 tools/frame_bench.py; python3 tools/gather_bench.py; } 2>&1 | grep -v "RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl" | grep -v amdgpu.ids > $out/aux_kernels.txt
+# round 4: per-generation instruction counts / launch times, and SQ + PMC counters of the other BASELINE configs
+bash tools/gen_counters.sh config2 1000000 > /dev/null 2>&1
+bash tools/gen_counters.sh config3 4000000 > /dev/null 2>&1
+cp gpurun_out/gen_counters/config2_per_generation.txt $out/per_generation_config2.txt
+cp gpurun_out/gen_counters/config3_per_generation.txt $out/per_generation_config3.txt
+bash tools/counters_cfg.sh > $out/counters_cfg.log 2>&1
+cp gpurun_out/counters/sq_counters_config*.txt gpurun_out/counters/traffic_config*.json gpurun_out/counters/gen_times_config*.txt $out/
 # keep the summaries, drop the bulky per-dispatch traces
 rm -f $out/*_kernel_trace.csv $out/*_agent_info.csv $out/*domain_stats.csv
 ls -la $out | head -60
