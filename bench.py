@@ -532,6 +532,23 @@ def main():
     else:
         total_rows_per_step = float(rows_per_step)
 
+    def sink_stats(rows_local, counts_local, group, comm):
+        """ms of one DeviceFrame.group_stats call on the last step's rows (best of the last two of three)."""
+        from pyrayt_amd.frame import DeviceFrame
+
+        frame = DeviceFrame(rows_local, counts_local)
+        detector = float(snap.prims["surface_id"][-1])
+        per_group = max(1, n_job // 8)
+        times = []
+        for _ in range(3):
+            torch.cuda.synchronize(device)
+            if group is not None:
+                dist.barrier()
+            s0 = time.perf_counter()
+            frame.group_stats(surface=detector, rays_per_source=per_group, n_groups=8, group=group, comm=comm)
+            times.append(time.perf_counter() - s0)
+        return min(times[1:]) * 1e3
+
     # frame re-assembly (not in the timed region): the library's RCCL all-gathers + placement kernel
     # when the group is RCCL-backed, torch.distributed + the placement kernel otherwise
     gather = None
@@ -555,10 +572,26 @@ def main():
                       "GB_into_each_gpu": total_rows_per_step * 120 * (world - 1) / world / 1e9,
                       "transport": "RCCL inside libprt_hip (prt_allgather_rows)" if comm is not None
                                    else f"torch.distributed {backend} + prt_place_rows"}
+            # ... and what most design loops want instead of the frame: the detector's spot / focus statistics per
+            # source group, from the rows every rank kept (prt_frame_stats_sharded: per-rank sums + two small
+            # all-reduces; nothing of the frame moves)
+            stats_ms = sink_stats(rows, counts, dist.group.WORLD, comm)
+            agg = torch.tensor([stats_ms], dtype=torch.float64, device=comm_device)
+            dist.all_reduce(agg, op=dist.ReduceOp.MAX)
+            gather["stats_ms"] = float(agg[0])
+            gather["stats_transport"] = ("ncclAllReduce inside libprt_hip (prt_frame_stats_sharded)" if comm is not None
+                                         else f"torch.distributed {backend} between prt_frame_reduce passes")
             if comm is not None:
                 comm.close()
         except Exception as exc:  # noqa: BLE001
             gather = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    result_sink = None
+    if not distributed:
+        try:
+            result_sink = {"stats_ms": sink_stats(rows, counts, None, None), "groups": 8,
+                           "what": "DeviceFrame.group_stats of the detector's rows, 8 source groups (prt_frame_stats), incl. the D2H of the 8 x 8 result"}
+        except Exception as exc:  # noqa: BLE001
+            result_sink = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     # PCIe-inclusive end-to-end trace() on rank 0 (H2D rays, trace, D2H rows, DataFrame)
     end_to_end = None
@@ -760,6 +793,8 @@ def main():
         # its one-off costs (table upload, kernel load) are in end_to_end_trace.first_call_ms
         line["value_first_trace"] = side_resized["rows_per_s_this_gpu"] * world
         line["changing_ray_count"] = side_resized
+    if result_sink:
+        line["result_sink"] = result_sink
     if gather:
         line["gather"] = gather
         if "ms" in gather:
