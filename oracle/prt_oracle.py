@@ -31,14 +31,16 @@ Scene format (dict of arrays; P primitives, N nodes, C components, M materials):
     prim_surface_id (P) int64, prim_params (P,6), prim_minv (P,16) row-major
     node_op (N) int32 [0 leaf, 1 union, 2 intersect, 3 difference], node_left, node_right,
     node_prim (N) int32, node_aabb (N,6) [xmin,xmax,ymin,ymax,zmin,zmax]
-    roots (C) int32, mat_kind (M) int32 [0 none 1 absorber 2 mirror 3 const 4 sellmeier],
-    mat_coef (M,6)
+    roots (C) int32, mat_kind (M) int32 [0 none 1 absorber 2 mirror 3 const 4 sellmeier
+    5 a user's Glass subclass: index_at is host code  6 a user's TracableMaterial: trace() is host code],
+    mat_coef (M,6); for kinds 5 / 6 also "user_materials" {material slot: the material object} and, for
+    kind 6, "user_surfaces" {primitive index: the surface object handed to its trace()}
 """
 import numpy as np
 
 SPHERE, CYLINDER, PLANE, CUBE, PARABOLOID = range(5)
 LEAF, UNION, INTERSECT, DIFFERENCE = range(4)
-MAT_NONE, MAT_ABSORBER, MAT_MIRROR, MAT_CONST, MAT_SELLMEIER = range(5)
+MAT_NONE, MAT_ABSORBER, MAT_MIRROR, MAT_CONST, MAT_SELLMEIER, MAT_TABLE, MAT_HOST = range(7)
 
 INF = np.inf
 
@@ -372,7 +374,19 @@ def material_trace(scene, p, sub):
     if kind == MAT_MIRROR:
         sub[4:8] = reflect(sub[4:8], normals)
         return sub
-    n_glass = material_index(kind, scene["mat_coef"][m], sub[10])
+    if kind == MAT_HOST:
+        # a user's trace() (materials.py:26-37): called as _pyrayt.py:408 calls it, on a RaySet view of the copy
+        material = scene["user_materials"][m]
+        surface = scene.get("user_surfaces", {}).get(p)
+        ray_set_type = scene.get("ray_set_type")
+        handed = sub.view(ray_set_type) if ray_set_type is not None else sub
+        sub[...] = np.asarray(material.trace(surface, handed), dtype=float)
+        return sub
+    if kind == MAT_TABLE:
+        # a user's Glass subclass: Glass.trace (materials.py:70-75) with ITS index_at on the wavelength row
+        n_glass = np.broadcast_to(np.asarray(scene["user_materials"][m].index_at(np.array(sub[10])), dtype=float), sub[10].shape)
+    else:
+        n_glass = material_index(kind, scene["mat_coef"][m], sub[10])
     with np.errstate(invalid="ignore", divide="ignore"):
         sub[4:8], sub[11] = refract(sub[4:8], normals, sub[11], n_glass)
     return sub

@@ -42,6 +42,33 @@ def flat_scene(snapshot):
     }
 
 
+def flat_scene_with_user_materials(snapshot, ray_set_type=None):
+    """flat_scene plus what the oracle needs to run a user's index_at / trace() itself: the material objects by
+    slot, the surfaces whose material.trace() is user code by primitive index -- for those a stand-in whose
+    get_world_normals is the oracle's own (the user's trace() must not need the GPU to be checked)."""
+    from oracle import prt_oracle
+
+    flat = flat_scene(snapshot)
+    flat["user_materials"] = {slot: material for slot, material in snapshot.table_materials}
+    flat["user_surfaces"] = {}
+    flat["ray_set_type"] = ray_set_type
+
+    class OracleSurface:
+        def __init__(self, prim, surface):
+            self._prim, self.material, self._surface = prim, surface.material, surface
+
+        def get_id(self):
+            return self._surface.get_id()
+
+        def get_world_normals(self, positions):
+            return prt_oracle.world_normals(flat, self._prim, np.asarray(positions, dtype=float).reshape(4, -1))
+
+    for prim, surface in snapshot.host_surfaces:
+        flat["user_materials"][int(snapshot.prims["material"][prim])] = surface.material
+        flat["user_surfaces"][prim] = OracleSurface(prim, surface)
+    return flat
+
+
 class FixtureSnapshot:
     """Adapter: a fixture's plain-array scene -> the structured arrays DeviceScene uploads."""
 

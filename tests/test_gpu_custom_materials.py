@@ -277,3 +277,22 @@ def test_c_abi_rejects_a_host_surface_in_the_fused_trace():
                            work.data_ptr(), flags, None)
         assert rc == engine.ERR_UNTRACABLE and b"PRT_MAT_HOST" in lib.prt_last_error()
     ds.close()
+
+
+@pytest.mark.parametrize("n,wavelengths", [(200_000, 16), (50_001, 1), (30_000, 3000)])
+def test_user_glass_at_size_against_the_oracle(n, wavelengths):
+    """Beyond the fixture's size: a Cauchy glass over many rays and wavelengths (a spectrum of 3000: the table is
+    searched, not scanned), HIP against the numpy oracle running the same index_at (ids exact, 1e-6 elsewhere)."""
+    from oracle import prt_oracle as orc
+
+    CountedObject.reset_ids()
+    lam = np.linspace(0.4, 0.8, wavelengths) if wavelengths > 1 else np.array([0.55])
+    parts, rays = scenes.custom_cauchy(scenes.product_api(), n, seed=99, wavelengths=lam)
+    snap = SceneSnapshot(parts)
+    ds = engine.DeviceScene(snap)
+    rows, counts = ds.trace(torch.from_numpy(rays).cuda(), 10)
+    want, want_counts = orc.trace(helpers.flat_scene_with_user_materials(snap, ray_set_type=RaySet), rays, 10)
+    assert counts == want_counts
+    helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"cauchy {n} rays, {wavelengths} wavelengths")
+    assert len(ds._tables[0]) == wavelengths
+    ds.close()

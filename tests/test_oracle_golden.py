@@ -38,6 +38,28 @@ def test_scene_trace_matches_reference(name):
     assert sum(counts) == fx["frame"].shape[0]
 
 
+@pytest.mark.parametrize("name,args", [("custom_cauchy", (2048,)), ("custom_retro", (10,))])
+def test_scene_with_user_defined_materials_matches_reference(name, args):
+    """The oracle runs a user's Glass.index_at / TracableMaterial.trace itself (materials.py:26-37, 88-99; called as
+    _pyrayt.py:408 calls them) and reproduces what the genuine reference did with the same user classes."""
+    import scenes
+    from pyrayt_amd import RaySet
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    fx = helpers.load(f"scene_{name}.npz")
+    CountedObject.reset_ids()
+    parts, rays = scenes.SCENES[name](scenes.product_api(), *args)
+    assert np.array_equal(rays, fx["rays0"])
+    scene = helpers.flat_scene_with_user_materials(SceneSnapshot(parts), ray_set_type=RaySet)
+    log = {}
+    frame, counts = orc.trace(scene, rays, int(fx["generation_limit"]), log=log)
+    helpers.assert_frames_match(frame, fx["frame"], what=name)
+    assert np.array_equal(frame, fx["frame"], equal_nan=True)  # bit for bit, like every other scene fixture
+    for g in range(int(fx["n_generations"])):
+        assert np.array_equal(log[f"surf_{g}"], fx[f"surf_{g}"]), f"{name}: surfaces gen {g}"
+
+
 def test_oracle_is_bit_identical_on_config2():
     """Same numpy primitives in the same order: on this machine the oracle reproduces the
     reference's float64 results exactly, not just within tolerance."""
