@@ -138,6 +138,9 @@ struct Ray8 {
 #define PRT_GRAZE_MARGIN 0     // implied cull boxes: a grazing axis takes the exact test only near a face of the box (A/B: 1;
                                // measured: config 3 -1.5 %, config 2 +0.8 % with 20 B of scratch per lane: not adopted)
 #endif
+#ifndef PRT_STEP_BY_POINTER
+#define PRT_STEP_BY_POINTER 1
+#endif
 #ifndef PRT_SEGMENT_CULL
 #define PRT_SEGMENT_CULL 1     // component cull steps: the segment-box test in front of may_reach (A/B: 0)
 #endif
@@ -1372,7 +1375,11 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
         continue;
       }
     }
+#if PRT_STEP_BY_POINTER
+    const DevInstr& step = code[pc];  // fields are fetched as they are used (a whole record is 48 SGPRs at once)
+#else
     const DevInstr step = code[pc];  // the whole record, one batch of scalar loads
+#endif
     if (CULL && RENDER && step.kind == I_BOX) {  // render programs: a component whose box the line of sight misses
       bool wanted = false;
 #pragma unroll
