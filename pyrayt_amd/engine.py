@@ -734,7 +734,11 @@ class DeviceScene:
                 if subset.shape[1] == 0:  # (upstream: `if np.any(surface_mask)`)
                     continue
                 handed = to_host(subset).copy().view(RaySet)
-                answer = np.asarray(surface.material.trace(surface, handed), dtype=float)
+                answer = surface.material.trace(surface, handed)
+                if answer is None:
+                    raise TypeError(f"{type(surface.material).__name__}.trace() returned None: it has to return the ray set "
+                                    "it was handed (pyrayt/materials.py:26-37)")
+                answer = np.asarray(answer, dtype=float)
                 if answer.shape != handed.shape:
                     # (upstream assigns the answer to next_ray_set[..., surface_mask]: numpy broadcasting rules)
                     answer = np.broadcast_to(answer, handed.shape)
