@@ -34,7 +34,7 @@ extern "C" {
 
 #define PRT_VERSION 200 /* 0.2.0: prt_interact takes the caller-shaded state, PRT_MAT_TABLE / PRT_MAT_HOST,
                            prt_scene_set_index_tables, prt_gather_hits / prt_scatter_shaded, prt_unique_values,
-                           prt_frame_stats_sharded / prt_frame_pivots / prt_frame_finish.  A caller built against another version must not load this library:
+                           prt_frame_stats_sharded / prt_frame_pivots / prt_frame_finish, prt_trace_telemetry fills 12 slots.  A caller built against another version must not load this library:
                            prt_version() is there to be compared with this constant (pyrayt_amd.engine.library does). */
 
 /* ---- ray buffer layout: pyrayt/_pyrayt.py:13-144 (RaySet) -------------------------------
@@ -327,6 +327,8 @@ int prt_generate_rays(int device, const prt_source* source, int64_t n_total, int
                                      trace, which is most of what a 125k-ray trace costs the host */
 #define PRT_TRACE_NO_TILE_RECORDS 512 /* do not run compacting generations on the per-tile records of the ticket's
                                      previous trace (they then run their look-back, as in a first trace); A/B, tests */
+#define PRT_TRACE_NO_SPARSE_KEEP 1024 /* do not launch sparse-loss generations dense with their absorbed rays kept
+                                     (see prt_trace_telemetry); A/B, tests */
 #define PRT_TRACE_COUNT_PATHS 128 /* count, in prt_trace_telemetry, the rays that are not well formed and
                                      the CSG node evaluations that took an exact path (see there) */
 int64_t prt_trace_workspace_bytes(int64_t n);
@@ -465,17 +467,26 @@ int prt_frame_finish(int device, const double* sums, const double* pivots, int n
 #define PRT_VARIANT_KLANES 3      /* ... with the surface-parallel nearest-hit kernel (K lanes per ray,
                                      shuffle min-reduce; prt_scene_options.hit_lanes = 4 | 8 | 16) */
 int prt_trace_stats(const prt_scene* scene, double* out8);
-/* counters of this scene since it was created: out10 = { traces re-run on the three-kernel path after a
+/* counters of this scene since it was created: out12 = { traces re-run on the three-kernel path after a
  * look-back gave up, traces repeated because a dense-mode hint did not hold, generation launches made in
  * dense mode, traces repeated with all 13 state rows (see below; at most one per scene),
  * and from the traces run with PRT_TRACE_COUNT_PATHS: how many such traces, ray-generations whose ray was
  * not well formed (see "shortcuts" in DESIGN.md: such a ray takes none), CSG node evaluations with
  * survivors under an implied cull box, ... of which evaluated upstream's box test exactly;
- * generation launches made on per-tile records, traces repeated because a record did not hold }.  Dense mode: a generation in which the previous trace of the same scene (whatever its ray count)
+ * generation launches made on per-tile records, traces repeated because a record did not hold,
+ * dense-mode launches that kept their absorbed rays (sparse loss, below), 0 }.
+ * Dense mode: a generation in which the previous trace of the same scene (whatever its ray count)
  * recorded every ray and carried all or none of them on is launched on the assumption that it will
  * again -- every tile then knows its output position without the look-back; each tile checks the
  * assumption on its own counts and a miss repeats the trace without assumptions (results are exact
  * either way; PRT_TRACE_NO_HINTS turns the hints off for a call).
+ * Sparse loss: a generation that recorded every ray and carried on all but a few absorbed ones (at most 1 in 64)
+ * is launched dense as well, with PRT_TRACE_KEEP_ABSORBED in force for that launch: the absorbed rays go on,
+ * direction zeroed, the way upstream carries them (_pyrayt.py:415-428), and the next generation -- which
+ * compacts -- finds them dead, records nothing for them and drops them.  The rows are the same; what is saved is
+ * the look-back of a generation whose few odd rays make their tiles the slowest ones, so that every tile waited
+ * for a straggler (PRT_TRACE_NO_SPARSE_KEEP turns it off for a call; a trace of the same ray buffer as the
+ * ticket's last prefers the per-tile record).
  * Per-tile records: a generation that does lose rays leaves, for every tile, where the tile's rows and carried
  * rays went and how many it had, in the workspace.  The next trace of the same ticket with the same workspace
  * and ray count runs that generation on the record instead of a look-back; every tile checks its own counts
@@ -490,7 +501,7 @@ int prt_trace_stats(const prt_scene* scene, double* out8);
  * checks the caller's rows, every generation checks the rays it hands on; the first ray that differs
  * makes the library repeat the trace with all rows and keep doing so for this scene
  * (PRT_TRACE_FULL_ROWS forces that form for a call). */
-int prt_trace_telemetry(const prt_scene* scene, int64_t* out10);
+int prt_trace_telemetry(const prt_scene* scene, int64_t* out12);
 
 /* ---- renderers (second consumer of the intersect path) ----------
  * tinygfx/g3d/renderers.py: an OrthographicCamera grid (world_objects.py:499-537) is pushed

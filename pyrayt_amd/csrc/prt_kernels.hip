@@ -641,9 +641,12 @@ __device__ __forceinline__ bool lookback(unsigned long long* state, int tile, un
 }
 
 #ifdef PRT_TIMING
-// experiment build: s_memtime stamps of every wave of generation 0 at 8 points of k_generation
+// experiment build: s_memtime stamps of every wave of one generation (PRT_TIMING_GEN, default 0) at 8 points of k_generation
 __device__ long long g_stamps[16384 * 4 * 8];
-#define STAMP(k) do { if (g == 0 && (threadIdx.x & 63) == 0 && blockIdx.x < 16384) g_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#ifndef PRT_TIMING_GEN
+#define PRT_TIMING_GEN 0
+#endif
+#define STAMP(k) do { if (g == PRT_TIMING_GEN && (threadIdx.x & 63) == 0 && blockIdx.x < 16384) g_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define STAMP(k) do {} while (0)
 #endif
@@ -1644,10 +1647,35 @@ static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
     if (t->use_hints && gg < (int)s->hint_mode.size()) assume = s->hint_mode[gg];
     // (a generation whose dense hint was refuted lately keeps compacting for a while: see hint_rest)
     if (assume && gg < (int)s->hint_rest.size() && s->hint_rest[gg] > 0) assume = 0;
+    // a generation that compacts on the per-tile record its last run left in this workspace (exact, and it leaves
+    // nothing behind: preferred to mode 4 below when the trace is of the same ray buffer again)
+    const bool on_record = (assume == 0 || assume == 4) && t->use_tile_records && !t->records_off &&
+                           gg < kTileHintGenerations && t->tile_record[gg];
+    const bool kept_then = t->launch_mode[gg] == 4;  // in the ticket's last trace (meaningful where it left records)
+    // Mode 4 (sparse loss): last time every ray of this generation was recorded and all but a few of them -- absorbed
+    // ones -- were carried on.  Compacting those few away costs every tile a look-back, and the tiles that hold such a
+    // ray are as a rule the slow ones (a ray that misses the part it was expected to hit visits the parts behind it):
+    // with 1 tile in 60 slow and 1280 in flight, every tile waits for a straggler (profiles/r4/lookback_stragglers.txt).
+    // Such a generation runs dense instead, keeping its absorbed rays the way upstream does (PRT_TRACE_KEEP_ABSORBED
+    // for this launch only: _pyrayt.py:415-428 carries them, direction zeroed, and drops them a generation later);
+    // the next generation finds them dead on arrival, records nothing for them and drops them when it compacts.
+    int keep = keep_absorbed;
+    if (assume == 4) {
+      // (a trace of the ticket's last ray buffer without a record of this generation -- it ran dense last time --
+      // compacts once to leave one: from then on such traces run on records, which leave the next generation alone)
+      const bool wants_record = t->use_tile_records && gg < kTileHintGenerations;
+      if (on_record || wants_record || (t->flags & PRT_TRACE_NO_SPARSE_KEEP)) assume = 0;
+      else { assume = 1; keep = 1; }
+    }
+    t->launch_mode[gg] = (char)(keep && !keep_absorbed ? 4 : assume);
+    // (a generation that keeps its absorbed rays this time and did not last time, or the other way round, hands the
+    // generations behind it other rays than their records were taken on)
+    if ((t->launch_mode[gg] == 4) != kept_then) t->records_off = true;
     s->dense_launches += assume ? 1 : 0;
-    // a generation that compacts (no dense hint) on the per-tile record its last run left in this workspace
-    if (assume == 0 && t->use_tile_records && gg < kTileHintGenerations && t->tile_record[gg]) {
+    s->sparse_keep_launches += keep && !keep_absorbed ? 1 : 0;
+    if (on_record && assume == 0) {
       assume = 3;
+      t->launch_mode[gg] = 3;
       t->used_tile_hints = true;
       s->tile_hint_launches += 1;
     }
@@ -1655,7 +1683,7 @@ static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
     // launch works on the one the launch before it left clean and cleans the other (k_generation)
     hipLaunchKernelGGL(kernel, dim3(blocks_for(n)), dim3(PRT_BLOCK), lds, st, sd, src, src_ld, buf[gg & 1], n,
                        t->rows_out, t->rows_cap, ctrl, gen, gg, tiles[t->flip], tiles[t->flip ^ 1], (double)(gg + 1),
-                       t->limit, t->ray_offset, keep_absorbed,
+                       t->limit, t->ray_offset, keep,
                        t->publish_in_kernel ? t->mirror_dev : (HostMirror*)nullptr, epoch, b,
                        b + 1 == t->batch ? 1 : 0, assume);
     t->flip ^= 1;
@@ -1731,6 +1759,7 @@ static int fused_start(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
     allow_tiles = false;
   }
   t->use_tile_records = allow_tiles;
+  t->records_off = false;
   t->used_tile_hints = false;
   t->g = 0;
   t->n_seen = 0;
@@ -1768,8 +1797,19 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
       rows_per_generation[t->g + b] = host_gen[b].n_live;
       t->total_rows += host_gen[b].n_live;
       const bool all_live = host_gen[b].n_live == host_gen[b].n_in;
-      t->seen_mode[t->n_seen++] = all_live && host_gen[b].n_carry == host_gen[b].n_in ? 1
-                                  : all_live && host_gen[b].n_carry == 0 ? 2 : 0;
+      char mode = all_live && host_gen[b].n_carry == host_gen[b].n_in ? 1 : all_live && host_gen[b].n_carry == 0 ? 2 : 0;
+      const int at = t->n_seen;
+      if (t->launch_mode[at] == 4) {
+        mode = mode == 1 ? 4 : 0;  // (kept its absorbed rays: how many there were cannot be told from the counts)
+      } else if (all_live && !keep_absorbed && !(t->flags & PRT_TRACE_NO_SPARSE_KEEP) && host_gen[b].n_carry > 0 &&
+                 host_gen[b].n_carry < host_gen[b].n_in &&
+                 (host_gen[b].n_in - host_gen[b].n_carry) * 64 <= host_gen[b].n_in) {
+        mode = 4;  // sparse loss: see the launch loop
+      }
+      // the generation before this one keeps its absorbed rays next time: this one then finds dead rays among its
+      // own whenever there are any, whatever it looked like now -- it is not offered a dense hint
+      if (at > 0 && t->seen_mode[at - 1] == 4) mode = 0;
+      t->seen_mode[t->n_seen++] = mode;
     }
     if (!done && host_gen[t->batch].n_in == 0) done = true;
     t->g += t->batch;
@@ -1802,6 +1842,8 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
     if (s->hint_rest.size() < s->missed_mode.size()) { s->hint_rest.resize(s->missed_mode.size(), 0); s->hint_rest_span.resize(s->missed_mode.size(), 0); }
     for (size_t g = 0; g < s->missed_mode.size(); ++g) {
       const char now = g < (size_t)t->n_seen ? t->seen_mode[g] : 0;
+      // (offered as dense, found to absorb a few rays: the hint it gets now -- mode 4 -- covers both, nothing to rest)
+      if (s->missed_mode[g] == 1 && now == 4) { found = true; continue; }
       if (s->missed_mode[g] != 0 && s->missed_mode[g] != now) {
         s->hint_rest_span[g] = s->hint_rest_span[g] ? std::min(s->hint_rest_span[g] * 2, 4096) : 32;
         s->hint_rest[g] = s->hint_rest_span[g];
@@ -1818,7 +1860,8 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
   // (a trace that published through k_fused_reinit had its generation slots -- the ray count and totals the records
   // are checked against -- cleared behind it: its records are not offered)
   for (int g = 0; g < kTileHintGenerations; ++g)
-    t->tile_record[g] = t->publish_in_kernel && g < t->n_seen && t->seen_mode[g] == 0;
+    t->tile_record[g] = t->publish_in_kernel && g < t->n_seen && (t->launch_mode[g] == 0 || t->launch_mode[g] == 3) &&
+                        (t->seen_mode[g] == 0 || t->seen_mode[g] == 4);
   t->record_rays = t->rays;
   // the control words are as a next trace of this shape needs them (see the launch loop)
   t->ready_workspace = t->w;
@@ -1996,11 +2039,13 @@ extern "C" int64_t prt_trace_batch(prt_scene* s, int device, prt_trace_job* jobs
 }
 
 
-extern "C" int prt_trace_telemetry(const prt_scene* s, int64_t* out10) {
-  int64_t* out8 = out10;
+extern "C" int prt_trace_telemetry(const prt_scene* s, int64_t* out12) {
+  int64_t* out8 = out12;
   if (!s || !out8) return fail(PRT_ERR_ARG, "null argument");
-  out10[8] = s->tile_hint_launches;
-  out10[9] = s->tile_hint_misses;
+  out12[8] = s->tile_hint_launches;
+  out12[9] = s->tile_hint_misses;
+  out12[10] = s->sparse_keep_launches;
+  out12[11] = 0;
   out8[0] = s->lookback_fallbacks;
   out8[1] = s->speculation_misses;
   out8[2] = s->dense_launches;

@@ -60,6 +60,7 @@ struct TraceTicket {
   int g = 0, batch = 0, test_stall = 0, n_seen = 0;
   int64_t total_rows = 0;
   char seen_mode[kMaxGenerationSlots];
+  char launch_mode[kMaxGenerationSlots] = {0};  // how each generation of the attempt was launched: assume value, 4 = dense with absorbed rays kept
   double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // include/prt.h prt_trace_stats
   // resources of the ticket
   int64_t* host_pinned = nullptr;               // 16 x int64 pinned staging (three-kernel path: control block, row count)
@@ -78,6 +79,7 @@ struct TraceTicket {
   bool tile_record[16] = {false};
   const double* record_rays = nullptr;  // the ray buffer of the trace those records are from
   bool allow_tile_hints = true, use_tile_records = false, used_tile_hints = false;
+  bool records_off = false;  // this attempt: the records of the generations still to come were taken on other rays (see launch_mode 4)
   unsigned long long user = 0;  // identity of this ticket in the workspace registry (0: not drawn yet)
 };
 
@@ -120,11 +122,13 @@ struct prt_scene {
   // what the previous trace's generations looked like (dense-mode hints for the next one, see k_generation)
   int64_t hint_n = -1;          // ray count of the trace the hints were recorded from (-1: no hints)
   int hint_keep_absorbed = 0;
-  std::vector<char> hint_mode;  // per generation: 0 general, 1 every ray recorded and carried on, 2 recorded, none carried
+  std::vector<char> hint_mode;  // per generation: 0 general, 1 every ray recorded and carried on, 2 recorded, none carried,
+                                // 4 recorded, all but a few (absorbed) carried on: runs as 1 with the absorbed rays kept
   long speculation_misses = 0;  // traces that had to be repeated because a hint did not hold
   bool full_rows = false;       // a ray set of this scene needed the state rows the compact form leaves out
   long full_rows_fallbacks = 0; // traces that had to be repeated for that reason (at most one per scene)
   long dense_launches = 0;      // generation launches made in dense mode so far
+  long sparse_keep_launches = 0;  // ... of which kept their absorbed rays to stay dense (hint mode 4)
   // PRT_TRACE_COUNT_PATHS: traces counted, rays that were not well formed, CSG node evaluations under an
   // implied cull box that had survivors, ... of which took upstream's exact box test
   long long path_counts[4] = {0, 0, 0, 0};

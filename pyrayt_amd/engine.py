@@ -33,6 +33,7 @@ TRACE_SYNC = 64
 TRACE_COUNT_PATHS = 128
 TRACE_NO_TIMING = 256
 TRACE_NO_TILE_RECORDS = 512
+TRACE_NO_SPARSE_KEEP = 1024
 TRACE_TICKETS = 4
 
 # prt_scene_options (include/prt.h): how a scene is compiled / which nearest-hit kernel serves
@@ -627,11 +628,11 @@ class DeviceScene:
 
     def telemetry(self):
         """Counters since the scene was created (``prt_trace_telemetry``)."""
-        out = (ctypes.c_int64 * 10)()
+        out = (ctypes.c_int64 * 12)()
         _check(library().prt_trace_telemetry(self.handle, out))
         keys = ("lookback_fallbacks", "speculation_misses", "dense_launches", "full_rows_fallbacks",
                 "counted_traces", "rays_not_well_formed", "implied_box_nodes", "exact_box_tests",
-                "tile_record_launches", "tile_record_misses")
+                "tile_record_launches", "tile_record_misses", "sparse_keep_launches")
         return dict(zip(keys, (int(v) for v in out)))
 
     # --- per-state entry points -----------------------------------------------------------------

@@ -1309,3 +1309,119 @@ def test_a_tile_record_that_does_not_hold_repeats_the_trace_and_rests():
         helpers.assert_frames_match(rows.cpu().numpy().T, want, what="records renewed")
     assert ds.telemetry()["tile_record_launches"] > launches
     ds.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# sparse loss (hint mode 4): a generation that records every ray and absorbs a few of them runs dense with those rays
+# kept the way upstream carries them (direction zeroed, dropped a generation later) instead of compacting them away
+# ---------------------------------------------------------------------------------------------
+def stop_before_lens(n=30_000, seed=3, ring=200, astray=0, with_hole=False):
+    """A small absorbing plate in front of a lens, a detector behind it: collimated rays, nearly all past the plate,
+    `ring` of them onto it (absorbed in generation 0: a sparse loss), `astray` past the plate and past everything
+    else (not recorded at all).  with_hole: the plate is an aperture() around the beam -- its hole stock has no
+    material, so the trace publishes its counts behind each batch and keeps no per-tile records."""
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    CountedObject.reset_ids()
+    api = scenes.product_api()
+    c = api.components
+    stop = c.aperture((10, 10), 6).move_x(-5) if with_hole else c.baffle((1, 1)).move(-5, 3.5, 0)
+    lens = c.thick_lens(60, -60, 3, aperture=8, material=api.materials.glass["BK7"])
+    det = c.baffle((6, 6)).move_x(40)
+    rng = np.random.default_rng(seed)
+    radius = 2.9 * np.sqrt(rng.random(n))
+    phi = 2 * np.pi * rng.random(n)
+    rays = scenes.blank_rays(n, 0.55)
+    rays[0] = -20.0
+    rays[1], rays[2] = radius * np.cos(phi), radius * np.sin(phi)
+    where = rng.choice(n, ring + astray, replace=False)
+    rays[1, where[:ring]] = rng.uniform(3.1, 3.9, ring)         # onto the plate
+    rays[2, where[:ring]] = rng.uniform(-0.4, 0.4, ring)
+    rays[1, where[ring:]] = rng.uniform(6.5, 9.0, astray)       # beside the plate, the lens and the detector
+    rays[4] = 1.0
+    return SceneSnapshot([stop, lens, det]), rays
+
+
+@pytest.mark.skipif(bool(engine.DEFAULT_OPTIONS) or bool(engine.DEFAULT_TRACE_FLAGS), reason="counts launches of the default path")
+@pytest.mark.parametrize("with_hole", [False, True])
+def test_sparse_loss_generations_run_dense_with_their_absorbed_rays_kept(with_hole):
+    from pyrayt_amd.engine import DeviceScene
+
+    snap, rays = stop_before_lens(with_hole=with_hole)
+    flat = helpers.flat_scene(snap)
+    want, want_counts = c_oracle.trace(flat, rays, 10)
+    n = rays.shape[1]
+    assert want_counts[0] == n and want_counts[1] == n - 200     # every ray recorded, the ring absorbed by the plate
+    ds = DeviceScene(snap)
+    block = torch.empty((15, n * 10), dtype=torch.float64, device="cuda:0")
+    buffers = [dev(rays) for _ in range(10)]                     # (all alive: ten addresses)
+    rows, counts = ds.trace(buffers.pop(), 10, out=block)       # first trace: no hints
+    assert counts == want_counts and ds.telemetry()["sparse_keep_launches"] == 0
+    for k in range(3):                                           # another buffer every time: no per-tile records
+        rows, counts = ds.trace(buffers[k], 10, out=block)
+        assert counts == want_counts
+        helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"absorbed rays kept, trace {k}")
+    told = ds.telemetry()
+    assert told["sparse_keep_launches"] == 3 and told["speculation_misses"] == 0
+    # other rays, lost elsewhere and in other numbers: the hint holds for them as well
+    _, other = stop_before_lens(seed=4, ring=350, with_hole=with_hole)
+    want_other, counts_other = c_oracle.trace(flat, other, 10)
+    other_buffer = dev(other)
+    rows, counts = ds.trace(other_buffer, 10, out=block)
+    assert counts == counts_other
+    helpers.assert_frames_match(rows.cpu().numpy().T, want_other, what="other rays on the same hint")
+    assert ds.telemetry()["sparse_keep_launches"] == 4 and ds.telemetry()["speculation_misses"] == 0
+    # the same buffer again: one compacting trace leaves the per-tile records, the traces after it run on those
+    buf = dev(rays)
+    for k in range(4):
+        rows, counts = ds.trace(buf, 10, out=block)
+        assert counts == want_counts
+        helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"same buffer, trace {k}")
+    if with_hole:                                                # (no records for this scene: the hint serves every trace)
+        assert ds.telemetry()["sparse_keep_launches"] == 8 and ds.telemetry()["tile_record_launches"] == 0
+    else:
+        assert ds.telemetry()["sparse_keep_launches"] == 5      # (the first of the four: its buffer was new)
+        assert ds.telemetry()["tile_record_launches"] == 2 * 2 and ds.telemetry()["tile_record_misses"] == 0
+    # not with the flag; upstream's bookkeeping for the whole trace is the other flag and has its own hints
+    before = ds.telemetry()["sparse_keep_launches"]
+    for flags in (engine.TRACE_NO_SPARSE_KEEP, engine.TRACE_KEEP_ABSORBED, engine.TRACE_NO_HINTS, engine.TRACE_UNFUSED):
+        for k in range(2):
+            rows, counts = ds.trace(buffers[3 + k], 10, out=block, flags=flags)
+            assert counts == want_counts
+            helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"flags {flags}")
+    assert ds.telemetry()["sparse_keep_launches"] == before
+    ds.close()
+
+
+@pytest.mark.skipif(bool(engine.DEFAULT_OPTIONS) or bool(engine.DEFAULT_TRACE_FLAGS), reason="counts misses of the default path")
+def test_a_sparse_loss_hint_that_does_not_hold_repeats_the_trace():
+    """Rays that are not recorded at all in a generation launched dense with its absorbed rays kept: the tiles
+    that hold them refute the hint, the trace is repeated without hints, the frame is the oracle's."""
+    from pyrayt_amd.engine import DeviceScene
+
+    snap, rays = stop_before_lens()
+    flat = helpers.flat_scene(snap)
+    ds = DeviceScene(snap)
+    n = rays.shape[1]
+    block = torch.empty((15, n * 10), dtype=torch.float64, device="cuda:0")
+    buffers = [dev(rays) for _ in range(2)]
+    for buffer in buffers:
+        ds.trace(buffer, 10, out=block)
+    assert ds.telemetry()["sparse_keep_launches"] == 1
+    _, astray = stop_before_lens(seed=8, astray=7)
+    want, want_counts = c_oracle.trace(flat, astray, 10)
+    assert want_counts[0] == n - 7
+    astray_buffer = dev(astray)
+    rows, counts = ds.trace(astray_buffer, 10, out=block)
+    assert counts == want_counts
+    helpers.assert_frames_match(rows.cpu().numpy().T, want, what="after a sparse-loss hint that did not hold")
+    assert ds.telemetry()["speculation_misses"] == 1
+    # the first ray set again, and in flight on two tickets
+    want, want_counts = c_oracle.trace(flat, rays, 10)
+    got = ds.trace_batch([dev(rays), dev(astray), dev(rays)], 10, depth=2)
+    torch.cuda.synchronize()
+    assert got[0][1] == want_counts and got[2][1] == want_counts
+    helpers.assert_frames_match(got[0][0].cpu().numpy().T, want, what="in flight, ticket 0")
+    helpers.assert_frames_match(got[2][0].cpu().numpy().T, want, what="in flight, ticket 0 again")
+    ds.close()
