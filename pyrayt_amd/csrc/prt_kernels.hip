@@ -1797,19 +1797,11 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
       rows_per_generation[t->g + b] = host_gen[b].n_live;
       t->total_rows += host_gen[b].n_live;
       const bool all_live = host_gen[b].n_live == host_gen[b].n_in;
-      char mode = all_live && host_gen[b].n_carry == host_gen[b].n_in ? 1 : all_live && host_gen[b].n_carry == 0 ? 2 : 0;
-      const int at = t->n_seen;
-      if (t->launch_mode[at] == 4) {
-        mode = mode == 1 ? 4 : 0;  // (kept its absorbed rays: how many there were cannot be told from the counts)
-      } else if (all_live && !keep_absorbed && !(t->flags & PRT_TRACE_NO_SPARSE_KEEP) && host_gen[b].n_carry > 0 &&
-                 host_gen[b].n_carry < host_gen[b].n_in &&
-                 (host_gen[b].n_in - host_gen[b].n_carry) * 64 <= host_gen[b].n_in) {
-        mode = 4;  // sparse loss: see the launch loop
-      }
-      // the generation before this one keeps its absorbed rays next time: this one then finds dead rays among its
-      // own whenever there are any, whatever it looked like now -- it is not offered a dense hint
-      if (at > 0 && t->seen_mode[at - 1] == 4) mode = 0;
-      t->seen_mode[t->n_seen++] = mode;
+      const int64_t lost = host_gen[b].n_in - host_gen[b].n_carry;
+      // (sparse loss: every ray recorded, at most 1 in 64 absorbed; 2: ... and at least one such ray in 128 tiles)
+      t->seen_sparse[t->n_seen] = !(all_live && host_gen[b].n_carry > 0 && lost > 0 && lost * 64 <= host_gen[b].n_in) ? 0
+                                  : lost * 128 * PRT_BLOCK >= host_gen[b].n_in ? 2 : 1;
+      t->seen_mode[t->n_seen++] = all_live && lost == 0 ? 1 : all_live && host_gen[b].n_carry == 0 ? 2 : 0;
     }
     if (!done && host_gen[t->batch].n_in == 0) done = true;
     t->g += t->batch;
@@ -1820,6 +1812,27 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
   }
   t->launched = false;
   if (error) for (bool& kept : t->tile_record) kept = false;  // (whatever the attempt overwrote before it failed)
+  if (!error) {
+    // Which generations keep their absorbed rays next time (mode 4, see the launch loop).  It moves the compaction to
+    // the generation behind: free when that one compacts anyway, worth it when the loss is dense enough for its
+    // stragglers to hold up most of the tiles in flight (config 3: one lost ray in 61 tiles, -6.6 % on the trace), a
+    // loss when it turns a dense generation into a compacting one for a handful of rays (config 2: one in 434 tiles,
+    // +3.4 %; profiles/r4/ab_round4.txt).
+    const bool sparse_ok = !keep_absorbed && !(t->flags & PRT_TRACE_NO_SPARSE_KEEP);
+    for (int g = 0; g < t->n_seen; ++g) {
+      char mode = t->seen_mode[g];
+      if (t->launch_mode[g] == 4) {
+        mode = mode == 1 ? 4 : 0;  // (kept its absorbed rays: how many there were cannot be told from the counts)
+      } else if (sparse_ok && t->seen_sparse[g] && g + 1 < t->n_seen &&
+                 (t->seen_sparse[g] == 2 || t->seen_mode[g + 1] == 0 || t->seen_sparse[g + 1])) {
+        mode = 4;
+      }
+      // the generation behind one that keeps its absorbed rays finds them dead among its own, whatever it looked like
+      // now: it is not offered a dense hint
+      if (g > 0 && t->seen_mode[g - 1] == 4) mode = 0;
+      t->seen_mode[g] = mode;
+    }
+  }
   if (error == PRT_ERR_SPECULATION || error == PRT_ERR_FULL_ROWS || error == PRT_ERR_TILE_HINT) return error;
   // a record block that looked too small to a generation launched on a hint may only have been too small
   // for the hint: the caller repeats without hints before it reports it

@@ -1,12 +1,14 @@
 #!/bin/bash
 # Per-dispatch durations of the generation kernel for one workload (rocprofv3 --kernel-trace), in launch order:
 #   bash tools/gen_trace.sh config3 4000000 -> gpurun_out/gen_trace/<workload>_durations.txt
+#   EXTRA='--flags 1024' LABEL=nokeep bash tools/gen_trace.sh config3 4000000 -> ..._nokeep_durations.txt (more bench.py arguments)
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/gen_trace
 mkdir -p $out; cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d $out -o $1 -- python3 $R/bench.py --workload $1 --rays $2 --steps 4 --warmup 2 --spinup-ms 0 --no-cpu-baseline --side-steps 0 --no-pipeline --ray-sets 1 > $out/$1.log 2>&1
-python3 - "$out" "$1" <<'PY'
+name=$1${LABEL:+_$LABEL}
+rocprofv3 --kernel-trace --output-format csv -d $out -o $name -- python3 $R/bench.py --workload $1 --rays $2 --steps 4 --warmup 2 --spinup-ms 0 --no-cpu-baseline --side-steps 0 --no-pipeline --ray-sets 1 $EXTRA > $out/$name.log 2>&1
+python3 - "$out" "$name" <<'PY'
 import csv, glob, sys
 out, name = sys.argv[1:3]
 rows = []
