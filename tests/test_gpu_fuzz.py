@@ -157,11 +157,15 @@ def test_random_bench(seed):
     want, want_counts = c_oracle.trace(flat, rays, limit)
     ds = DeviceScene(snap)
     device_rays = torch.from_numpy(rays).to("cuda:0")
-    for turn in range(3):           # the second and third run on the hints of the one before
-        rows, counts = ds.trace(device_rays, limit)
+    twin = device_rays.clone()
+    # every trace after the first runs on the hints of the one before: from another buffer the dense hints only
+    # (among them sparse-loss generations with their absorbed rays kept), from the same buffer again the per-tile
+    # records as well (the first such trace compacts where the hint kept absorbed rays, to leave a record)
+    for turn, buffer in enumerate((device_rays, twin, device_rays, device_rays, device_rays)):
+        rows, counts = ds.trace(buffer, limit)
         assert counts == want_counts, (seed, turn)
         helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"bench seed {seed} turn {turn}")
-    assert ds.telemetry()["speculation_misses"] == 0
+    assert ds.telemetry()["speculation_misses"] == 0 and ds.telemetry()["tile_record_misses"] == 0
     rows, counts = ds.trace(device_rays, limit, flags=2)       # and the three-kernel path
     assert counts == want_counts
     helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"bench seed {seed} unfused")
