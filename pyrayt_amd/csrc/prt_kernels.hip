@@ -502,8 +502,19 @@ static_assert(sizeof(GenCtrl) == 64, "host_gen sizing");
 // (no kernel argument of their own: the generation kernel has no register to spare for one).
 struct TileHint { unsigned excl_live, excl_carry, live, carry; };
 static const int kTileHintGenerations = 16;
-static const size_t kTileHintOffset =
+// Dead lists: a generation launched dense with its absorbed rays kept (hint mode 4) notes, per tile that kept any,
+// (tile << 9 | how many); the generation behind it, launched on that list (assume 5 / 6), takes its tiles' offsets
+// from "tile index x tile size minus the dead rays in front" -- no look-back for a handful of dead rays.  Three
+// lists in rotation: generation g writes list g % 3, g + 1 reads it, and every generation empties list (g + 1) % 3.
+static const int kDeadListCap = 1020;
+struct DeadList { unsigned count, pad[3], entry[kDeadListCap]; };
+static_assert(sizeof(DeadList) == 4096, "dead list sizing");
+static const size_t kDeadListOffset =
     ((size_t)(kMaxGenerationSlots + 2) * sizeof(GenCtrl) + 255) / 256 * 256 - sizeof(GenCtrl);  // from gen[0], see trace_layout
+static const size_t kTileHintOffset = kDeadListOffset + 3 * sizeof(DeadList);
+__device__ __forceinline__ DeadList* dead_list(GenCtrl* gen, int g) {
+  return reinterpret_cast<DeadList*>(reinterpret_cast<char*>(gen) + kDeadListOffset) + (g % 3);
+}
 __device__ __forceinline__ TileHint* tile_hints(GenCtrl* gen, int g) {
   return reinterpret_cast<TileHint*>(reinterpret_cast<char*>(gen) + kTileHintOffset) + (size_t)g * gridDim.x;
 }
@@ -773,7 +784,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
              int mirror_slot, int batch_last, int assume) {
   const int relaunch = (g + 1 != generation_limit) ? 1 : 0;  // the state written here is traced further
   __shared__ int s_wave_live[4], s_wave_carry[4];
-  __shared__ unsigned s_excl[2];
+  __shared__ unsigned s_excl[3];
   // A ticket from one atomic word would also give start-ordered tile numbers, but a single
   // word hands out only ~80 tickets/us chip-wide: 4k tiles would cost ~50 us per generation.
   const int tile = blockIdx.x;
@@ -789,7 +800,10 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   // aggregate: tiles behind it may already be waiting on it.
   const bool failed = ctrl->error != 0;
   const int64_t row_base = gen[g].row_base;
-  if (threadIdx.x == 0) tiles_next[tile] = TILE_INVALID;  // recycle the other buffer's word
+  if (threadIdx.x == 0) {
+    tiles_next[tile] = TILE_INVALID;  // recycle the other buffer's word
+    if (tile == 0) dead_list(gen, g + 1)->count = 0;  // ... and the dead list the next generation may write
+  }
 
   const int64_t i = (int64_t)tile * PRT_BLOCK + threadIdx.x;
   const LaneLists lists = lane_lists(scene.lds_slots);
@@ -797,7 +811,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   Ray8 r = {0, 0, 0, 1, 0, 0, 0, 0};
   double t = PRT_INF;
   int prim = -1;
-  bool live = false, carry = false;
+  bool live = false, carry = false, absorbs = false;
   STAMP(0);
   if (i < n && !failed) {
     // all 13 rows in one burst; the five metadata rows go straight to the lane's parking slots in
@@ -847,7 +861,6 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     live = is_live(r, prim);
     // absorbed rays are recorded and dropped; which primitives absorb is a bit mask for the first 64
     // (one scalar test instead of a per-lane table lookup in HBM)
-    bool absorbs = false;
     if (live) absorbs = prim < 64 ? ((scene.absorber_mask >> prim) & 1ull) != 0 : scene.prims[prim].mat_kind == MAT_ABSORBER;
     carry = live && (keep_absorbed || !absorbs);
   }
@@ -855,18 +868,44 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   STAMP(2);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long m_live = __ballot(live), m_carry = __ballot(carry);
+  // (absorbed rays that go on, dead, because this launch keeps them: counted per tile for the dead list)
+  const unsigned long long m_kept = keep_absorbed ? __ballot(absorbs) : 0ull;
   const unsigned long long below = (1ull << lane) - 1ull;
   int live_rank = __popcll(m_live & below), carry_rank = __popcll(m_carry & below);
   if (lane == 0) {
     s_wave_live[wave] = __popcll(m_live);
-    s_wave_carry[wave] = __popcll(m_carry);
+    s_wave_carry[wave] = __popcll(m_carry) | (__popcll(m_kept) << 16);  // (two counts of at most 64 in one word)
   }
   __syncthreads();
   unsigned agg_live = 0, agg_carry = 0;
   for (int w = 0; w < PRT_BLOCK / 64; ++w) {
-    if (w < wave) { live_rank += s_wave_live[w]; carry_rank += s_wave_carry[w]; }
+    if (w < wave) { live_rank += s_wave_live[w]; carry_rank += s_wave_carry[w] & 0xffff; }
     agg_live += s_wave_live[w];
     agg_carry += s_wave_carry[w];
+  }
+  const unsigned agg_kept = agg_carry >> 16;
+  agg_carry &= 0xffffu;
+  // Launched on the dead list of the generation before (assume 5 / 6): the dead rays in front of this tile, in it,
+  // and in all; one wave reads the list (a handful of entries as a rule: that is when the host offers this mode)
+  if (assume >= 5 && wave == 0) {
+    const DeadList* dead = dead_list(gen, g - 1);
+    const unsigned entries = dead->count;
+    unsigned before = 0, here = 0, all = 0;
+    if (entries > kDeadListCap) here = 0xffffu;  // (more tiles kept rays than the list holds: no tile's counts agree)
+    else if (entries) {
+      for (unsigned k = lane; k < entries; k += 64) {
+        const unsigned e = dead->entry[k], at = e >> 9, count = e & 511u;
+        all += count;
+        before += at < (unsigned)tile ? count : 0u;
+        here += at == (unsigned)tile ? count : 0u;
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+        all += __shfl_xor(all, off);
+        before += __shfl_xor(before, off);
+        here += __shfl_xor(here, off);
+      }
+    }
+    if (lane == 0) { s_excl[0] = before; s_excl[1] = here; s_excl[2] = all; }
   }
   STAMP(3);
   // Dense mode (assume != 0): the previous trace of this scene and ray count recorded every ray of this
@@ -881,11 +920,26 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   // any status word), and the last one to arrive publishes, with every tile's verdict visible to it
   // (assume == 3: whether the generation ends the trace is in the previous trace's totals, still in its slot)
   const bool publish_here = assume && mirror != nullptr &&
-                            (assume == 2 || batch_last || (assume == 3 && (gen[g].n_live == 0 || gen[g].n_carry == 0)));
+                            (assume == 2 || assume == 6 || batch_last ||
+                             (assume == 3 && (gen[g].n_live == 0 || gen[g].n_carry == 0)));
   if (assume) {
     if (threadIdx.x == 0) {
       const int64_t mine = (n - (int64_t)tile * PRT_BLOCK) < PRT_BLOCK ? (n - (int64_t)tile * PRT_BLOCK) : PRT_BLOCK;
       bool holds = (int64_t)agg_live == mine && (int64_t)agg_carry == (assume == 1 ? mine : 0);
+      if (assume >= 5) {  // (thread 0 wrote s_excl itself, above)
+        const unsigned before = s_excl[0];
+        const int64_t alive = mine - (int64_t)s_excl[1];
+        holds = (int64_t)agg_live == alive && (int64_t)agg_carry == (assume == 5 ? alive : 0);
+        s_excl[0] = (unsigned)tile * PRT_BLOCK - before;
+        s_excl[1] = assume == 5 ? (unsigned)tile * PRT_BLOCK - before : 0u;
+      }
+      // a tile of a launch that keeps its absorbed rays notes how many it kept (generation 0 has nobody to empty
+      // its list for it: it keeps rays without noting them, and the generation behind it compacts by look-back)
+      if (agg_kept && g > 0) {
+        DeadList* dead = dead_list(gen, g);
+        const unsigned at = atomicAdd(&dead->count, 1u);
+        if (at < (unsigned)kDeadListCap) dead->entry[at] = ((unsigned)tile << 9) | agg_kept;
+      }
       if (assume == 3) {  // the previous trace's record of this tile
         const TileHint h = tile_hints(gen, g)[tile];
         holds = agg_live == h.live && agg_carry == h.carry && n == *reinterpret_cast<const int64_t*>(gen[g].pad);
@@ -932,7 +986,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   STAMP(5);
   const int64_t last_tile = (n - 1) / PRT_BLOCK;
   int64_t excl_live, excl_carry;
-  if (assume == 3) {
+  if (assume == 3 || assume >= 5) {
     __syncthreads();
     excl_live = s_excl[0];
     excl_carry = s_excl[1];
@@ -968,8 +1022,10 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   if (finisher && threadIdx.x == 0) {  // totals are known here: hand over to g + 1
     // (dense mode: the totals are the assumption itself; if it failed the error word says so)
     // (assume == 3: the totals of the previous trace's generation g are still in its slot)
-    const int64_t total_live = assume == 3 ? gen[g].n_live : assume ? n : excl_live + agg_live;
-    const int64_t total_carry = assume == 3 ? gen[g].n_carry : assume ? (assume == 1 ? n : 0) : excl_carry + agg_carry;
+    // (assume 5 / 6: every ray but the dead ones of the list)
+    const int64_t total_live = assume == 3 ? gen[g].n_live : assume >= 5 ? n - (int64_t)s_excl[2] : assume ? n : excl_live + agg_live;
+    const int64_t total_carry = assume == 3 ? gen[g].n_carry
+                                : assume ? (assume == 1 ? n : assume == 5 ? n - (int64_t)s_excl[2] : 0) : excl_carry + agg_carry;
     const int64_t next_in = (total_live == 0) ? 0 : total_carry;
     gen[g].n_live = total_live;
     gen[g].n_carry = total_carry;
@@ -1427,7 +1483,7 @@ extern "C" int prt_interact(prt_scene* s, int device, const double* rays_in, int
 //   | block counts | block offsets | hit_t (n f64) | hit_prim (n i32)      [unfused path only]
 //   | ray buffer A (13 n) | ray buffer B (13 n)
 struct TraceLayout {
-  size_t ctrl, fctrl, gen, tile_hints, gen_rows, tiles_a, tiles_b, counts, offsets, hit_t, hit_prim, rays_a,
+  size_t ctrl, fctrl, gen, dead_lists, tile_hints, gen_rows, tiles_a, tiles_b, counts, offsets, hit_t, hit_prim, rays_a,
       rays_b, total;
 };
 static TraceLayout trace_layout(int64_t n) {
@@ -1441,6 +1497,7 @@ static TraceLayout trace_layout(int64_t n) {
   // host reads both back with one copy
   l.fctrl = take(sizeof(GenCtrl) + (kMaxGenerationSlots + 1) * sizeof(GenCtrl));
   l.gen = l.fctrl + sizeof(GenCtrl);
+  l.dead_lists = take(3 * sizeof(DeadList));                                   // (at kDeadListOffset from gen[0]: dead_list())
   l.tile_hints = take((size_t)kTileHintGenerations * nb * sizeof(TileHint));  // (at kTileHintOffset from gen[0]: tile_hints())
   l.gen_rows = take(kMaxGenerationSlots * sizeof(int64_t));
   l.tiles_a = take(nb * sizeof(unsigned long long));
@@ -1452,7 +1509,7 @@ static TraceLayout trace_layout(int64_t n) {
   l.rays_a = take(nn * PRT_RAY_ROWS * sizeof(double));
   l.rays_b = take(nn * PRT_RAY_ROWS * sizeof(double));
   l.total = at;
-  if (l.tile_hints - l.gen != kTileHintOffset) abort();  // (the kernel finds the records by this constant)
+  if (l.tile_hints - l.gen != kTileHintOffset || l.dead_lists - l.gen != kDeadListOffset) abort();  // (the kernel finds them by these constants)
   return l;
 }
 
@@ -1667,6 +1724,15 @@ static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
       if (on_record || wants_record || (t->flags & PRT_TRACE_NO_SPARSE_KEEP)) assume = 0;
       else { assume = 1; keep = 1; }
     }
+    // Modes 5 / 6: the generation behind one that keeps its absorbed rays and loses none of its own (5: carries the
+    // live ones on, 6: carries none) takes its offsets from the dead list its predecessor wrote (k_generation) --
+    // no look-back for a handful of dead rays.  Only right behind such a launch of this attempt (generation 0 keeps
+    // rays without listing them); behind anything else nothing dead arrives and the plain dense forms apply.
+    if (assume == 5 || assume == 6) {
+      const bool kept_before = gg > 0 && t->launch_mode[gg - 1] == 4;
+      if (!kept_before) assume -= 4;
+      else if (gg == 1) assume = 0;
+    }
     t->launch_mode[gg] = (char)(keep && !keep_absorbed ? 4 : assume);
     // (a generation that keeps its absorbed rays this time and did not last time, or the other way round, hands the
     // generations behind it other rays than their records were taken on)
@@ -1819,17 +1885,30 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
     // loss when it turns a dense generation into a compacting one for a handful of rays (config 2: one in 434 tiles,
     // +3.4 %; profiles/r4/ab_round4.txt).
     const bool sparse_ok = !keep_absorbed && !(t->flags & PRT_TRACE_NO_SPARSE_KEEP);
+    // (raw: what the counts say -- 1 every ray recorded and carried, 2 every ray recorded, none carried, 0 neither)
+    char raw_next = t->n_seen ? t->seen_mode[0] : 0;
     for (int g = 0; g < t->n_seen; ++g) {
-      char mode = t->seen_mode[g];
+      const char raw = raw_next, was = g < (int)s->hint_mode.size() && t->use_hints ? s->hint_mode[g] : 0;
+      raw_next = g + 1 < t->n_seen ? t->seen_mode[g + 1] : 0;
+      char mode = raw;
       if (t->launch_mode[g] == 4) {
-        mode = mode == 1 ? 4 : 0;  // (kept its absorbed rays: how many there were cannot be told from the counts)
+        mode = raw == 1 ? 4 : 0;  // (kept its absorbed rays: how many there were cannot be told from the counts)
       } else if (sparse_ok && t->seen_sparse[g] && g + 1 < t->n_seen &&
-                 (t->seen_sparse[g] == 2 || t->seen_mode[g + 1] == 0 || t->seen_sparse[g + 1])) {
+                 (t->seen_sparse[g] == 2 || raw_next == 0 || t->seen_sparse[g + 1] || g > 0)) {
+        // (g > 0: whatever the generation behind looks like, it can take the dead list -- modes 5 / 6 -- or compacts)
         mode = 4;
+      } else if (sparse_ok && was == 4 && raw == 1) {
+        mode = 4;  // nothing absorbed this time: the form that covers both stays
       }
-      // the generation behind one that keeps its absorbed rays finds them dead among its own, whatever it looked like
-      // now: it is not offered a dense hint
-      if (g > 0 && t->seen_mode[g - 1] == 4) mode = 0;
+      // The generation behind one that keeps its absorbed rays finds them dead among its own.  If it loses none of
+      // its own it runs on the dead list (5 / 6; generation 0 writes no list); otherwise it compacts.
+      if (g > 0 && t->seen_mode[g - 1] == 4) {
+        const bool listed = g > 1;
+        if (t->launch_mode[g] == 5 || t->launch_mode[g] == 6) mode = t->launch_mode[g];  // held, tile by tile
+        else if (listed && raw == 1) mode = 5;
+        else if (listed && raw == 2) mode = 6;
+        else mode = 0;
+      }
       t->seen_mode[g] = mode;
     }
   }
@@ -1855,9 +1934,13 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
     if (s->hint_rest.size() < s->missed_mode.size()) { s->hint_rest.resize(s->missed_mode.size(), 0); s->hint_rest_span.resize(s->missed_mode.size(), 0); }
     for (size_t g = 0; g < s->missed_mode.size(); ++g) {
       const char now = g < (size_t)t->n_seen ? t->seen_mode[g] : 0;
-      // (offered as dense, found to absorb a few rays: the hint it gets now -- mode 4 -- covers both, nothing to rest)
-      if (s->missed_mode[g] == 1 && now == 4) { found = true; continue; }
-      if (s->missed_mode[g] != 0 && s->missed_mode[g] != now) {
+      const char offered = s->missed_mode[g];
+      // (offered a plain dense form, found to absorb a few rays or to sit behind a generation that does: the hint it
+      // gets now covers both cases, nothing to rest)
+      if ((offered == 1 && (now == 4 || now == 5)) || (offered == 2 && now == 6)) { found = true; continue; }
+      // (offered a form that also covers what the repeat saw: not the one that missed)
+      if ((offered == 4 && now == 1) || (offered == 5 && now == 1) || (offered == 6 && now == 2)) continue;
+      if (offered != 0 && offered != now) {
         s->hint_rest_span[g] = s->hint_rest_span[g] ? std::min(s->hint_rest_span[g] * 2, 4096) : 32;
         s->hint_rest[g] = s->hint_rest_span[g];
         found = true;

@@ -1425,3 +1425,137 @@ def test_a_sparse_loss_hint_that_does_not_hold_repeats_the_trace():
     helpers.assert_frames_match(got[0][0].cpu().numpy().T, want, what="in flight, ticket 0")
     helpers.assert_frames_match(got[2][0].cpu().numpy().T, want, what="in flight, ticket 0 again")
     ds.close()
+
+
+def plate_between_two_lenses(n=30_000, seed=3, ring=200, astray=0):
+    """stop_before_lens with a weak lens in front: the plate absorbs its rays in generation 2, so that the sparse loss
+    has a generation in front of it (which empties the dead list) and one behind it that loses nothing."""
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    CountedObject.reset_ids()
+    api = scenes.product_api()
+    c = api.components
+    first = c.thick_lens(200, -200, 2, aperture=8.4, material=api.materials.glass["BK7"]).move_x(-12)
+    stop = c.baffle((1, 1)).move(-5, 3.5, 0)
+    lens = c.thick_lens(60, -60, 3, aperture=8, material=api.materials.glass["BK7"])
+    det = c.baffle((6, 6)).move_x(40)
+    trap = c.baffle((0.6, 0.6)).move(0, -3.1, 0)                # inside the second lens, off the beam: for `astray`
+    rng = np.random.default_rng(seed)
+    radius = 0.3 + 2.6 * np.sqrt(rng.random(n))                 # (no near-axial rays: those have quirks of their own)
+    phi = 2 * np.pi * rng.random(n)
+    rays = scenes.blank_rays(n, 0.55)
+    rays[0] = -20.0
+    rays[1], rays[2] = radius * np.cos(phi), radius * np.sin(phi)
+    where = rng.choice(n, ring + astray, replace=False)
+    rays[1, where[:ring]] = rng.uniform(3.3, 3.9, ring)         # onto the plate
+    rays[2, where[:ring]] = rng.uniform(-0.4, 0.4, ring)
+    rays[1, where[ring:]] = rng.uniform(-3.35, -3.25, astray)   # into the second lens and onto the trap inside it:
+    rays[2, where[ring:]] = rng.uniform(-0.1, 0.1, astray)      # absorbed a generation after the plate's rays
+    rays[4] = 1.0
+    return SceneSnapshot([first, stop, lens, det, trap]), rays
+
+
+def near_axial_config2(n=20_000, seed=5, odd=60):
+    """Config 2 with a handful of near-axial rays: they miss the lens's back surface (an upstream quirk) and end on the
+    detector a generation early -- generation 1 records every ray and absorbs those few, generation 2 absorbs the rest."""
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    CountedObject.reset_ids()
+    parts, rays = scenes.config2(scenes.product_api(), n, seed=seed)
+    rng = np.random.default_rng(seed + 100)
+    idx = rng.choice(n, odd, replace=False)
+    angle, phi = rng.uniform(0, 3e-4, odd), rng.uniform(0, 2 * np.pi, odd)
+    rays[4, idx], rays[5, idx], rays[6, idx] = np.cos(angle), np.sin(angle) * np.cos(phi), np.sin(angle) * np.sin(phi)
+    return SceneSnapshot(parts), rays
+
+
+@pytest.mark.skipif(bool(engine.DEFAULT_OPTIONS) or bool(engine.DEFAULT_TRACE_FLAGS), reason="counts launches of the default path")
+@pytest.mark.parametrize("which", ["carried", "ends"])
+def test_the_generation_behind_a_sparse_loss_runs_on_its_dead_list(which):
+    """Hint modes 5 / 6: behind a generation that kept its absorbed rays, a generation that loses none of its own takes
+    its tiles' offsets from the list of kept rays -- no generation of such a trace compacts by look-back."""
+    from pyrayt_amd.engine import DeviceScene
+
+    if which == "carried":
+        snap, rays = plate_between_two_lenses()
+        _, other = plate_between_two_lenses(seed=4, ring=350)
+        shape = lambda counts, n: len(counts) == 5 and counts[2] == n and counts[3] < n and counts[4] == counts[3]
+    else:
+        snap, rays = near_axial_config2()
+        _, other = near_axial_config2(seed=6, odd=25)
+        shape = lambda counts, n: len(counts) == 3 and counts[1] == n and counts[2] < n
+    flat = helpers.flat_scene(snap)
+    want, want_counts = c_oracle.trace(flat, rays, 10)
+    n = rays.shape[1]
+    assert shape(want_counts, n), want_counts
+    ds = DeviceScene(snap)
+    block = torch.empty((15, n * 10), dtype=torch.float64, device="cuda:0")
+    buffers = [dev(rays) for _ in range(8)]
+    generations = len(want_counts)
+    rows, counts = ds.trace(buffers[0], 10, out=block)           # first trace: look-backs
+    assert counts == want_counts and ds.telemetry()["dense_launches"] == 0
+    for k in range(1, 4):                                        # from other buffers: every generation dense
+        before = ds.telemetry()
+        rows, counts = ds.trace(buffers[k], 10, out=block)
+        assert counts == want_counts
+        helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"dead list, trace {k}")
+        told = ds.telemetry()
+        assert told["dense_launches"] - before["dense_launches"] == generations, (told, before)
+        assert told["sparse_keep_launches"] - before["sparse_keep_launches"] == 1 and told["speculation_misses"] == 0
+    # other rays, lost in other tiles and other numbers
+    want_other, counts_other = c_oracle.trace(flat, other, 10)
+    assert shape(counts_other, n)
+    other_buffer = dev(other)
+    rows, counts = ds.trace(other_buffer, 10, out=block)
+    assert counts == counts_other and ds.telemetry()["speculation_misses"] == 0
+    helpers.assert_frames_match(rows.cpu().numpy().T, want_other, what="other rays on the same hints")
+    # in flight on two tickets and two streams, and under the flags that switch the forms off
+    got = ds.trace_batch([buffers[4], other_buffer, buffers[5]], 10, depth=2)
+    torch.cuda.synchronize()
+    for (rows, counts), (frame, frame_counts) in zip(got, ((want, want_counts), (want_other, counts_other), (want, want_counts))):
+        assert counts == frame_counts
+        helpers.assert_frames_match(rows.cpu().numpy().T, frame, what="in flight")
+    for flags in (engine.TRACE_NO_SPARSE_KEEP, engine.TRACE_NO_HINTS, engine.TRACE_KEEP_ABSORBED):
+        for k in (6, 7):
+            rows, counts = ds.trace(buffers[k], 10, out=block, flags=flags)
+            assert counts == want_counts
+            helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"flags {flags}")
+    # the same buffer again and again: the per-tile records take over from the second such trace on
+    for k in range(4):
+        rows, counts = ds.trace(buffers[7], 10, out=block)
+        assert counts == want_counts
+        helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"same buffer, trace {k}")
+    assert ds.telemetry()["tile_record_misses"] == 0 and ds.telemetry()["speculation_misses"] == 0
+    ds.close()
+
+
+@pytest.mark.skipif(bool(engine.DEFAULT_OPTIONS) or bool(engine.DEFAULT_TRACE_FLAGS), reason="counts misses of the default path")
+def test_a_dead_list_hint_that_does_not_hold_repeats_the_trace():
+    """Rays absorbed in the generation launched on the dead list (by a trap inside the second lens): their tiles' counts
+    refute the hint, the trace is repeated, the frame is the oracle's."""
+    from pyrayt_amd.engine import DeviceScene
+
+    snap, rays = plate_between_two_lenses()
+    flat = helpers.flat_scene(snap)
+    ds = DeviceScene(snap)
+    n = rays.shape[1]
+    block = torch.empty((15, n * 10), dtype=torch.float64, device="cuda:0")
+    buffers = [dev(rays) for _ in range(3)]
+    for buffer in buffers[:2]:
+        ds.trace(buffer, 10, out=block)
+    assert ds.telemetry()["sparse_keep_launches"] == 1
+    _, astray = plate_between_two_lenses(seed=8, astray=5)
+    want, want_counts = c_oracle.trace(flat, astray, 10)
+    assert want_counts[3] == n - 200 and want_counts[4] == n - 205   # (recorded in generation 3, by the trap)
+    astray_buffer = dev(astray)
+    rows, counts = ds.trace(astray_buffer, 10, out=block)
+    assert counts == want_counts
+    helpers.assert_frames_match(rows.cpu().numpy().T, want, what="after a dead-list hint that did not hold")
+    assert ds.telemetry()["speculation_misses"] == 1
+    want, want_counts = c_oracle.trace(flat, rays, 10)
+    rows, counts = ds.trace(buffers[2], 10, out=block)
+    assert counts == want_counts
+    helpers.assert_frames_match(rows.cpu().numpy().T, want, what="the first rays again")
+    ds.close()
