@@ -486,7 +486,9 @@ int prt_trace_stats(const prt_scene* scene, double* out8);
  * compacts -- finds them dead, records nothing for them and drops them.  The rows are the same; what is saved is
  * the look-back of a generation whose few odd rays make their tiles the slowest ones, so that every tile waited
  * for a straggler (PRT_TRACE_NO_SPARSE_KEEP turns it off for a call; a trace of the same ray buffer as the
- * ticket's last prefers the per-tile record).
+ * ticket's last prefers the per-tile record).  Such a launch notes, per tile, how many rays it kept (a dead list
+ * in the workspace), and the generation behind it -- if it loses no ray of its own -- is launched on that list:
+ * its tiles' positions are "tile index x tile size minus the dead rays in front", again without a look-back.
  * Per-tile records: a generation that does lose rays leaves, for every tile, where the tile's rows and carried
  * rays went and how many it had, in the workspace.  The next trace of the same ticket with the same workspace
  * and ray count runs that generation on the record instead of a look-back; every tile checks its own counts
