@@ -1946,6 +1946,16 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
         found = true;
       }
     }
+    if (!found) {
+      // Nobody looks different in the repeat: if generations ran on a dead list, the list it is (more tiles kept
+      // rays than it holds -- a reader cannot tell from the counts of a trace without hints): those rest.
+      for (size_t g = 0; g < s->missed_mode.size(); ++g) {
+        if (s->missed_mode[g] != 5 && s->missed_mode[g] != 6) continue;
+        s->hint_rest_span[g] = s->hint_rest_span[g] ? std::min(s->hint_rest_span[g] * 2, 4096) : 32;
+        s->hint_rest[g] = s->hint_rest_span[g];
+        found = true;
+      }
+    }
     if (found) { s->hint_holdoff = 0; s->hint_misses_in_a_row = 0; }  // (the culprit rests by itself)
     s->missed_mode.clear();
   }

@@ -1559,3 +1559,28 @@ def test_a_dead_list_hint_that_does_not_hold_repeats_the_trace():
     assert counts == want_counts
     helpers.assert_frames_match(rows.cpu().numpy().T, want, what="the first rays again")
     ds.close()
+
+
+@pytest.mark.skipif(bool(engine.DEFAULT_OPTIONS) or bool(engine.DEFAULT_TRACE_FLAGS), reason="counts misses of the default path")
+def test_a_dead_list_that_overflows_costs_one_repeat_and_rests():
+    """More tiles keep rays than the dead list has entries (1020): the generation launched on it cannot take its
+    offsets from it, every tile says so, the trace is repeated; from then on that generation compacts."""
+    from pyrayt_amd.engine import DeviceScene
+
+    snap, rays = near_axial_config2(n=600_000, odd=2500)
+    flat = helpers.flat_scene(snap)
+    want, want_counts = c_oracle.trace(flat, rays, 10)
+    n = rays.shape[1]
+    lost = n - want_counts[2]
+    assert want_counts[1] == n and 1500 < lost and lost * 64 <= n
+    ds = DeviceScene(snap)
+    block = torch.empty((15, n * 3), dtype=torch.float64, device="cuda:0")
+    buffers = [dev(rays) for _ in range(4)]
+    for k, buffer in enumerate(buffers):
+        rows, counts = ds.trace(buffer, 10, out=block)
+        assert counts == want_counts, k
+        helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"overflowing dead list, trace {k}")
+        told = ds.telemetry()
+        assert told["speculation_misses"] == (0 if k == 0 else 1), (k, told)   # (the second trace found out)
+    assert told["sparse_keep_launches"] == 3                     # generation 1 keeps its rays all the same
+    ds.close()
