@@ -214,3 +214,20 @@ def test_package_asks_for_hardware_queues_before_the_runtime_loads():
     assert run(show) == ["set", "8"]
     assert run("import torch; " + show) == ["late", "None"]
     assert run(show, {"GPU_MAX_HW_QUEUES": "2"}) == ["user", "2"]
+
+
+def test_binding_constants_are_the_headers():
+    """Every PRT_TRACE_* flag and PRT_ERR_* code the binding names has the header's value, and no two flags share a
+    bit (the flags travel as one int through prt_trace / prt_trace_begin / prt_trace_batch)."""
+    from pyrayt_amd import engine
+
+    header = open(HEADER).read()
+    flags = {name: int(value) for name, value in re.findall(r"#define PRT_TRACE_([A-Z_]+) (\d+)", header)}
+    tickets = flags.pop("TICKETS")
+    assert tickets == engine.TRACE_TICKETS
+    assert len(flags) >= 11 and all(v & (v - 1) == 0 for v in flags.values()) and len(set(flags.values())) == len(flags)
+    for name, value in flags.items():
+        assert getattr(engine, "TRACE_" + name) == value, name
+    errors = {name: int(value) for name, value in re.findall(r"#define PRT_ERR_([A-Z_]+) \((-\d+)\)", header)}
+    for name in ("ROWS_CAP", "UNTRACABLE", "WAVELENGTH"):
+        assert getattr(engine, "ERR_" + name) == errors[name], name
