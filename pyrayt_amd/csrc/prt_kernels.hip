@@ -1864,9 +1864,12 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
       t->total_rows += host_gen[b].n_live;
       const bool all_live = host_gen[b].n_live == host_gen[b].n_in;
       const int64_t lost = host_gen[b].n_in - host_gen[b].n_carry;
-      // (sparse loss: every ray recorded, at most 1 in 64 absorbed; 2: ... and at least one such ray in 128 tiles)
+      // (bit 0, sparse loss: every ray recorded, at most 1 in 64 absorbed; bit 1: ... at least one such ray in 128
+      // tiles, enough to stall a look-back; bit 2: ... few enough for the generation behind to read them off the dead
+      // list -- a tile reads the whole list, and from a few hundred entries on that costs what a look-back without
+      // stragglers costs: ab_round4.txt, "mode 7")
       t->seen_sparse[t->n_seen] = !(all_live && host_gen[b].n_carry > 0 && lost > 0 && lost * 64 <= host_gen[b].n_in) ? 0
-                                  : lost * 128 * PRT_BLOCK >= host_gen[b].n_in ? 2 : 1;
+                                  : (char)(1 | (lost * 128 * PRT_BLOCK >= host_gen[b].n_in ? 2 : 0) | (lost <= 256 ? 4 : 0));
       t->seen_mode[t->n_seen++] = all_live && lost == 0 ? 1 : all_live && host_gen[b].n_carry == 0 ? 2 : 0;
     }
     if (!done && host_gen[t->batch].n_in == 0) done = true;
@@ -1894,8 +1897,8 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
       if (t->launch_mode[g] == 4) {
         mode = raw == 1 ? 4 : 0;  // (kept its absorbed rays: how many there were cannot be told from the counts)
       } else if (sparse_ok && t->seen_sparse[g] && g + 1 < t->n_seen &&
-                 (t->seen_sparse[g] == 2 || raw_next == 0 || t->seen_sparse[g + 1] || g > 0)) {
-        // (g > 0: whatever the generation behind looks like, it can take the dead list -- modes 5 / 6 -- or compacts)
+                 ((t->seen_sparse[g] & 2) || raw_next == 0 || t->seen_sparse[g + 1] || (g > 0 && (t->seen_sparse[g] & 4)))) {
+        // (g > 0 and few: whatever the generation behind looks like, it can take the dead list -- modes 5 / 6)
         mode = 4;
       } else if (sparse_ok && was == 4 && raw == 1) {
         mode = 4;  // nothing absorbed this time: the form that covers both stays
@@ -1903,7 +1906,8 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
       // The generation behind one that keeps its absorbed rays finds them dead among its own.  If it loses none of
       // its own it runs on the dead list (5 / 6; generation 0 writes no list); otherwise it compacts.
       if (g > 0 && t->seen_mode[g - 1] == 4) {
-        const bool listed = g > 1;
+        // (the list is worth reading when it is short: known when the generation before was seen without keeping)
+        const bool listed = g > 1 && t->launch_mode[g - 1] != 4 && (t->seen_sparse[g - 1] & 4);
         if (t->launch_mode[g] == 5 || t->launch_mode[g] == 6) mode = t->launch_mode[g];  // held, tile by tile
         else if (listed && raw == 1) mode = 5;
         else if (listed && raw == 2) mode = 6;
