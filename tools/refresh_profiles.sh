@@ -47,6 +47,12 @@ cp gpurun_out/gen_counters/config2_per_generation.txt $out/per_generation_config
 cp gpurun_out/gen_counters/config3_per_generation.txt $out/per_generation_config3.txt
 bash tools/counters_cfg.sh > $out/counters_cfg.log 2>&1
 cp gpurun_out/counters/sq_counters_config*.txt gpurun_out/counters/traffic_config*.json gpurun_out/counters/gen_times_config*.txt $out/
+# per-dispatch durations with and without the sparse-loss forms (hint modes 4 / 5 / 6)
+bash tools/gen_trace.sh config3 4000000 > /dev/null 2>&1
+EXTRA="--flags 1024" LABEL=nokeep bash tools/gen_trace.sh config3 4000000 > /dev/null 2>&1
+EXTRA="--ray-sets 4" LABEL=rotating bash tools/gen_trace.sh config2 1000000 > /dev/null 2>&1
+EXTRA="--ray-sets 4 --flags 1024" LABEL=rotating_nokeep bash tools/gen_trace.sh config2 1000000 > /dev/null 2>&1
+python3 tools/gen_durations.py gpurun_out/gen_trace > $out/gen_durations.txt
 # keep the summaries, drop the bulky per-dispatch traces
 rm -f $out/*_kernel_trace.csv $out/*_agent_info.csv $out/*domain_stats.csv
 ls -la $out | head -60
