@@ -348,6 +348,7 @@ def test_config2_one_million_rays():
     ds.close()
 
 
+@pytest.mark.skipif(bool(engine.DEFAULT_TRACE_FLAGS & 3), reason="counts the launches of the fused path without upstream's extra generation")
 def test_lookback_stall_falls_back_to_three_kernel_path():
     """If the decoupled look-back ever gave up (it relies on in-order workgroup dispatch, which
     is observed but not promised), prt_trace must transparently redo the loop on the path with
@@ -821,7 +822,8 @@ def test_traces_in_flight_equal_synchronous_traces(name):
         torch.cuda.synchronize()
         assert np.array_equal(rows.cpu().numpy(), want, equal_nan=True), k
         st = ds.trace_stats()
-        assert st["variant"] == 1 and st["rows"] == want.shape[1] and st["kernel_ms"] > 0
+        fused = not (engine.DEFAULT_TRACE_FLAGS & engine.TRACE_UNFUSED)
+        assert st["variant"] == (1 if fused else 2) and st["rows"] == want.shape[1] and st["kernel_ms"] > 0
         blocks[k & 1].fill_(float("nan"))
     ds.close()
 
@@ -853,7 +855,8 @@ def test_tickets_reject_misuse_and_every_flag_goes_through_them():
             for ticket, block in ((1, b), (0, a)):
                 rows, counts = ds.trace_end(ticket)
                 helpers.assert_frames_match(rows.cpu().numpy().T, fx["frame"], what=f"flags {flags} ticket {ticket}")
-    assert ds.telemetry()["lookback_fallbacks"] == 4
+    # (the stall hook lives in the fused kernels: two flag sets carry it, two traces each, on two tickets)
+    assert ds.telemetry()["lookback_fallbacks"] == (0 if engine.DEFAULT_TRACE_FLAGS & engine.TRACE_UNFUSED else 4)
     # a record block one column short is reported by prt_trace_end
     short = torch.empty((15, fx["frame"].shape[0] - 1), dtype=torch.float64, device="cuda:0")
     ds.trace_begin(0, rays, limit, short)
@@ -924,6 +927,7 @@ def test_a_missed_hint_with_an_exact_fit_record_block_is_repeated_not_reported()
 # ---------------------------------------------------------------------------------------------
 # PRT_TRACE_COUNT_PATHS: the shipping library says how often its shortcuts fall through
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.skipif(bool(engine.DEFAULT_TRACE_FLAGS & 1), reason="absorbed rays that are carried on have no direction: they count as not well formed")
 def test_path_counters_tell_well_formed_rays_from_the_others():
     if engine.DEFAULT_OPTIONS:
         pytest.skip("the expected counts are those of the default scene options")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # the parity, fuzz, cull and multi-rank tests under every product-path switch (one summary line per switch):
 # scene options (prt_scene_options) and trace flags (PRT_TRACE_*), handed to the product by tests/conftest.py
-for env in "PRT_TEST_FLAGS=4" "PRT_TEST_FLAGS=8" "PRT_TEST_FLAGS=16" "PRT_TEST_FLAGS=512" "PRT_TEST_FLAGS=1024" "PRT_TEST_OPTIONS=no_chain=1" "PRT_TEST_OPTIONS=no_cull=1" \
+for env in "PRT_TEST_FLAGS=1" "PRT_TEST_FLAGS=2" "PRT_TEST_FLAGS=4" "PRT_TEST_FLAGS=8" "PRT_TEST_FLAGS=16" "PRT_TEST_FLAGS=512" "PRT_TEST_FLAGS=1024" "PRT_TEST_OPTIONS=no_chain=1" "PRT_TEST_OPTIONS=no_cull=1" \
            "PRT_TEST_OPTIONS=no_groups=1" "PRT_TEST_OPTIONS=list_order_groups=1" "PRT_TEST_OPTIONS=no_implied=1" \
            "PRT_TEST_OPTIONS=hit_lanes=8" "PRT_TEST_OPTIONS=no_intervals=1"; do
   echo "== $env"
