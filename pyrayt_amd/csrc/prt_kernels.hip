@@ -1870,6 +1870,11 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
       // stragglers costs: ab_round4.txt, "mode 7")
       t->seen_sparse[t->n_seen] = !(all_live && host_gen[b].n_carry > 0 && lost > 0 && lost * 64 <= host_gen[b].n_in) ? 0
                                   : (char)(1 | (lost * 128 * PRT_BLOCK >= host_gen[b].n_in ? 2 : 0) | (lost <= 256 ? 4 : 0));
+      // (bits 3, 4: more than 1 ray in 32 / in 16 arrived dead or hit nothing.  The first keeps the generation before
+      // from starting to keep its absorbed rays -- this one would carry too many dead lanes --, the second makes one
+      // that does keep them stop: it is keeping too many by now.  Two thresholds, a sparse loss apart: no flip-flop.)
+      if ((host_gen[b].n_in - host_gen[b].n_live) * 32 > host_gen[b].n_in) t->seen_sparse[t->n_seen] |= 8;
+      if ((host_gen[b].n_in - host_gen[b].n_live) * 16 > host_gen[b].n_in) t->seen_sparse[t->n_seen] |= 16;
       t->seen_mode[t->n_seen++] = all_live && lost == 0 ? 1 : all_live && host_gen[b].n_carry == 0 ? 2 : 0;
     }
     if (!done && host_gen[t->batch].n_in == 0) done = true;
@@ -1895,9 +1900,12 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
       raw_next = g + 1 < t->n_seen ? t->seen_mode[g + 1] : 0;
       char mode = raw;
       if (t->launch_mode[g] == 4) {
-        mode = raw == 1 ? 4 : 0;  // (kept its absorbed rays: how many there were cannot be told from the counts)
-      } else if (sparse_ok && t->seen_sparse[g] && g + 1 < t->n_seen &&
-                 ((t->seen_sparse[g] & 2) || raw_next == 0 || t->seen_sparse[g + 1] || (g > 0 && (t->seen_sparse[g] & 4)))) {
+        // (kept its absorbed rays: how many there were cannot be told from its own counts -- the generation behind
+        // tells: when a thirty-second of what it received is dead, this one goes back to compacting and is judged anew)
+        const bool flooded = g + 1 < t->n_seen && (t->seen_sparse[g + 1] & 16);
+        mode = raw == 1 && !flooded ? 4 : 0;
+      } else if (sparse_ok && (t->seen_sparse[g] & 1) && g + 1 < t->n_seen && !(t->seen_sparse[g + 1] & 8) &&
+                 ((t->seen_sparse[g] & 2) || raw_next == 0 || (t->seen_sparse[g + 1] & 1) || (g > 0 && (t->seen_sparse[g] & 4)))) {
         // (g > 0 and few: whatever the generation behind looks like, it can take the dead list -- modes 5 / 6)
         mode = 4;
       } else if (sparse_ok && was == 4 && raw == 1) {

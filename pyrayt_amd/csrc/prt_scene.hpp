@@ -60,7 +60,7 @@ struct TraceTicket {
   int g = 0, batch = 0, test_stall = 0, n_seen = 0;
   int64_t total_rows = 0;
   char seen_mode[kMaxGenerationSlots];
-  char seen_sparse[kMaxGenerationSlots];         // per generation seen: bit 0 sparse loss, bit 1 dense enough to stall a look-back, bit 2 few enough for a dead list
+  char seen_sparse[kMaxGenerationSlots];         // per generation seen: bit 0 sparse loss, bit 1 dense enough to stall a look-back, bit 2 few enough for a dead list, bits 3 / 4 more than 1 ray in 32 / 16 not recorded
   char launch_mode[kMaxGenerationSlots] = {0};  // how each generation of the attempt was launched: assume value, 4 = dense with absorbed rays kept
   double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // include/prt.h prt_trace_stats
   // resources of the ticket

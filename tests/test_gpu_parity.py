@@ -1599,3 +1599,34 @@ def test_a_dead_list_that_overflows_costs_one_repeat_and_rests():
         assert told["speculation_misses"] == 1, (k, told)        # (the first of them found out)
     assert told["sparse_keep_launches"] == 2 + 3                 # generation 1 keeps its rays all the same
     ds.close()
+
+
+@pytest.mark.skipif(bool(engine.DEFAULT_OPTIONS) or bool(engine.DEFAULT_TRACE_FLAGS), reason="counts launches of the default path")
+def test_a_generation_that_keeps_too_many_rays_goes_back_to_compacting():
+    """The sparse-loss form is sticky (how many rays a launch kept cannot be told from its counts), but the generation
+    behind sees them arrive dead: when they are more than a sixteenth of its rays the form is dropped, and taken up
+    again when the loss is sparse again."""
+    from pyrayt_amd.engine import DeviceScene
+
+    snap, few = stop_before_lens(ring=200)
+    _, many = stop_before_lens(seed=4, ring=3000)
+    flat = helpers.flat_scene(snap)
+    frames = {"few": c_oracle.trace(flat, few, 10), "many": c_oracle.trace(flat, many, 10)}
+    n = few.shape[1]
+    assert frames["many"][1][1] == n - 3000
+    ds = DeviceScene(snap)
+    block = torch.empty((15, n * 10), dtype=torch.float64, device="cuda:0")
+    kept = []
+    buffers = []                                                  # (all alive: another address every time)
+    for which in ("few", "few", "many", "many", "few", "few"):
+        buffers.append(dev(few if which == "few" else many))
+        rows, counts = ds.trace(buffers[-1], 10, out=block)
+        want, want_counts = frames[which]
+        assert counts == want_counts, which
+        helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"{which}, trace {len(kept)}")
+        kept.append(ds.telemetry()["sparse_keep_launches"])
+    # first trace: no hints; second: kept; third: still kept (3000 rays of them); fourth: dropped; fifth: compacts and
+    # sees a sparse loss again; sixth: kept
+    assert kept == [0, 1, 2, 2, 2, 3], kept
+    assert ds.telemetry()["speculation_misses"] == 0
+    ds.close()
