@@ -453,6 +453,19 @@ int prt_frame_stats_sharded(prt_comm* comm, const double* rows, int64_t ld, int6
  * out (n_groups, 8) = the statistics from a second pass's sums and the pivots it ran about.  All device pointers. */
 int prt_frame_pivots(int device, const double* sums, int n_groups, double* pivots_out, void* stream);
 int prt_frame_finish(int device, const double* sums, const double* pivots, int n_groups, double* out, void* stream);
+/* Mean squares of one quantity of the frame: the merit functions of examples/lens_design.ipynb, all of the form
+ * np.mean(np.square(f(rows) - c)) over a selection of rows (cell 20, the coma metric: np.sin(ray_set['y_tilt']) -
+ * np.sin(angle) over the rows of the last generation; cells 28 / 32: the axis intercept minus the design focus).
+ * quantity: a frame column (PRT_COL_*, 0..14) or PRT_FRAME_AXIS_INTERCEPT = x0 - x_tilt * y0 / y_tilt (cells 12, 15);
+ * transform: 0 none, 1 sin; v = transform(quantity) - about.  out = (n_groups, 3) float64 on the device, per group
+ * the rows counted, sum v, sum v^2, over the rows that pass the surface / generation filter (NaN = every row) and
+ * whose v is finite (pandas' mean skips a NaN: a ray parallel to the axis has no intercept); the sums are additive
+ * over any partition of the rows, so a sharded frame adds them across ranks before dividing.  rays_per_source <= 0:
+ * one group.  Stream-ordered. */
+#define PRT_FRAME_AXIS_INTERCEPT 15
+int prt_frame_mean_square(int device, const double* rows, int64_t ld, int64_t n_rows, double surface,
+                          double generation, double rays_per_source, int n_groups, int quantity, int transform,
+                          double about, double* out, void* stream);
 
 /* statistics of the trace of this scene that ended last (prt_trace / prt_trace_end; for bench.py's roofline):
  * out[0] = generations that found rays, out[1] = sum over generations of rays alive at entry,

@@ -265,7 +265,7 @@ __device__ __forceinline__ void binomial_root(double a, double b, double c, doub
   div2(-b + s, -b - s, den, p0, p1);
   if (!(disc >= 0)) { p0 = PRT_INF; p1 = PRT_INF; }
   if (lin) {
-    const double root = -c / (b + (b == 0 ? 1.0 : 0.0));
+    const double root = PRT_DIV(-c, b + (b == 0 ? 1.0 : 0.0));
     p0 = root; p1 = root;
     if (near0(b)) {
       p0 = (c <= 0) ? -PRT_INF : PRT_INF;
@@ -379,9 +379,9 @@ __device__ __forceinline__ void primitive_pair(int type, const double* __restric
       const bool skew = near0(dz);
       double t;
       if (no_lane(skew)) {
-        t = -oz / dz;
+        t = PRT_DIV(-oz, dz);
       } else {
-        t = -oz / (dz + (skew ? 1.0 : 0.0));
+        t = PRT_DIV(-oz, dz + (skew ? 1.0 : 0.0));
         if (skew) t = PRT_INF;
       }
       if (!(t >= enter && t <= leave)) t = PRT_INF;
@@ -407,7 +407,7 @@ __device__ __forceinline__ void primitive_pair(int type, const double* __restric
         div2(-b + s, -b - s, den, p0, p1);
         if (!(disc >= 0)) { p0 = PRT_INF; p1 = PRT_INF; }
         if (lin) {
-          p0 = -c / (b + (near0(b) ? 1.0 : 0.0));
+          p0 = PRT_DIV(-c, b + (near0(b) ? 1.0 : 0.0));
           p1 = (dz >= 0) ? PRT_INF : -PRT_INF;
         }
       }
@@ -546,7 +546,11 @@ __device__ __forceinline__ void world_normal(PrimPtr p, double px, double py, do
 #ifdef PRT_SHARED_DIV_OBJNORMAL  // measured: the branch diamond here costs the generation kernel 20 B/lane of scratch
     div3(ax, ay, az, len, ax, ay, az);
 #else
+#ifdef PRT_FAST
+    div3(ax, ay, az, len, ax, ay, az);
+#else
     ax /= len; ay /= len; az /= len;
+#endif
 #endif
   }
   double wx = col_dot(m, 0, ax, ay, az, 0.0);
@@ -588,8 +592,8 @@ __device__ __forceinline__ double glass_index(PrimPtr p, double wavelength, bool
   if (p->mat_kind == MAT_TABLE) return table_index(p, wavelength, found);
   const auto k = p->coef;                             // materials.py:136-145
   const double w2 = wavelength * wavelength;
-  return prt_sqrt(((1 + (k[0] * w2) / (w2 - k[3])) + (k[1] * w2) / (w2 - k[4])) +
-                  (k[2] * w2) / (w2 - k[5]));
+  return prt_sqrt(((1 + PRT_DIV(k[0] * w2, w2 - k[3])) + PRT_DIV(k[1] * w2, w2 - k[4])) +
+                  PRT_DIV(k[2] * w2, w2 - k[5]));
 }
 
 // operations.reflect (operations.py:104-107): v - (2 n) (v.n), in place
@@ -616,7 +620,7 @@ __device__ __forceinline__ void refract4(double vx, double vy, double vz, double
   const double n2 = leaving ? n_global : n2_in;
   const double mx = leaving ? -nx : nx, my = leaving ? -ny : ny, mz = leaving ? -nz : nz,
                mw = leaving ? -nw : nw;
-  const double r = n1 / n2;
+  const double r = PRT_DIV(n1, n2);
   const double cos1 = leaving ? cos_p : cos_n;
   const double radicand = 1 - (r * r) * (1 - cos1 * cos1);
   const double cos2 = prt_sqrt_clamped(radicand);  // (only looked at when radicand > 0)
@@ -631,7 +635,7 @@ __device__ __forceinline__ void refract4(double vx, double vy, double vz, double
   const double ulen = norm4(ux, uy, uz, uw);
   div3(ux, uy, uz, ulen, ox, oy, oz);
   ow = uw;  // (+-0) / ulen = +-0 for the finite positive ulen of a non-degenerate ray
-  if (uw != 0.0 || !(ulen > 0.0 && ulen < PRT_INF)) ow = uw / ulen;
+  if (uw != 0.0 || !(ulen > 0.0 && ulen < PRT_INF)) ow = PRT_DIV(uw, ulen);
   index_out = (radicand > 0) ? n2 : n1;
 }
 
@@ -666,7 +670,7 @@ __device__ __forceinline__ int shade(PrimPtr p, double px, double py, double pz,
   double vx = tx, vy = ty, vz = tz, vw = dw;  // dw == 0: (+-0) / |d| = +-0
   if (dw != 0.0) {
     const double len = norm4(dx, dy, dz, dw);
-    vx = dx / len; vy = dy / len; vz = dz / len; vw = dw / len;
+    vx = PRT_DIV(dx, len); vy = PRT_DIV(dy, len); vz = PRT_DIV(dz, len); vw = PRT_DIV(dw, len);
   }
   refract4(vx, vy, vz, vw, nx, ny, nz, nw, index, n_mat, 1.0, dx, dy, dz, dw, index);
   return found ? 0 : -6;  // PRT_ERR_WAVELENGTH

@@ -253,3 +253,88 @@ extern "C" int prt_frame_finish(int device, const double* sums, const double* pi
   HIP_TRY(hipGetLastError());
   return PRT_OK;
 }
+
+// ---- mean squares of one quantity of the frame (examples/lens_design.ipynb cells 20, 28, 32) ------------------
+// The notebook's merit functions are all `np.mean(np.square(f(rows) - c))` over the rows of the last generation
+// (cell 20: f = sin(y_tilt), c = sin(angle) -- the coma metric; cells 28 / 32: f = the axis intercept, c = the design
+// focus).  One pass: per group [0] rows counted  [1] sum of v  [2] sum of v^2, v = f(quantity) - about, over the rows
+// that pass the surface / generation filter and whose v is finite (a ray parallel to the axis has no intercept:
+// pandas' mean skips the NaN).  quantity: a frame column (PRT_COL_*, 0..14) or PRT_FRAME_AXIS_INTERCEPT (15) =
+// x0 - x_tilt y0 / y_tilt; transform: 0 none, 1 sin (numpy's, libm-accurate: the device's sin()).
+enum { FRAME_AXIS_INTERCEPT = 15, FRAME_MS_STATS = 3 };
+__global__ void __launch_bounds__(PRT_BLOCK)
+k_frame_mean_square(const double* __restrict__ rows, int64_t ld, int64_t n_rows, double surface, double generation,
+                    double rays_per_source, int n_groups, int quantity, int transform, double about,
+                    double* __restrict__ out) {
+  const bool any_surface = surface != surface, any_generation = generation != generation;  // NaN = no filter
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (PRT_BLOCK / 64) + (threadIdx.x >> 6);
+  const int64_t first = wave * kFrameRowsPerWave;
+  const int64_t last = first + kFrameRowsPerWave < n_rows ? first + kFrameRowsPerWave : n_rows;
+  double acc[FRAME_MS_STATS] = {0, 0, 0};
+  int current = -1;
+  auto flush = [&](int group) {
+#pragma unroll
+    for (int k = 0; k < FRAME_MS_STATS; ++k) {
+      double v = acc[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0 && v != 0.0) atomicAdd(out + (size_t)group * FRAME_MS_STATS + k, v);
+      acc[k] = 0.0;
+    }
+  };
+  for (int64_t base = first; base < last; base += 64) {
+    const int64_t j = base + lane;
+    int group = -1;
+    double v = 0.0;
+    if (j < last && (any_surface || rows[PRT_COL_SURFACE * ld + j] == surface) &&
+        (any_generation || rows[PRT_COL_GENERATION * ld + j] == generation)) {
+      group = 0;
+      if (rays_per_source > 0) {
+        const double g = floor(rows[PRT_COL_ID * ld + j] / rays_per_source);  // _pyrayt.py:352
+        group = (g >= 0 && g < (double)n_groups) ? (int)g : -1;
+      }
+      double q = quantity == FRAME_AXIS_INTERCEPT
+                     ? rows[PRT_COL_X0 * ld + j] - rows[PRT_COL_XTILT * ld + j] * rows[PRT_COL_Y0 * ld + j] / rows[PRT_COL_YTILT * ld + j]
+                     : rows[(int64_t)quantity * ld + j];
+      if (transform == 1) q = sin(q);
+      v = q - about;
+      if (!(v == v && fabs(v) < PRT_INF)) group = -1;
+    }
+    unsigned long long pending = __ballot(group >= 0);
+    while (pending) {  // one turn per group present in the slice: almost always exactly one
+      const int leader = __ffsll((long long)pending) - 1;
+      const int g = __shfl(group, leader);
+      if (g != current) {
+        if (current >= 0) flush(current);
+        current = g;
+      }
+      const bool take = group == g;
+      if (take) { acc[0] += 1.0; acc[1] += v; acc[2] += v * v; }
+      pending &= ~__ballot(take);
+    }
+  }
+  if (current >= 0) flush(current);
+}
+
+// out: (n_groups, 3) float64 on the device, overwritten: rows counted, sum v, sum v^2 (additive over any partition
+// of the rows: a sharded frame adds them across ranks and divides afterwards).
+extern "C" int prt_frame_mean_square(int device, const double* rows, int64_t ld, int64_t n_rows, double surface,
+                                     double generation, double rays_per_source, int n_groups, int quantity,
+                                     int transform, double about, double* out, void* stream) {
+  if (n_rows < 0 || ld < n_rows || n_groups < 1 || !out || (n_rows && !rows)) return fail(PRT_ERR_ARG, "bad buffers");
+  if (!(rays_per_source > 0) && n_groups != 1) return fail(PRT_ERR_ARG, "one group without rays_per_source");
+  if (quantity < 0 || quantity > FRAME_AXIS_INTERCEPT || transform < 0 || transform > 1)
+    return fail(PRT_ERR_ARG, "quantity: a frame column 0..14 or 15 (axis intercept); transform: 0 none, 1 sin");
+  int rc = ops_device(device);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_groups * FRAME_MS_STATS * sizeof(double), st));
+  if (n_rows == 0) return PRT_OK;
+  const int64_t waves = (n_rows + kFrameRowsPerWave - 1) / kFrameRowsPerWave;
+  const unsigned grid = (unsigned)((waves + PRT_BLOCK / 64 - 1) / (PRT_BLOCK / 64));
+  hipLaunchKernelGGL(k_frame_mean_square, dim3(grid), dim3(PRT_BLOCK), 0, st, rows, ld, n_rows, surface, generation,
+                     rays_per_source, n_groups, quantity, transform, about, out);
+  HIP_TRY(hipGetLastError());
+  return PRT_OK;
+}

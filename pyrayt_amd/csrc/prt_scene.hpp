@@ -1045,6 +1045,10 @@ extern "C" int prt_scene_set_index_tables(prt_scene* s, const int64_t* ranges, i
         return fail(PRT_ERR_ARG, "index table wavelengths must be strictly ascending (and not NaN) inside a material's range");
   }
   s->table_ranges.assign(ranges, ranges + 2 * (size_t)n_mats);
+  // (only the ranges checked above are kept: a slot that is not a table now holds (0, 0), so a later
+  // prt_scene_update that turns it into one finds an empty table -- every look-up misses -- not an unchecked range)
+  for (int m = 0; m < n_mats; ++m)
+    if (s->mats[m].kind != PRT_MAT_TABLE) s->table_ranges[2 * m] = s->table_ranges[2 * m + 1] = 0;
   s->table_wavelengths.assign(wavelengths, wavelengths + total);
   s->table_indices.assign(indices, indices + total);
   for (size_t d = 0; d < s->per_device.size(); ++d) {

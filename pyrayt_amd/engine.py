@@ -66,6 +66,7 @@ ERR_ROWS_CAP = -4
 ERR_UNTRACABLE = -5
 ERR_WAVELENGTH = -6
 PRT_VERSION = 200  # include/prt.h: the ABI this binding was written for
+TABLE_KEEP_FACTOR, TABLE_KEEP_MIN = 4, 64  # index tables keep earlier wavelengths up to this multiple of a ray set's own
 UNIQUE_CAP = 4096  # distinct wavelengths looked for on the device before the host sorts the whole row
 
 
@@ -140,6 +141,7 @@ def _declare(lib):
         "prt_frame_stats_sharded": (c_int, [c_p, c_p, c_i64, c_i64, c_d, c_d, c_d, c_int, c_p, c_p, c_p]),
         "prt_frame_pivots": (c_int, [c_int, c_p, c_int, c_p, c_p]),
         "prt_frame_finish": (c_int, [c_int, c_p, c_p, c_int, c_p, c_p]),
+        "prt_frame_mean_square": (c_int, [c_int, c_p, c_i64, c_i64, c_d, c_d, c_d, c_int, c_int, c_int, c_d, c_p, c_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = the library does not match prt.h
@@ -160,7 +162,7 @@ EXPORTED_SYMBOLS = (
     "prt_primitive_normal", "prt_comm_unique_id", "prt_comm_create", "prt_comm_destroy",
     "prt_allgather_counts", "prt_allgather_workspace_bytes", "prt_allgather_rows",
     "prt_place_workspace_bytes", "prt_place_rows", "prt_frame_reduce", "prt_frame_stats_workspace_bytes",
-    "prt_frame_stats", "prt_frame_stats_sharded", "prt_frame_pivots", "prt_frame_finish",
+    "prt_frame_stats", "prt_frame_stats_sharded", "prt_frame_pivots", "prt_frame_finish", "prt_frame_mean_square",
 )
 
 
@@ -173,13 +175,19 @@ def library():
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (or `make -C pyrayt_amd/csrc`). pyrayt_amd has no CPU fallback."
             )
-        lib = _declare(ctypes.CDLL(LIB_PATH))
+        lib = ctypes.CDLL(LIB_PATH)
         # (the ABI changed incompatibly between versions -- argument lists grew, output blocks widened: a stale
-        # libprt_hip.so must fail here, loudly, not corrupt memory later)
-        if lib.prt_version() != PRT_VERSION:
-            raise EngineUnavailable(f"{LIB_PATH} is ABI version {lib.prt_version()}, this binding needs {PRT_VERSION}: "
+        # libprt_hip.so must fail here, loudly and before its missing symbols are asked for, not corrupt memory later)
+        try:
+            lib.prt_version.restype = ctypes.c_int
+            lib.prt_version.argtypes = []
+            found = lib.prt_version()
+        except AttributeError:
+            found = None
+        if found != PRT_VERSION:
+            raise EngineUnavailable(f"{LIB_PATH} is ABI version {found}, this binding needs {PRT_VERSION}: "
                                     "rebuild it (make -C pyrayt_amd/csrc)")
-        _lib = lib
+        _lib = _declare(lib)
     return _lib
 
 
@@ -270,8 +278,10 @@ class DeviceScene:
         if rc == 1:
             return False
         _check(rc)
-        if [slot for slot, _ in getattr(snapshot, "table_materials", ())] != [slot for slot, _ in self._table_materials]:
-            self._tables = None  # (other materials hold tables now: they are set again before the next trace)
+        if getattr(snapshot, "table_materials", ()) or self._table_materials:
+            # (the snapshot may hold another glass in the same slot, or the same glass with other coefficients: the
+            # tables are evaluated again -- on the wavelengths they held -- before the next trace)
+            self._stale_tables, self._tables = self._tables, None
         self.snapshot = snapshot
         return True
 
@@ -289,9 +299,15 @@ class DeviceScene:
         from . import materials as matl
 
         wanted = np.asarray(wavelengths, dtype=float).ravel()
-        wanted = wanted[~np.isnan(wanted)]  # (a NaN wavelength is served by prt_material.coef[3])
+        wanted = np.unique(wanted[~np.isnan(wanted)])  # (a NaN wavelength is served by prt_material.coef[3])
         if self._tables is not None:
-            wanted = np.concatenate([self._tables[0], wanted])
+            held = self._tables[0]
+            # The tables keep what they held -- a loop over a few ray sets then settles on their union -- but not
+            # without bound: a loop over ever new spectra would grow them, and with them every call's index_at
+            # evaluation, upload and the kernels' binary search, by one ray set per trace.  Beyond a few times what
+            # this ray set needs the tables start again from it (a later miss is PRT_ERR_WAVELENGTH: rescan, repeat).
+            if len(held) <= max(TABLE_KEEP_FACTOR * len(wanted), TABLE_KEEP_MIN):
+                wanted = np.concatenate([held, wanted])
         lam = np.unique(wanted)  # ascending, by value
         indices = [matl.table_indices(material, lam) for _, material in mats]
         if self._tables is not None and np.array_equal(lam, self._tables[0]) and all(
@@ -306,6 +322,20 @@ class DeviceScene:
         _check(library().prt_scene_set_index_tables(self.handle, ranges.ctypes.data, n_mats, all_lam.ctypes.data,
                                                     all_idx.ctypes.data, len(all_lam)))
         self._tables = (lam, indices)
+
+    def _refresh_tables(self, rays):
+        """Before a trace of a scene with user-defined glasses: a first trace scans the ray set's wavelengths; every
+        later one evaluates ``index_at`` again on the wavelengths the tables hold (a handful of values: cheap) and
+        uploads them only if a glass answers differently now -- the caller may have changed its coefficients, or
+        put another glass into the slot (``update``), since the last trace."""
+        if not self._table_materials:
+            return
+        if self._tables is not None:
+            self.ensure_tables(self._tables[0])
+            return
+        stale = getattr(self, "_stale_tables", None)  # (after update(): what the tables held is still what the rays carry)
+        self._stale_tables = None
+        self.ensure_tables(stale[0] if stale is not None else self.distinct_wavelengths(rays))
 
     def distinct_wavelengths(self, rays):
         """The distinct wavelengths of a device (13, n) ray set, as a host array: found on the device
@@ -401,8 +431,7 @@ class DeviceScene:
         if self._host_surfaces:
             raise TypeError("this scene has a material with a user-defined trace(): use trace_stepwise() "
                             "(RayTracer.trace() does)")
-        if self._table_materials and self._tables is None:
-            self.ensure_tables(self.distinct_wavelengths(rays))  # a user-defined glass, first trace
+        self._refresh_tables(rays)
         rescanned = False
         while True:
             rows = out if out is not None else torch.empty((RECORD_COLS, cap), dtype=torch.float64, device=dev)
@@ -450,6 +479,8 @@ class DeviceScene:
         # ray sets): the call's arguments are as they were -- checking and converting them again costs as much as
         # the call itself (about 15 us, which is most of a 125k-ray step).  A handful of entries per ticket, keyed
         # by the tensor objects and validated by their addresses (an id can be reused, an address in use cannot).
+        if self._table_materials:  # (user-defined glasses: a glass changed since the last trace is evaluated again)
+            self._refresh_tables(rays)
         caches = self._begin_cache if hasattr(self, "_begin_cache") else None
         if caches is None or not isinstance(caches[ticket], dict):
             if caches is None:
@@ -719,8 +750,7 @@ class DeviceScene:
         n, dev, limit = rays.shape[1], rays.device, int(generation_limit)
         if n == 0 or limit <= 0:
             return torch.empty((RECORD_COLS, 0), dtype=torch.float64, device=dev), []
-        if self._table_materials and self._tables is None:
-            self.ensure_tables(self.distinct_wavelengths(rays))
+        self._refresh_tables(rays)
         rows = torch.empty((RECORD_COLS, n * limit), dtype=torch.float64, device=dev)
         current = rays if rays.stride(1) == 1 else rays.contiguous()
         counts, base = [], 0
@@ -906,6 +936,8 @@ class TraceBatch:
         if len(self.ray_sets) == 0:
             return 0
         torch = _torch()
+        if self.scene._table_materials:  # (user-defined glasses: see DeviceScene._refresh_tables)
+            self.scene._refresh_tables(self.ray_sets[0])
         current = torch.cuda.current_stream(self.device)
         for stream in self.streams:  # whatever produced the ray sets
             stream.wait_stream(current)

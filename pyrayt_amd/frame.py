@@ -50,6 +50,24 @@ class DeviceFrame:
                                [0] * g + [self.rows_per_generation[g]])
         return self.where(generation=g)
 
+    def last_generation(self):
+        """Rows of the highest generation in the frame -- the notebook's way to say "the rays that reached the imager"
+        when the imager is not at hand (``examples/lens_design.ipynb`` cells 12, 15, 20:
+        ``results.loc[results['generation'] == np.max(results['generation'])]``).  Rows are generation-major, so
+        this is the frame's last slice: no kernel, no copy."""
+        number = self.last_generation_number()
+        return self if number is None else self.generation(number)
+
+    def last_generation_number(self):
+        """The highest generation that recorded rows (None for an empty frame)."""
+        counts = self.rows_per_generation
+        if counts:
+            working = [g for g, k in enumerate(counts) if k]
+            return working[-1] if working else None
+        if len(self) == 0:
+            return None
+        return int(float(self["generation"].max()))
+
     def where(self, **equals):
         """Rows whose named columns equal the given values, e.g. where(surface=6, generation=2)."""
         mask = None
@@ -185,6 +203,68 @@ class DeviceFrame:
         engine._check(engine.library().prt_frame_finish(sums.device.index or 0, sums.data_ptr(), pivots.data_ptr(), n_groups,
                                                         out.data_ptr(), engine._stream_ptr(torch, sums.device)))
         return out
+
+    def mean_square(self, quantity, about=0.0, transform=None, surface=None, generation=None, rays_per_source=None,
+                    n_groups=None, group=None):
+        """``np.mean(np.square(f(rows) - about))`` -- the shape of every merit function in the lens-design notebook --
+        as one HIP reduction over the column block (``prt_frame_mean_square``), nothing but the result crossing PCIe.
+
+        quantity: a column name, or ``"axis_intercept"`` for ``x0 - x_tilt * y0 / y_tilt`` (the notebook's paraxial
+        focus, cells 12 / 15); transform: None or ``"sin"``; surface / generation filter the rows as in
+        ``group_stats`` (``generation="last"``: the highest generation, cells 12 / 15 / 20).  Examples:
+        the coma metric of cell 20, ``np.mean(np.square(np.sin(ray_set['y_tilt']) - np.sin(angle)))``, is
+        ``frame.mean_square("y_tilt", about=np.sin(angle), transform="sin", generation="last")``; the focus error
+        of cells 28 / 32 is ``frame.mean_square("axis_intercept", about=system_focus, generation="last")``.
+        Rows whose value is not finite are skipped, like pandas' mean skips NaN.
+
+        Returns a float, or with ``rays_per_source`` a DataFrame indexed by source id (``count``, ``mean`` of
+        f(rows) - about, ``mean_square``).  ``group`` (a ``torch.distributed`` group): this frame is one rank's
+        share of a sharded trace; the three sums per source are added across the ranks before dividing."""
+        import torch
+
+        from . import engine
+
+        column = 15 if quantity == "axis_intercept" else _INDEX[quantity]
+        how = {None: 0, "sin": 1}[transform]
+        if generation == "last":
+            generation = self.last_generation_number()
+            if group is not None:
+                generation = int(_all_reduce_max(-1.0 if generation is None else float(generation), group, None,
+                                                 self.rows.device))
+            if generation is None or generation < 0:
+                generation = 0
+        if rays_per_source:
+            if n_groups is None:
+                top = float(self["id"].max()) if len(self) else -1.0
+                if group is not None:
+                    top = _all_reduce_max(top, group, None, self.rows.device)
+                n_groups = max(1, int(top // rays_per_source) + 1)
+        else:
+            n_groups = 1
+        rows = self.rows if self.rows.stride(1) == 1 else self.rows.contiguous()
+        dev = rows.device
+        sums = torch.empty((n_groups, 3), dtype=torch.float64, device=dev)
+        nan = float("nan")
+        engine._check(engine.library().prt_frame_mean_square(
+            dev.index or 0, rows.data_ptr(), max(rows.stride(0), 1), rows.shape[1],
+            nan if surface is None else float(surface), nan if generation is None else float(generation),
+            float(rays_per_source or 0), n_groups, column, how, float(about), sums.data_ptr(),
+            engine._stream_ptr(torch, dev)))
+        if group is not None:
+            sums = _all_reduce_sum(sums, group)
+        sums = sums.cpu().numpy()
+        with np.errstate(invalid="ignore", divide="ignore"):
+            mean, mean_square = sums[:, 1] / sums[:, 0], sums[:, 2] / sums[:, 0]
+        if not rays_per_source:
+            return float(mean_square[0])
+        frame = pd.DataFrame({"count": sums[:, 0].astype(np.int64), "mean": mean, "mean_square": mean_square})
+        frame.index.name = "source_id"
+        return frame
+
+    def axis_intercept(self):
+        """x where each ray's line crosses the optical (x) axis in the xy plane, from the segment's start point as the
+        notebook writes it (cells 12, 15): ``x0 - x_tilt * y0 / y_tilt``."""
+        return self["x0"] - self["x_tilt"] * self["y0"] / self["y_tilt"]
 
     def spot(self, plane=("y1", "z1")):
         """(centroid, rms radius) of the end points in a transverse plane."""

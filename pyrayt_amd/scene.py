@@ -64,6 +64,12 @@ class SceneSnapshot:
                     coef = material.packed_coefficients()
                 elif kind == matl.TABLE:
                     self.table_materials.append((len(mats), material))
+                    # a NaN wavelength has no place in an ascending table: its index travels in coef[3]
+                    # (include/prt.h) -- what upstream's index_at(NaN) answers, NaN if the glass will not say
+                    try:
+                        coef[3] = float(matl.table_indices(material, np.array([np.nan]))[0])
+                    except Exception:  # noqa: BLE001
+                        coef[3] = float("nan")
                 self._material_slots[key] = len(mats)
                 mats.append((kind, 0, coef))
             return self._material_slots[key]

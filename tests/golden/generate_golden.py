@@ -424,11 +424,14 @@ def source_vectors():
     print(f"sources              -> {os.path.basename(path)} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
-def config2_summary(n=1_000_000):
+def config2_summary(n=1_000_000, seed=1234, sample=4096):
     """Summary (not the 360 MB frame) of the north-star run: rows per generation x surface,
-    ids of the rays that skip the second lens surface, column checksums."""
+    ids of the rays that skip the second lens surface, column checksums.
+    seed 1234 is BASELINE config 2 itself (config2_1m_summary.npz); bench.py rotates its timed steps through the
+    ray sets of seeds 1234 ... 1237 and checks the rows of EVERY one of them against the reference's summary of it
+    (config2_1m_summary_seed<seed>.npz, a smaller point-wise sample each)."""
     reset_ids()
-    components, rays = scenes.config2(API, n)
+    components, rays = scenes.config2(API, n, seed=seed)
     tracer = pyrayt.RayTracer(_PresetSource(rays), components, rays_per_source=n, generation_limit=10)
     frame = tracer.trace().to_numpy(dtype=float)
     gens = frame[:, 0].astype(np.int64)
@@ -442,12 +445,12 @@ def config2_summary(n=1_000_000):
         "column_sums": frame.sum(axis=0), "column_abs_sums": np.abs(frame).sum(axis=0),
         "surface_checksum": np.int64(int((surf * (gens + 1)).sum())),
         # a deterministic 4096-row sample for point-wise comparison
-        "sample_rows": frame[:: max(1, frame.shape[0] // 4096)][:4096],
-        "sample_index": np.arange(0, frame.shape[0], max(1, frame.shape[0] // 4096))[:4096],
+        "sample_rows": frame[:: max(1, frame.shape[0] // sample)][:sample],
+        "sample_index": np.arange(0, frame.shape[0], max(1, frame.shape[0] // sample))[:sample],
     }
-    path = os.path.join(HERE, "config2_1m_summary.npz")
+    path = os.path.join(HERE, "config2_1m_summary.npz" if seed == 1234 else f"config2_1m_summary_seed{seed}.npz")
     np.savez_compressed(path, **out)
-    print(f"config2 1M summary   rows={frame.shape[0]} q5={q5.tolist()} -> {os.path.basename(path)}")
+    print(f"config2 1M summary   seed={seed} rows={frame.shape[0]} q5={q5.tolist()} -> {os.path.basename(path)}")
 
 
 def raw_primitive_vectors():
@@ -664,7 +667,7 @@ def render_ray_vectors(seeds=range(12)):
 
 def main():
     which = set(sys.argv[1:]) or {"scenes", "primitives", "csg", "shading", "sources", "summary", "render", "operations", "raw",
-                                  "adversarial", "stale", "render_rays", "custom"}
+                                  "adversarial", "stale", "render_rays", "custom", "summary_seeds"}
     print(f"numpy {np.__version__} pandas {pd.__version__} (reference locks numpy 1.20.2 / pandas 1.2.4)")
     if "scenes" in which:
         scene_fixture("config1", 100, 1000)
@@ -696,6 +699,9 @@ def main():
         source_vectors()
     if "summary" in which:
         config2_summary()
+    if "summary_seeds" in which:  # the other ray sets of bench.py's rotation
+        for seed in (1235, 1236, 1237):
+            config2_summary(seed=seed, sample=512)
     if "render" in which:
         render_vectors()
     if "render_rays" in which:

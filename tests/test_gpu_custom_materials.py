@@ -133,6 +133,84 @@ def test_a_glass_whose_coefficients_change_between_traces_is_picked_up():
     assert np.array_equal(tracer.trace().to_numpy(dtype=float), first)
 
 
+def test_a_changed_glass_is_picked_up_on_the_direct_scene_paths_too():
+    """DeviceScene.trace / trace_begin / TraceBatch / update(): index_at is evaluated again before every trace (on
+    the wavelengths the tables hold), so a glass whose coefficients changed, or another glass put into the same
+    slot with update(), never refracts with the old indices."""
+    parts, rays = build("custom_cauchy")
+    glass = parts[0].surface_ids[0][1].material
+    ds = engine.DeviceScene(SceneSnapshot(parts))
+    dev = torch.from_numpy(rays).cuda()
+
+    def inside_index(rows):
+        got = rows.cpu().numpy().T
+        inside = got[got[:, 0] == 1]
+        return inside[:, 3], inside[:, 2]
+
+    rows, _ = ds.trace(dev, 10)
+    first = rows.cpu().numpy().T.copy()
+    glass.b = 0.009  # mutated in place, no update()
+    index, lam = inside_index(ds.trace(dev, 10)[0])
+    assert np.allclose(index, 1.5046 + 0.009 / lam ** 2, rtol=0, atol=1e-12)
+    glass.b = 0.011
+    out = torch.empty((15, rays.shape[1] * 10), dtype=torch.float64, device="cuda")
+    ds.trace_begin(0, dev, 10, out)
+    index, lam = inside_index(ds.trace_end(0)[0])
+    assert np.allclose(index, 1.5046 + 0.011 / lam ** 2, rtol=0, atol=1e-12)
+    glass.b = 0.013
+    batch = engine.TraceBatch(ds, [dev, dev], 10, depth=2)
+    batch.run()
+    index, lam = inside_index(batch.result(-1)[0])
+    assert np.allclose(index, 1.5046 + 0.013 / lam ** 2, rtol=0, atol=1e-12)
+    # update() with a snapshot of the same parts whose glass changed again
+    glass.b = 0.0042
+    assert ds.update(SceneSnapshot(parts)) is True
+    assert np.array_equal(ds.trace(dev, 10)[0].cpu().numpy().T, first)
+    ds.close()
+
+
+def test_index_tables_do_not_grow_without_bound():
+    """A loop over ever new spectra: the tables keep earlier wavelengths only up to a few times what a ray set needs."""
+    parts, rays = build("custom_cauchy")
+    ds = engine.DeviceScene(SceneSnapshot(parts))
+    rng = np.random.default_rng(5)
+    for _ in range(6):
+        other = rays.copy()
+        other[10] = rng.uniform(0.45, 0.7, size=64)[np.arange(other.shape[1]) % 64]
+        rows, _ = ds.trace(torch.from_numpy(other).cuda(), 10)
+        index, lam = rows.cpu().numpy()[3], rows.cpu().numpy()[2]
+        inside = rows.cpu().numpy()[0] == 1
+        assert np.allclose(index[inside], 1.5046 + 0.0042 / lam[inside] ** 2, rtol=0, atol=1e-12)
+    assert len(ds._tables[0]) <= (engine.TABLE_KEEP_FACTOR + 1) * 64 + 8
+    ds.close()
+
+
+def test_a_nan_wavelength_gets_what_index_at_says_about_it():
+    """pyrayt/materials.py:72-73 calls index_at on the wavelength row as it is: a ray with a NaN wavelength is
+    refracted with index_at(NaN) -- NaN for a dispersion formula, a number for a glass that ignores the wavelength --
+    never with a made-up value (the table cannot hold a NaN key: the answer travels in prt_material.coef[3])."""
+    CountedObject.reset_ids()
+    api = scenes.product_api()
+    user = scenes.user_materials(api)
+
+    class FlatGlass(api.materials.Glass):  # index_at without the wavelength in it: index_at(NaN) is a number
+        def index_at(self, wavelength):
+            return np.full(np.shape(wavelength), 1.7)
+
+    for glass, want_nan in ((user.CauchyGlass(1.5, 0.004), float("nan")), (FlatGlass(), 1.7)):
+        surf = api.cg.Sphere(1.0, material=glass)
+        snap = SceneSnapshot([surf])
+        got_nan = snap.materials["coef"][snap.table_materials[0][0]][3]
+        assert (np.isnan(got_nan) and np.isnan(want_nan)) or got_nan == want_nan
+        rs = RaySet(4)
+        rs.rays[0, :3] = np.array([[-1.0, 0, 0]] * 4).T
+        rs.rays[1, 0] = 1.0
+        rs.wavelength = np.array([0.5, np.nan, 0.6, np.nan])
+        glass.trace(surf, rs)
+        want = np.asarray(glass.index_at(np.array([0.5, np.nan, 0.6, np.nan])), dtype=float)
+        assert np.array_equal(np.asarray(rs.index), want, equal_nan=True)
+
+
 def test_user_glass_from_device_sources_and_sharded_ids():
     """Device-side sources: the tables come from the sources' wavelengths, no ray ever visits the host."""
     CountedObject.reset_ids()
