@@ -130,23 +130,6 @@ struct Ray8 {
 // of the ray and is written out at every site: holding its value across the hit phase instead costs the
 // generation kernel its register allocation -- the lane mask lives in SGPRs, of which the kernel has none
 // to spare -- while the compiler is free to share it between neighbouring sites as it is.)
-#ifndef PRT_CHAIN_SHARED
-#define PRT_CHAIN_SHARED 0     // chain steps: leaves that share the linear part of M^-1 share its partial sums (A/B: 1; costs the
-                               // generation kernel its register allocation: 12-28 B of scratch per lane)
-#endif
-#ifndef PRT_GRAZE_MARGIN
-#define PRT_GRAZE_MARGIN 0     // implied cull boxes: a grazing axis takes the exact test only near a face of the box (A/B: 1;
-                               // measured: config 3 -1.5 %, config 2 +0.8 % with 20 B of scratch per lane: not adopted)
-#endif
-#ifndef PRT_STEP_BY_POINTER
-#define PRT_STEP_BY_POINTER 1
-#endif
-#ifndef PRT_SEGMENT_CULL
-#define PRT_SEGMENT_CULL 1     // component cull steps: the segment-box test in front of may_reach (A/B: 0)
-#endif
-#ifndef PRT_CHAIN_INTERVALS
-#define PRT_CHAIN_INTERVALS 1  // chain steps: INTERSECT-only chains as interval intersections (A/B: 0)
-#endif
 #define kWellFormedLen2Lo 0.81
 __device__ __forceinline__ bool well_formed(const Ray8& r) {
   if (!r.gated) return false;
@@ -163,11 +146,7 @@ __device__ __forceinline__ bool well_formed(const Ray8& r) {
 // (checked by the scene compiler), so that is (t, list index).  In a list-order program the second clause
 // never fires.
 __device__ __forceinline__ bool beats(const Ray8& ray, double t, int prim, double best_t, int best_prim) {
-#ifdef PRT_NO_LEX  // experiment: what the second clause costs (results wrong for ties in reordered programs)
-  return t < best_t;
-#else
   return t < best_t || (ray.lex && t == best_t && prim < best_prim);
-#endif
 }
 // PRT_TRACE_COUNT_PATHS: one atomic per wave and site; `paths` is null (a compile-time constant in the
 // fused kernel, which carries none of this) unless the trace asked for the counts
@@ -232,11 +211,7 @@ __device__ __forceinline__ void div2(double n0, double n1, double d, double& q0,
 }
 __device__ __forceinline__ void div3(double n0, double n1, double n2, double d, double& q0, double& q1,
                                      double& q2) {
-#if defined(PRT_PLAIN_DIV) || defined(PRT_PLAIN_DIV3)
-  q0 = n0 / d; q1 = n1 / d; q2 = n2 / d;
-#else
   prt_div3(n0, n1, n2, d, q0, q1, q2);
-#endif
 }
 
 // ---- quadratic with the reference's degenerate branches (operations.py:28-63) ----------------
@@ -245,12 +220,8 @@ __device__ __forceinline__ void div3(double n0, double n1, double n2, double d, 
 // -- `x + (flag ? 1 : 0)`, `if (flag) v = ...` -- a wave without such a lane runs a body without it:
 // x + 0.0 is x for every x the flag leaves alone (it is set for +-0), the replacement is not taken.)
 __device__ __forceinline__ bool no_lane(bool flag) {
-#if PRT_OPT & 2
-  return __ballot(flag) == 0ull;
-#else
   (void)flag;
   return false;
-#endif
 }
 __device__ __forceinline__ void binomial_root(double a, double b, double c, double& p0, double& p1) {
   const double disc = b * b - 4 * a * c;
@@ -543,15 +514,7 @@ __device__ __forceinline__ void world_normal(PrimPtr p, double px, double py, do
   }
   if (normalise) {
     const double len = norm4(ax, ay, az, 0.0);
-#ifdef PRT_SHARED_DIV_OBJNORMAL  // measured: the branch diamond here costs the generation kernel 20 B/lane of scratch
-    div3(ax, ay, az, len, ax, ay, az);
-#else
-#ifdef PRT_FAST
-    div3(ax, ay, az, len, ax, ay, az);
-#else
     ax /= len; ay /= len; az /= len;
-#endif
-#endif
   }
   double wx = col_dot(m, 0, ax, ay, az, 0.0);
   double wy = col_dot(m, 1, ax, ay, az, 0.0);
@@ -872,9 +835,7 @@ __device__ __forceinline__ bool implied_touch(const double* __restrict__ aabb, c
         const double e = 1e-6 * (((1.0 + fabs(aabb[4])) + fabs(aabb[5])) + fabs(ray.oz));
         near_face = near_face || (!pz && az < 1e-4 && !(fmin(at_lo, at_hi) >= aabb[4] + e && fmax(at_lo, at_hi) <= aabb[5] - e));
       }
-#if !PRT_GRAZE_MARGIN
       near_face = grazing;  // (A/B: every grazing axis takes the exact test, the round-3 rule)
-#endif
       const bool exact = near_face && any && robust;  // (a NaN anywhere: not clear of the face, exact test)
       if (__ballot(exact) != 0ull) {
         count_paths(ray.paths, 3, exact);
@@ -1216,16 +1177,7 @@ __device__ __forceinline__ void chain_candidate(const DevChain* __restrict__ ch,
 __device__ __forceinline__ void chain_step(const DevChain* __restrict__ ch, int shape, const Ray8& ray,
                                            double& best_t, int& best_prim) {
   switch (shape) {  // wave-uniform
-#ifdef PRT_FIXED_SSC  // experiment: the INTERSECT / INTERSECT / implied form of the lens chain as its own body
-    case CHAIN_SSC:
-      if (ch->op1 == CSG_INTERSECT && ch->op2 == CSG_INTERSECT && ch->implied1 && ch->implied2)
-        chain_candidate<PRIM_SPHERE, PRIM_SPHERE, PRIM_CYLINDER, true>(ch, ray, best_t, best_prim);
-      else
-        chain_candidate<PRIM_SPHERE, PRIM_SPHERE, PRIM_CYLINDER>(ch, ray, best_t, best_prim);
-      break;
-#else
     case CHAIN_SSC: chain_candidate<PRIM_SPHERE, PRIM_SPHERE, PRIM_CYLINDER>(ch, ray, best_t, best_prim); break;
-#endif
     case CHAIN_SSQ: chain_candidate<PRIM_SPHERE, PRIM_SPHERE, PRIM_CUBE>(ch, ray, best_t, best_prim); break;
     case CHAIN_CSS: chain_candidate<PRIM_CYLINDER, PRIM_SPHERE, PRIM_SPHERE>(ch, ray, best_t, best_prim); break;
     case CHAIN_QSS: chain_candidate<PRIM_CUBE, PRIM_SPHERE, PRIM_SPHERE>(ch, ray, best_t, best_prim); break;
@@ -1251,7 +1203,6 @@ __device__ __forceinline__ void run_step(const DevInstr* in, const Ray8& ray, co
   if (kind == I_LEAF) {
     const int p = in->a0;
     double t0, t1;
-#ifndef PRT_NO_LEAF_SKIP
     if (in->pad[0] == 1) {
       // right leaf of an INTERSECT / DIFFERENCE node: not worth evaluating for this wave when no
       // lane's left operand (a3 mode, a4 base, a5 length) holds a positive entry
@@ -1279,12 +1230,7 @@ __device__ __forceinline__ void run_step(const DevInstr* in, const Ray8& ray, co
         return;
       }
     }
-#endif
-#if defined(PRT_ABLATE) && (PRT_ABLATE & 4)
-    t0 = ray.ox + in->data[0]; t1 = ray.dx;  // timing experiment: no primitive math
-#else
     surface_pair(in->type, in->data, in->data + 6, ray, t0, t1);
-#endif
     const int dst = in->a1;
     if (in->pad[0] == 2) {
       // the leaf is a whole component (a bare surface): its sorted pair reduces right here to the
@@ -1310,11 +1256,7 @@ __device__ __forceinline__ void run_step(const DevInstr* in, const Ray8& ray, co
     bool is_root;
     double t = PRT_INF;
     int prim = -1;
-#if defined(PRT_ABLATE) && (PRT_ABLATE & 2)
-    is_root = in->pad[0] != 0; t = ra.t0 + rb.t0; prim = ra.prim;  // timing experiment: no CSG
-#else
     csg_step(in, ray, lists, ra, rb, is_root, t, prim);
-#endif
     if (is_root && beats(ray, t, prim, best_t, best_prim)) {
       best_t = t;
       best_prim = prim;
@@ -1355,21 +1297,6 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
     rb[k] = Pair{PRT_INF, PRT_INF, -1};
     if (ray[k].paths != nullptr) count_paths(ray[k].paths, 1, !well_formed(ray[k]));
   }
-#ifdef PRT_SPECIAL_C2
-  // EXPERIMENT (timing of a fully specialised program, results valid for BASELINE config 2 only): the
-  // program [chain S,S,C with INTERSECT nodes and implied boxes][bare plane] as straight-line code
-  if (!RENDER && R == 1 && !CULL) {
-    const DevChain* ch = reinterpret_cast<const DevChain*>(code);
-    const DevInstr* leaf = code + CHAIN_SLOTS;
-    double p0, p1;
-    surface_pair(PRIM_PLANE, leaf->data, leaf->data + 6, ray[0], p0, p1);
-    chain_candidate<PRIM_SPHERE, PRIM_SPHERE, PRIM_CYLINDER, true>(ch, ray[0], best_t[0], best_prim[0]);
-    const bool pos0 = p0 > 0 && p0 < PRT_INF, pos1 = p1 > 0 && p1 < PRT_INF;
-    const double t = pos0 ? p0 : (pos1 ? p1 : PRT_INF);
-    if ((pos0 || pos1) && t < best_t[0]) { best_t[0] = t; best_prim[0] = leaf->a0; }
-    return;
-  }
-#endif
   for (int pc = 0; pc < n_instr; ++pc) {
     if (!RENDER && R == 1) {  // trace programs: a whole component may be one chain record
       const int kind = code[pc].kind, shape = code[pc].a0;
@@ -1379,11 +1306,7 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
         continue;
       }
     }
-#if PRT_STEP_BY_POINTER
     const DevInstr& step = code[pc];  // fields are fetched as they are used (a whole record is 48 SGPRs at once)
-#else
-    const DevInstr step = code[pc];  // the whole record, one batch of scalar loads
-#endif
     if (CULL && RENDER && step.kind == I_BOX) {  // render programs: a component whose box the line of sight misses
       bool wanted = false;
 #pragma unroll
@@ -1404,7 +1327,6 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
         continue;
       }
       bool wanted = false;
-#if PRT_SEGMENT_CULL
       // (the coarse test first: a wave none of whose segments comes near the box is done with five instructions
       // per axis; only a wave that does come near pays for the exact one)
 #pragma unroll
@@ -1412,7 +1334,6 @@ __device__ __forceinline__ void nearest_hit_n(const DevInstr* __restrict__ code,
         wanted = wanted || !well_formed(ray[k]) || segment_meets(step.data, ray[k], best_t[k]);
       if (__ballot(wanted) == 0ull) { pc += step.a0; continue; }
       wanted = false;
-#endif
 #pragma unroll
       for (int k = 0; k < R; ++k)
         wanted = wanted || !well_formed(ray[k]) || may_reach(step.data, ray[k], best_t[k]);

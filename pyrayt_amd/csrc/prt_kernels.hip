@@ -313,7 +313,6 @@ __device__ __forceinline__ Shaded interact_compute(const SceneDev& scene, const 
   // (v_readfirstlane of the lanes still pending: the index is in an SGPR, so the compiler knows the
   // table entry is uniform and fetches it with scalar loads -- one batch for the whole record --
   // instead of per-lane vector loads that all hit the same address)
-#ifndef PRT_SCALAR_WATERFALL
   // (the table reads below are per-lane vector loads of one address -- a single L1 line per field
   // group, fetched in one batch.  The scalar-load form of this loop, kept under PRT_SCALAR_WATERFALL,
   // measured 7 % slower for the whole kernel: its reads are dependent round trips to the scalar cache.)
@@ -330,7 +329,6 @@ __device__ __forceinline__ Shaded interact_compute(const SceneDev& scene, const 
     todo &= ~__ballot(prim == cur);
   }
   return s;
-#endif
   for (bool pending = true; __ballot(pending) != 0ull;) {
     if (pending) {
       const int cur = __builtin_amdgcn_readfirstlane(prim);
@@ -996,13 +994,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   } else {
   if (wave == 0) {
     unsigned e_live, e_carry;
-#if defined(PRT_ABLATE) && (PRT_ABLATE & 16)
-    bool ok = true;  // timing experiment: no look-back (rows land uncompacted, results invalid)
-    e_live = (unsigned)tile * PRT_BLOCK; e_carry = (unsigned)tile * PRT_BLOCK;
-    if (lane == 0) tile_store(tiles_cur + tile, tile_pack(TILE_PREFIX, e_live + agg_live, e_carry + agg_carry));
-#else
     bool ok = lookback(tiles_cur, tile, agg_live, agg_carry, e_live, e_carry, &ctrl->error);
-#endif
     // test hook: pretend the spin expired (such traces publish through k_fused_reinit behind the batch)
     if (ctrl->pad == 1 && tile == 3 && lane == 0) raise_verdict(&ctrl->error, PRT_ERR_STALL);
     (void)ok;
@@ -1063,25 +1055,10 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   sh.generation = PARK(0); sh.intensity = PARK(1); sh.wavelength = PARK(2);
   sh.index_in = PARK(3); sh.id = PARK(4);
   r.ox = PARK(5); r.oy = PARK(6); r.oz = PARK(7);
-#if defined(PRT_ABLATE) && (PRT_ABLATE & 32)
-  {  // timing experiment: no stores, but every shaded value stays live
-    const double sum = sh.generation + sh.intensity + sh.wavelength + sh.index_in + sh.id + sh.px +
-                       sh.py + sh.pz + sh.pw + sh.dx + sh.dy + sh.dz + sh.dw + sh.index +
-                       sh.surface_id + sh.tx + sh.ty + sh.tz;
-    if (sum == 12345.678) rows[0] = sum;
-    return;
-  }
-#endif
-#if defined(PRT_ABLATE) && (PRT_ABLATE & 64)
-  // timing experiment: same 28 store instructions, but every tile writes the same 56 KiB (L2 hits)
-  interact_store(sh, r, carry, threadIdx.x, threadIdx.x, next, ld_next, rows, ld_rows,
-                 next_generation, relaunch, ray_offset);
-#else
   if (!interact_store_rows<COMPACT>(sh, r, carry, (unsigned)live_rank * 8u, (unsigned)carry_rank * 8u,
                                     next + uniform64(excl_carry), ld_next, rows + uniform64(row_base + excl_live),
                                     ld_rows, next_generation, relaunch, ray_offset))
     atomicExch(&ctrl->error, PRT_ERR_FULL_ROWS);
-#endif
   if (sh.err) raise_error(&ctrl->error, sh.err);
   STAMP(7);
 }
@@ -1680,9 +1657,6 @@ static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
   // (shading from an LDS copy of the primitive table was tried in two forms -- per lane without the
   // waterfall, and inside the waterfall -- and measured 2-17 % slower than the batched L1 reads)
   size_t lds = lds_bytes_fused(sd.lds_slots);
-#ifdef PRT_LDS_PAD  // experiment build: extra dynamic LDS lowers the occupancy without touching the code
-  lds += PRT_LDS_PAD;
-#endif
   hipStream_t st = t->st;
   int rc = settle_timing(t);
   if (rc) return rc;

@@ -19,45 +19,7 @@
 #include <hip/hip_runtime.h>
 
 // ---- EXPERIMENT (-DPRT_FAST): approximate division / square root (about 1 ulp, not correctly rounded) ----------
-#ifdef PRT_FAST
-#ifndef PRT_FAST_NEWTON
-#define PRT_FAST_NEWTON 1
-#endif
-__device__ __forceinline__ double prt_fast_rcp(double d) {
-  double r = __builtin_amdgcn_rcp(d);
-#pragma unroll
-  for (int k = 0; k < PRT_FAST_NEWTON; ++k) {
-    const double e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(r, e, r);
-  }
-  return r;
-}
-__device__ __forceinline__ double prt_fast_quot(double n, double d, double r) {
-#if PRT_FAST >= 2
-  (void)d;
-  return n * r;
-#else
-  const double q = n * r;
-  const double e = __builtin_fma(-d, q, n);
-  return __builtin_fma(e, r, q);
-#endif
-}
-__device__ __forceinline__ double prt_fast_div(double n, double d) { return prt_fast_quot(n, d, prt_fast_rcp(d)); }
-__device__ __forceinline__ double prt_fast_sqrt(double x) {
-  const double y = __builtin_amdgcn_rsq(x);
-  double g = x * y;
-  double h = y * 0.5;
-  const double r = __builtin_fma(-h, g, 0.5);
-  g = __builtin_fma(g, r, g);
-  h = __builtin_fma(h, r, h);
-  const double d = __builtin_fma(-g, g, x);
-  g = __builtin_fma(d, h, g);
-  return __builtin_amdgcn_class(x, 0x260) ? x : g;  // +-0, +inf: themselves
-}
-#define PRT_DIV(n, d) prt_fast_div((n), (d))
-#else
 #define PRT_DIV(n, d) ((n) / (d))
-#endif
 
 // biased exponent in [643, 1403]  <=>  2^-380 <= |x| < 2^381
 __device__ __forceinline__ bool prt_exp_window(double x) {
@@ -89,9 +51,6 @@ __device__ __forceinline__ double prt_div_by(double n, double d, double r) {
 
 // (n0 / d, n1 / d)
 __device__ __forceinline__ void prt_div2(double n0, double n1, double d, double& q0, double& q1) {
-#ifdef PRT_FAST
-  { const double r = prt_fast_rcp(d); q0 = prt_fast_quot(n0, d, r); q1 = prt_fast_quot(n1, d, r); return; }
-#endif
   const bool ok = prt_exp_window(d) && prt_num_ok(n0) && prt_num_ok(n1);
   if (__ballot(!ok) == 0ull) {
     const double r = prt_refined_rcp(d);
@@ -106,9 +65,6 @@ __device__ __forceinline__ void prt_div2(double n0, double n1, double d, double&
 // (n0 / d, n1 / d, n2 / d)
 __device__ __forceinline__ void prt_div3(double n0, double n1, double n2, double d, double& q0,
                                          double& q1, double& q2) {
-#ifdef PRT_FAST
-  { const double r = prt_fast_rcp(d); q0 = prt_fast_quot(n0, d, r); q1 = prt_fast_quot(n1, d, r); q2 = prt_fast_quot(n2, d, r); return; }
-#endif
   const bool ok = prt_exp_window(d) && prt_num_ok(n0) && prt_num_ok(n1) && prt_num_ok(n2);
   if (__ballot(!ok) == 0ull) {
     const double r = prt_refined_rcp(d);
@@ -132,9 +88,6 @@ __device__ __forceinline__ void prt_div3(double n0, double n1, double n2, double
 // trace) -- a uniform branch costs this kernel what about three VALU instructions cost it, so a shortcut
 // has to save well over that to pay, and none of these does.  4 costs the register allocation (48 B of
 // scratch per lane) and 3.5 %.
-#ifndef PRT_OPT
-#define PRT_OPT 0
-#endif
 
 // ---- square root ---------------------------------------------------------------------------------
 // hipcc expands sqrt(double) into
@@ -161,29 +114,12 @@ __device__ __forceinline__ double prt_sqrt_core(double x) {
 }
 // sqrt(x)
 __device__ __forceinline__ double prt_sqrt(double x) {
-#ifdef PRT_FAST
-  return prt_fast_sqrt(x);
-#endif
-#if PRT_OPT & 1
-  // high word in [0x10000000, 0x7ff00000)  <=>  2^-767 <= x < +inf  (negative, zero, tiny, inf, NaN: the rest)
-  const unsigned u = (unsigned)__double2hiint(x) - 0x10000000u;
-  if (__ballot(u >= 0x6ff00000u) == 0ull) return prt_sqrt_core(x);
-#endif
   return sqrt(x);
 }
 // sqrt(max(0, x)) for the lanes with x >= 0; a lane with x < 0 (or NaN) gets some finite value -- every
 // caller overrides what it derives from it (the `!(disc >= 0)` rule of the quadratics, the total-reflection
 // branch of refract).  max(0, x) is never -0 here: x is a difference of products, b*b - 4ac resp. 1 - ...
 __device__ __forceinline__ double prt_sqrt_clamped(double x) {
-#ifdef PRT_FAST
-  return prt_fast_sqrt(0.0 > x ? 0.0 : x);
-#endif
-#if PRT_OPT & 1
-  const unsigned hi = (unsigned)__double2hiint(x);
-  // lanes that need the general sequence: 0 <= x < 2^-767 (zero included), +inf, +NaN
-  const bool special = hi < 0x10000000u || (hi - 0x7ff00000u) < 0x00100000u;
-  if (__ballot(special) == 0ull) return prt_sqrt_core(fmax(x, 0x1p-767));
-#endif
   return sqrt(0.0 > x ? 0.0 : x);
 }
 
@@ -194,28 +130,6 @@ __device__ __forceinline__ double prt_sqrt_clamped(double x) {
 // the compiler's own sequence on the same operands (v_div_scale of the numerator, its VCC into v_div_fmas,
 // v_div_fixup): bit-identical quotients by construction, with no assumption about the operands.
 __device__ __forceinline__ void prt_div2_same_scale(double n0, double n1, double d, double& q0, double& q1) {
-#ifdef PRT_FAST
-  { const double r = prt_fast_rcp(d); q0 = prt_fast_quot(n0, d, r); q1 = prt_fast_quot(n1, d, r); return; }
-#endif
-#if PRT_OPT & 4
-  bool f0, f1, g0, g1;
-  const double ds0 = __builtin_amdgcn_div_scale(n0, d, false, &f0);   // (numerator, denominator, scale the numerator?, &vcc)
-  const double ds1 = __builtin_amdgcn_div_scale(n1, d, false, &f1);
-  if (__ballot(__double_as_longlong(ds0) != __double_as_longlong(ds1)) == 0ull) {
-    const double ns0 = __builtin_amdgcn_div_scale(n0, d, true, &g0);
-    const double ns1 = __builtin_amdgcn_div_scale(n1, d, true, &g1);
-    double r = __builtin_amdgcn_rcp(ds0);
-    double e = __builtin_fma(-ds0, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-ds0, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    const double m0 = ns0 * r, m1 = ns1 * r;
-    const double e0 = __builtin_fma(-ds0, m0, ns0), e1 = __builtin_fma(-ds0, m1, ns1);
-    q0 = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(e0, r, m0, g0), d, n0);
-    q1 = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(e1, r, m1, g1), d, n1);
-    return;
-  }
-#endif
   q0 = n0 / d;
   q1 = n1 / d;
 }

@@ -205,10 +205,20 @@ def test_a_nan_wavelength_gets_what_index_at_says_about_it():
         rs = RaySet(4)
         rs.rays[0, :3] = np.array([[-1.0, 0, 0]] * 4).T
         rs.rays[1, 0] = 1.0
+        rs.rays[1, 1] = np.array([0.0, 0.1, -0.1, 0.2])
+        rs.rays[1, :3] /= np.linalg.norm(rs.rays[1, :3], axis=0)
         rs.wavelength = np.array([0.5, np.nan, 0.6, np.nan])
+        n2 = np.asarray(glass.index_at(np.array([0.5, np.nan, 0.6, np.nan])), dtype=float)
+        # what upstream's refract makes of such an index (operations.py:110-162: a NaN radicand is "not > 0", i.e. the
+        # total-reflection branch and the index the ray came with), restated by the oracle
+        from oracle import operations_oracle
+
+        with np.errstate(all="ignore"):
+            want_dirs, want_index, _ = operations_oracle.refract(np.array(rs.rays[1]), np.array(surf.get_world_normals(rs.rays[0])),
+                                                                 np.ones(4), n2)
         glass.trace(surf, rs)
-        want = np.asarray(glass.index_at(np.array([0.5, np.nan, 0.6, np.nan])), dtype=float)
-        assert np.array_equal(np.asarray(rs.index), want, equal_nan=True)
+        assert np.array_equal(np.asarray(rs.index), want_index, equal_nan=True)
+        assert np.allclose(np.asarray(rs.rays[1]), want_dirs, rtol=0, atol=1e-12, equal_nan=True)
 
 
 def test_user_glass_from_device_sources_and_sharded_ids():
