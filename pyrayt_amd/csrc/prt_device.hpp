@@ -87,7 +87,7 @@ struct DevChain {
   int32_t op1, op2;      // CSG_*
   int32_t prim[3];
   int32_t implied1, implied2;  // cull box implied by the survivors (see csg_keep)
-  int32_t shared_rows;         // the leaves' M^-1 agree bit for bit in their linear part (see SharedRows)
+  int32_t shared_rows;         // the leaves' M^-1 agree bit for bit in their linear part (recorded by the compiler; no kernel uses it)
   int32_t intervals;           // every node INTERSECT with an implied box: the interval form applies (chain_candidate)
   double box1[6], box2[6];     // upstream cull boxes of the two nodes (csg.py:126-128)
   double leaf[3][18];          // params[0..5], M^-1 rows 0..2 [6..17]
@@ -201,13 +201,12 @@ __device__ __forceinline__ double norm3(double x, double y, double z) {
   return prt_sqrt((x * x + y * y) + z * z);
 }
 
-// Quotients that share a denominator: one refined reciprocal for all of them (prt_math.hpp), the
-// same bits as separate `/`.  Used for the three-component normalisations; -DPRT_PLAIN_DIV3 builds
-// the A/B partner.
+// Quotients that share a denominator.  Three of them (the normalisations) go through one refined reciprocal
+// (prt_math.hpp), the same bits as separate `/`; for a pair the operand-window check costs what the shared
+// reciprocal saves (measured in round 2), so a pair is two plain divisions.
 __device__ __forceinline__ void div2(double n0, double n1, double d, double& q0, double& q1) {
-  // (operand-window checks cost a pair what the shared reciprocal saves -- prt_div2, round 2; comparing the
-  // two scaled denominators is one instruction and needs no window)
-  prt_div2_same_scale(n0, n1, d, q0, q1);
+  q0 = n0 / d;
+  q1 = n1 / d;
 }
 __device__ __forceinline__ void div3(double n0, double n1, double n2, double d, double& q0, double& q1,
                                      double& q2) {
@@ -215,28 +214,15 @@ __device__ __forceinline__ void div3(double n0, double n1, double n2, double d, 
 }
 
 // ---- quadratic with the reference's degenerate branches (operations.py:28-63) ----------------
-// (PRT_OPT & 2: the `isclose` branches of the reference are evaluated for every lane of every wave, yet
-// in an optical trace almost no wave holds a lane they apply to.  Where a branch only *replaces* values
-// -- `x + (flag ? 1 : 0)`, `if (flag) v = ...` -- a wave without such a lane runs a body without it:
-// x + 0.0 is x for every x the flag leaves alone (it is set for +-0), the replacement is not taken.)
-__device__ __forceinline__ bool no_lane(bool flag) {
-  (void)flag;
-  return false;
-}
 __device__ __forceinline__ void binomial_root(double a, double b, double c, double& p0, double& p1) {
   const double disc = b * b - 4 * a * c;
   const bool lin = near0(a);
   const double s = prt_sqrt_clamped(disc);
-  if (no_lane(lin)) {  // the quadratic proper
-    div2(-b + s, -b - s, 2 * a, p0, p1);
-    if (!(disc >= 0)) { p0 = PRT_INF; p1 = PRT_INF; }
-    return;
-  }
   const double den = 2 * a + (lin ? 1.0 : 0.0);
   div2(-b + s, -b - s, den, p0, p1);
   if (!(disc >= 0)) { p0 = PRT_INF; p1 = PRT_INF; }
   if (lin) {
-    const double root = PRT_DIV(-c, b + (b == 0 ? 1.0 : 0.0));
+    const double root = -c / (b + (b == 0 ? 1.0 : 0.0));
     p0 = root; p1 = root;
     if (near0(b)) {
       p0 = (c <= 0) ? -PRT_INF : PRT_INF;
@@ -249,10 +235,6 @@ __device__ __forceinline__ void binomial_root(double a, double b, double c, doub
 __device__ __forceinline__ void z_slab(double oz, double dz, double lo, double hi, double& c0,
                                        double& c1) {
   const bool par = near0(dz);
-  if (no_lane(par)) {
-    div2(lo - oz, hi - oz, dz, c0, c1);
-    return;
-  }
   const double den = dz + (par ? 1.0 : 0.0);
   div2(lo - oz, hi - oz, den, c0, c1);
   if (par) {
@@ -277,15 +259,11 @@ __device__ __forceinline__ void axis_slab(double o, double d, double lo, double 
                                           double& s_lo, double& s_hi) {
   const bool z = near0(d);
   double first, second;
-  if (no_lane(z)) {
-    div2(-(o - lo), -(o - hi), d, first, second);
-  } else {
-    const double den = d + (z ? 1.0 : 0.0);
-    div2(-(o - lo), -(o - hi), den, first, second);
-    if (z) {
-      first = inside ? -PRT_INF : PRT_INF;
-      second = PRT_INF;
-    }
+  const double den = d + (z ? 1.0 : 0.0);
+  div2(-(o - lo), -(o - hi), den, first, second);
+  if (z) {
+    first = inside ? -PRT_INF : PRT_INF;
+    second = PRT_INF;
   }
   s_lo = dmin(first, second);
   s_hi = dmax(first, second);
@@ -348,13 +326,8 @@ __device__ __forceinline__ void primitive_pair(int type, const double* __restric
       axis_slab(oy, dy, hl, -hl, fabs(oy) <= hl, ly, hy);
       const double enter = dmax(lx, ly), leave = dmin(hx, hy);
       const bool skew = near0(dz);
-      double t;
-      if (no_lane(skew)) {
-        t = PRT_DIV(-oz, dz);
-      } else {
-        t = PRT_DIV(-oz, dz + (skew ? 1.0 : 0.0));
-        if (skew) t = PRT_INF;
-      }
+      double t = -oz / (dz + (skew ? 1.0 : 0.0));
+      if (skew) t = PRT_INF;
       if (!(t >= enter && t <= leave)) t = PRT_INF;
       h0 = t; h1 = t;
     } break;
@@ -370,17 +343,12 @@ __device__ __forceinline__ void primitive_pair(int type, const double* __restric
       const bool lin = near0(a);
       const double s = prt_sqrt_clamped(disc);
       double p0, p1;
-      if (no_lane(lin)) {
-        div2(-b + s, -b - s, 2 * a, p0, p1);
-        if (!(disc >= 0)) { p0 = PRT_INF; p1 = PRT_INF; }
-      } else {
-        const double den = 2 * a + (lin ? 1.0 : 0.0);
-        div2(-b + s, -b - s, den, p0, p1);
-        if (!(disc >= 0)) { p0 = PRT_INF; p1 = PRT_INF; }
-        if (lin) {
-          p0 = PRT_DIV(-c, b + (near0(b) ? 1.0 : 0.0));
-          p1 = (dz >= 0) ? PRT_INF : -PRT_INF;
-        }
+      const double den = 2 * a + (lin ? 1.0 : 0.0);
+      div2(-b + s, -b - s, den, p0, p1);
+      if (!(disc >= 0)) { p0 = PRT_INF; p1 = PRT_INF; }
+      if (lin) {
+        p0 = -c / (b + (near0(b) ? 1.0 : 0.0));
+        p1 = (dz >= 0) ? PRT_INF : -PRT_INF;
       }
       double c0, c1;
       z_slab(oz, dz, 0.0, q[1], c0, c1);
@@ -396,10 +364,8 @@ __device__ __forceinline__ void object_pair(int type, const double* __restrict__
                                             double dx, double dy, double dz, double& t0, double& t1) {
   double h0, h1;
   primitive_pair(type, q, ox, oy, oz, dx, dy, dz, h0, h1);
-  if (!no_lane(__builtin_isunordered(h0, h1))) {  // (0 / 0 of a zero direction: one compare for the pair)
-    h0 = nan_to_inf(h0);
-    h1 = nan_to_inf(h1);
-  }
+  h0 = nan_to_inf(h0);  // (0 / 0 of a zero direction)
+  h1 = nan_to_inf(h1);
   t0 = fmin(h0, h1);  // NaN-free here: v_min / v_max order the pair like np.sort (signed zeros compare equal)
   t1 = fmax(h0, h1);
 }
@@ -413,30 +379,6 @@ __device__ __forceinline__ void surface_pair(int type, const double* __restrict_
   const double dy = row_dot(m, 1, r.dx, r.dy, r.dz, r.dw);
   const double dz = row_dot(m, 2, r.dx, r.dy, r.dz, r.dw);
   object_pair(type, q, ox, oy, oz, dx, dy, dz, t0, t1);
-}
-
-// The leaves of a part share the linear part of their world -> object matrices when the part was moved as a whole
-// (every lens factory: components.py:73-198 builds the faces along the axis and rotates the finished CSG): the
-// first three terms of every row_dot are then the same numbers for all of them.  `Shared` holds those partial
-// sums -- the very fma chain row_dot runs, stopped before the translation term -- and a leaf finishes each with
-// its own fourth term: bit for bit what surface_pair computes, at 6 instead of 24 operations per further leaf.
-struct SharedRows {
-  double o[3], d[3];
-};
-__device__ __forceinline__ SharedRows shared_rows(const double* __restrict__ m, const Ray8& r) {
-  SharedRows s;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    s.o[k] = fma(m[4 * k + 2], r.oz, fma(m[4 * k + 1], r.oy, m[4 * k + 0] * r.ox));
-    s.d[k] = fma(m[4 * k + 2], r.dz, fma(m[4 * k + 1], r.dy, m[4 * k + 0] * r.dx));
-  }
-  return s;
-}
-__device__ __forceinline__ void surface_pair_shared(int type, const double* __restrict__ q,
-                                                    const double* __restrict__ m, const SharedRows& s, const Ray8& r,
-                                                    double& t0, double& t1) {
-  object_pair(type, q, fma(m[3], r.ow, s.o[0]), fma(m[7], r.ow, s.o[1]), fma(m[11], r.ow, s.o[2]),
-              fma(m[3], r.dw, s.d[0]), fma(m[7], r.dw, s.d[1]), fma(m[11], r.dw, s.d[2]), t0, t1);
 }
 
 // ---- primitive.normal in object space (primitives.py Sphere :273-296, Paraboloid :401-419,
@@ -555,8 +497,8 @@ __device__ __forceinline__ double glass_index(PrimPtr p, double wavelength, bool
   if (p->mat_kind == MAT_TABLE) return table_index(p, wavelength, found);
   const auto k = p->coef;                             // materials.py:136-145
   const double w2 = wavelength * wavelength;
-  return prt_sqrt(((1 + PRT_DIV(k[0] * w2, w2 - k[3])) + PRT_DIV(k[1] * w2, w2 - k[4])) +
-                  PRT_DIV(k[2] * w2, w2 - k[5]));
+  return prt_sqrt(((1 + (k[0] * w2) / (w2 - k[3])) + (k[1] * w2) / (w2 - k[4])) +
+                  (k[2] * w2) / (w2 - k[5]));
 }
 
 // operations.reflect (operations.py:104-107): v - (2 n) (v.n), in place
@@ -583,7 +525,7 @@ __device__ __forceinline__ void refract4(double vx, double vy, double vz, double
   const double n2 = leaving ? n_global : n2_in;
   const double mx = leaving ? -nx : nx, my = leaving ? -ny : ny, mz = leaving ? -nz : nz,
                mw = leaving ? -nw : nw;
-  const double r = PRT_DIV(n1, n2);
+  const double r = n1 / n2;
   const double cos1 = leaving ? cos_p : cos_n;
   const double radicand = 1 - (r * r) * (1 - cos1 * cos1);
   const double cos2 = prt_sqrt_clamped(radicand);  // (only looked at when radicand > 0)
@@ -598,7 +540,7 @@ __device__ __forceinline__ void refract4(double vx, double vy, double vz, double
   const double ulen = norm4(ux, uy, uz, uw);
   div3(ux, uy, uz, ulen, ox, oy, oz);
   ow = uw;  // (+-0) / ulen = +-0 for the finite positive ulen of a non-degenerate ray
-  if (uw != 0.0 || !(ulen > 0.0 && ulen < PRT_INF)) ow = PRT_DIV(uw, ulen);
+  if (uw != 0.0 || !(ulen > 0.0 && ulen < PRT_INF)) ow = uw / ulen;
   index_out = (radicand > 0) ? n2 : n1;
 }
 
@@ -633,7 +575,7 @@ __device__ __forceinline__ int shade(PrimPtr p, double px, double py, double pz,
   double vx = tx, vy = ty, vz = tz, vw = dw;  // dw == 0: (+-0) / |d| = +-0
   if (dw != 0.0) {
     const double len = norm4(dx, dy, dz, dw);
-    vx = PRT_DIV(dx, len); vy = PRT_DIV(dy, len); vz = PRT_DIV(dz, len); vw = PRT_DIV(dw, len);
+    vx = dx / len; vy = dy / len; vz = dz / len; vw = dw / len;
   }
   refract4(vx, vy, vz, vw, nx, ny, nz, nw, index, n_mat, 1.0, dx, dy, dz, dw, index);
   return found ? 0 : -6;  // PRT_ERR_WAVELENGTH
@@ -809,34 +751,13 @@ __device__ __forceinline__ bool implied_touch(const double* __restrict__ aabb, c
     // drops the ray wherever it sits; a paraboloid child would still report the finite -c / 1 of its
     // linear branch, primitives.py:361 -- found by fuzz seed 8061 of a 12 000-seed run)
     touched = touched && !outside && !(px && py && pz);
-    // A grazing axis (1e-8 < |d_k| < 1e-4) can only spoil the chord argument if the chord comes close to a face of
-    // the box along it: upstream's slab parameters (lo_k - o_k) / d_k, (hi_k - o_k) / d_k are then huge numbers
-    // with absolute errors to match, but as long as the ray's k coordinate stays inside [lo_k + e, hi_k - e] over
-    // the whole chord [lo, hi] they bracket the chord by e / |d_k| >= 1e4 e on both sides -- their rounding,
-    // 3e-16 |lo_k - o_k| / |d_k|, is eleven orders below that for e = 1e-6 (1 + |lo_k| + |hi_k| + |o_k|) -- and
-    // axis k does not take part in `enter < leave` at all.  Collimated beams are full of such axes (a ray a few
-    // micro-radians off the optical axis), and nearly all of them run well inside the part's box: only a chord
-    // that comes within e of a face (the rim of an aperture) takes the exact test.
+    // A grazing axis (1e-8 < |d_k| < 1e-4): upstream's slab parameters (lo_k - o_k) / d_k, (hi_k - o_k) / d_k are
+    // huge numbers with absolute errors to match, and the chord argument does not cover them: such a ray takes the
+    // exact test.  (Only near a face of the box would it have to -- measured in round 4: config 3 -1.5 %, config 2
+    // +0.8 % with 20 B of scratch per lane; not adopted, tools/experiments/.)
     const bool grazing = (!px && ax < 1e-4) || (!py && ay < 1e-4) || (!pz && az < 1e-4);
     if (__ballot(grazing && any && robust) != 0ull) {
-      bool near_face = false;
-      {
-        const double at_lo = fma(lo, ray.dx, ray.ox), at_hi = fma(hi, ray.dx, ray.ox);
-        const double e = 1e-6 * (((1.0 + fabs(aabb[0])) + fabs(aabb[1])) + fabs(ray.ox));
-        near_face = !px && ax < 1e-4 && !(fmin(at_lo, at_hi) >= aabb[0] + e && fmax(at_lo, at_hi) <= aabb[1] - e);
-      }
-      {
-        const double at_lo = fma(lo, ray.dy, ray.oy), at_hi = fma(hi, ray.dy, ray.oy);
-        const double e = 1e-6 * (((1.0 + fabs(aabb[2])) + fabs(aabb[3])) + fabs(ray.oy));
-        near_face = near_face || (!py && ay < 1e-4 && !(fmin(at_lo, at_hi) >= aabb[2] + e && fmax(at_lo, at_hi) <= aabb[3] - e));
-      }
-      {
-        const double at_lo = fma(lo, ray.dz, ray.oz), at_hi = fma(hi, ray.dz, ray.oz);
-        const double e = 1e-6 * (((1.0 + fabs(aabb[4])) + fabs(aabb[5])) + fabs(ray.oz));
-        near_face = near_face || (!pz && az < 1e-4 && !(fmin(at_lo, at_hi) >= aabb[4] + e && fmax(at_lo, at_hi) <= aabb[5] - e));
-      }
-      near_face = grazing;  // (A/B: every grazing axis takes the exact test, the round-3 rule)
-      const bool exact = near_face && any && robust;  // (a NaN anywhere: not clear of the face, exact test)
+      const bool exact = grazing && any && robust;
       if (__ballot(exact) != 0ull) {
         count_paths(ray.paths, 3, exact);
         if (exact) touched = touched && box_touched(aabb, ray);
@@ -1075,20 +996,12 @@ __device__ __forceinline__ bool segment_meets(const double* __restrict__ box, co
 // values at every level, so ties resolve as in csg_node.  When no lane of the wave holds a positive
 // survivor after the first node, the third leaf is not evaluated (an INTERSECT / DIFFERENCE result
 // lies inside its left operand: the same argument as the interpreter's right-leaf skip).
-template <int T0, int T1, int T2, bool FIXED = false>
+template <int T0, int T1, int T2>
 __device__ __forceinline__ void chain_candidate(const DevChain* __restrict__ ch, const Ray8& ray,
                                                 double& best_t, int& best_prim) {
   double lv[2], rv[2], r2[2] = {PRT_INF, PRT_INF};
-  const bool shared = PRT_CHAIN_SHARED && ch->shared_rows != 0;  // (uniform)
-  SharedRows rows;
-  if (shared) {
-    rows = shared_rows(ch->leaf[0] + 6, ray);
-    surface_pair_shared(T0, ch->leaf[0], ch->leaf[0] + 6, rows, ray, lv[0], lv[1]);
-    surface_pair_shared(T1, ch->leaf[1], ch->leaf[1] + 6, rows, ray, rv[0], rv[1]);
-  } else {
-    surface_pair(T0, ch->leaf[0], ch->leaf[0] + 6, ray, lv[0], lv[1]);
-    surface_pair(T1, ch->leaf[1], ch->leaf[1] + 6, ray, rv[0], rv[1]);
-  }
+  surface_pair(T0, ch->leaf[0], ch->leaf[0] + 6, ray, lv[0], lv[1]);
+  surface_pair(T1, ch->leaf[1], ch->leaf[1] + 6, ray, rv[0], rv[1]);
   const int id0 = ch->prim[0], id1 = ch->prim[1];
   bool have_third = false;
   // ---- the interval form ------------------------------------------------------------------------------------
@@ -1101,7 +1014,7 @@ __device__ __forceinline__ void chain_candidate(const DevChain* __restrict__ ch,
   // An enter that equals an exit (lo == hi: a chord of zero length, which the merge order may or may not keep) is
   // not decided here: a wave holding such a lane takes the general path below, with the pairs it already has.
   // The cull boxes go through implied_touch exactly as in csg_keep.
-  if (PRT_CHAIN_INTERVALS && !FIXED && ch->intervals != 0) {  // (uniform)
+  if (ch->intervals != 0) {  // (uniform)
     const bool b_in = rv[0] >= lv[0], b_out = rv[1] < lv[1];
     double lo = b_in ? rv[0] : lv[0], hi = b_out ? rv[1] : lv[1];
     int id_lo = b_in ? id1 : id0, id_hi = b_out ? id1 : id0;
@@ -1111,8 +1024,7 @@ __device__ __forceinline__ void chain_candidate(const DevChain* __restrict__ ch,
     if (T2 >= 0) {
       // (a chord that ends behind the ray leaves nothing positive for the third leaf to cut: see below)
       if (__ballot((some && hi > 0) || undecided) == 0ull) return;
-      if (shared) surface_pair_shared(T2 < 0 ? 0 : T2, ch->leaf[2], ch->leaf[2] + 6, rows, ray, r2[0], r2[1]);
-      else surface_pair(T2 < 0 ? 0 : T2, ch->leaf[2], ch->leaf[2] + 6, ray, r2[0], r2[1]);
+      surface_pair(T2 < 0 ? 0 : T2, ch->leaf[2], ch->leaf[2] + 6, ray, r2[0], r2[1]);
       have_third = true;
       const int id2 = ch->prim[2];
       const bool c_in = r2[0] >= lo, c_out = r2[1] < hi;
@@ -1135,9 +1047,8 @@ __device__ __forceinline__ void chain_candidate(const DevChain* __restrict__ ch,
     }
   }
   bool keep_l[2], keep_r[2], c1[2][2];
-  // (FIXED: experiment -- both operations INTERSECT and both boxes implied, known at compile time)
-  const int op1 = FIXED ? (int)CSG_INTERSECT : ch->op1, op2 = FIXED ? (int)CSG_INTERSECT : ch->op2;
-  const bool implied1 = FIXED ? true : ch->implied1 != 0, implied2 = FIXED ? true : ch->implied2 != 0;
+  const int op1 = ch->op1, op2 = ch->op2;
+  const bool implied1 = ch->implied1 != 0, implied2 = ch->implied2 != 0;
   csg_keep<2, 2>(op1, lv, rv, ch->box1, ray, implied1, keep_l, keep_r, c1);
   double t;
   int prim;
@@ -1159,8 +1070,7 @@ __device__ __forceinline__ void chain_candidate(const DevChain* __restrict__ ch,
     positive = positive || (behind & 1) || !well_formed(ray);
     if (op2 != CSG_UNION && __ballot(positive) == 0ull) return;
     if (!have_third) {  // (the interval form may have evaluated it already)
-      if (shared) surface_pair_shared(T2 < 0 ? 0 : T2, ch->leaf[2], ch->leaf[2] + 6, rows, ray, r2[0], r2[1]);
-      else surface_pair(T2 < 0 ? 0 : T2, ch->leaf[2], ch->leaf[2] + 6, ray, r2[0], r2[1]);
+      surface_pair(T2 < 0 ? 0 : T2, ch->leaf[2], ch->leaf[2] + 6, ray, r2[0], r2[1]);
     }
     bool keep4[4], keep2[2], c2[4][2];
     csg_keep<4, 2>(op2, l4, r2, ch->box2, ray, implied2, keep4, keep2, c2);

@@ -310,12 +310,10 @@ __device__ __forceinline__ Shaded interact_compute(const SceneDev& scene, const 
   div3(r.dx, r.dy, r.dz, tilt, s.tx, s.ty, s.tz);
   // material dispatch: the primitive table is wave-uniform data, so lanes that hit the same
   // surface shade together and the loop runs once per distinct surface hit in the wave
-  // (v_readfirstlane of the lanes still pending: the index is in an SGPR, so the compiler knows the
-  // table entry is uniform and fetches it with scalar loads -- one batch for the whole record --
-  // instead of per-lane vector loads that all hit the same address)
   // (the table reads below are per-lane vector loads of one address -- a single L1 line per field
-  // group, fetched in one batch.  The scalar-load form of this loop, kept under PRT_SCALAR_WATERFALL,
-  // measured 7 % slower for the whole kernel: its reads are dependent round trips to the scalar cache.)
+  // group, fetched in one batch.  The scalar-load form of this loop -- v_readfirstlane of the lanes still
+  // pending, table entry through the constant address space -- measured 7 % slower for the whole kernel:
+  // its reads are dependent round trips to the scalar cache.)
   unsigned long long todo = __ballot(true);
   while (todo) {
     const int leader = __ffsll((long long)todo) - 1;
@@ -327,23 +325,6 @@ __device__ __forceinline__ Shaded interact_compute(const SceneDev& scene, const 
       s.surface_id = p->surface_id;
     }
     todo &= ~__ballot(prim == cur);
-  }
-  return s;
-  for (bool pending = true; __ballot(pending) != 0ull;) {
-    if (pending) {
-      const int cur = __builtin_amdgcn_readfirstlane(prim);
-      // compare against an opaque copy: inside `if (prim == cur)` the optimiser would otherwise
-      // substitute the per-lane `prim` for `cur` and turn the table reads back into vector loads
-      int same = cur;
-      asm volatile("" : "+s"(same));
-      if (prim == same) {
-        const ConstPrimPtr p = const_prim(scene.prims, cur);
-        s.err = shade(p, s.px, s.py, s.pz, s.pw, s.dx, s.dy, s.dz, s.dw, s.wavelength, s.index,
-                     s.tx, s.ty, s.tz);
-        s.surface_id = p->surface_id;
-        pending = false;
-      }
-    }
   }
   return s;
 }

@@ -18,9 +18,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-// ---- EXPERIMENT (-DPRT_FAST): approximate division / square root (about 1 ulp, not correctly rounded) ----------
-#define PRT_DIV(n, d) ((n) / (d))
-
 // biased exponent in [643, 1403]  <=>  2^-380 <= |x| < 2^381
 __device__ __forceinline__ bool prt_exp_window(double x) {
   const unsigned e = ((unsigned)__double2hiint(x) >> 20) & 0x7ffu;
@@ -49,19 +46,6 @@ __device__ __forceinline__ double prt_div_by(double n, double d, double r) {
   return __builtin_amdgcn_div_fixup(q1, d, n);
 }
 
-// (n0 / d, n1 / d)
-__device__ __forceinline__ void prt_div2(double n0, double n1, double d, double& q0, double& q1) {
-  const bool ok = prt_exp_window(d) && prt_num_ok(n0) && prt_num_ok(n1);
-  if (__ballot(!ok) == 0ull) {
-    const double r = prt_refined_rcp(d);
-    q0 = prt_div_by(n0, d, r);
-    q1 = prt_div_by(n1, d, r);
-  } else {
-    q0 = n0 / d;
-    q1 = n1 / d;
-  }
-}
-
 // (n0 / d, n1 / d, n2 / d)
 __device__ __forceinline__ void prt_div3(double n0, double n1, double n2, double d, double& q0,
                                          double& q1, double& q2) {
@@ -78,58 +62,13 @@ __device__ __forceinline__ void prt_div3(double n0, double n1, double n2, double
   }
 }
 
-// ---- experiment switches of the round-3 "VALU diet" (-DPRT_OPT=<mask>; all OFF in the product) -----------
-//   1  square roots without the scaling wrapper when no lane of the wave needs it (prt_sqrt*)
-//   2  the reference's isclose / NaN selects only in waves that hold such a lane (prt_device.hpp)
-//   4  root / slab pairs on one refined reciprocal when v_div_scale gives both quotients the same denominator
-// Each is bit-identical to the plain form and each was measured on config 2 (profiles/r3/valu_diet.txt):
-// 1 + 2 take 5.4 % of the VALU instructions out of k_generation (1 217 -> 1 152 per wave) and put 24
-// wave-uniform branches per wave in (96 -> 119): the launch time does not move (174.4 vs 174.1 us per
-// trace) -- a uniform branch costs this kernel what about three VALU instructions cost it, so a shortcut
-// has to save well over that to pay, and none of these does.  4 costs the register allocation (48 B of
-// scratch per lane) and 3.5 %.
-
 // ---- square root ---------------------------------------------------------------------------------
-// hipcc expands sqrt(double) into
-//     scale = x < 2^-767;  xs = ldexp(x, scale ? 256 : 0)
-//     y = v_rsq(xs);  g = xs * y;  h = y * 0.5;  r = fma(-h, g, 0.5);  g = fma(g, r, g);  d = fma(-g, g, xs)
-//     h = fma(h, r, h);  g = fma(d, h, g);  d = fma(-g, g, xs);  g = fma(d, h, g)
-//     res = ldexp(g, scale ? -128 : 0);  res = class(xs, +-0 | +inf) ? xs : res
-// -- twenty instructions of which ten are the iteration.  For 2^-767 <= x < +inf the first ldexp moves
-// nothing, the last one neither, and the class test fails: the ten instructions in the middle on x itself
-// ARE the result, bit for bit (prt_sqrt_core; checked against sqrt() on 2^32 operands per launch by
-// tools/ubench/sqrt_fast.hip).  A wave in which any lane holds another operand takes the ordinary sqrt.
-__device__ __forceinline__ double prt_sqrt_core(double x) {
-  const double y = __builtin_amdgcn_rsq(x);
-  double g = x * y;
-  double h = y * 0.5;
-  const double r = __builtin_fma(-h, g, 0.5);
-  g = __builtin_fma(g, r, g);
-  double d = __builtin_fma(-g, g, x);
-  h = __builtin_fma(h, r, h);
-  g = __builtin_fma(d, h, g);
-  d = __builtin_fma(-g, g, x);
-  g = __builtin_fma(d, h, g);
-  return g;
-}
-// sqrt(x)
-__device__ __forceinline__ double prt_sqrt(double x) {
-  return sqrt(x);
-}
+// The compiler's sqrt(double): correctly rounded, twenty instructions of which ten are the iteration
+// (scaling wrapper for x < 2^-767, v_rsq, one Goldschmidt step, two corrections, class test for +-0 / +inf).
+// Shorter forms that give the same bits for operands in range exist (tools/ubench/sqrt_fast.hip,
+// tools/experiments/) and were measured: the wave-uniform branch that guards them costs what they save.
+__device__ __forceinline__ double prt_sqrt(double x) { return sqrt(x); }
 // sqrt(max(0, x)) for the lanes with x >= 0; a lane with x < 0 (or NaN) gets some finite value -- every
 // caller overrides what it derives from it (the `!(disc >= 0)` rule of the quadratics, the total-reflection
 // branch of refract).  max(0, x) is never -0 here: x is a difference of products, b*b - 4ac resp. 1 - ...
-__device__ __forceinline__ double prt_sqrt_clamped(double x) {
-  return sqrt(0.0 > x ? 0.0 : x);
-}
-
-// ---- two quotients of one denominator ----------------------------------------------------------------
-// The compiler's n / d scales d against the numerator first (ds = v_div_scale(d, d, n)) and refines the
-// reciprocal of THAT.  When both numerators give the same ds -- bit for bit, which is what is compared --
-// the refined reciprocal is the same value in both divisions, so it is computed once; everything else is
-// the compiler's own sequence on the same operands (v_div_scale of the numerator, its VCC into v_div_fmas,
-// v_div_fixup): bit-identical quotients by construction, with no assumption about the operands.
-__device__ __forceinline__ void prt_div2_same_scale(double n0, double n1, double d, double& q0, double& q1) {
-  q0 = n0 / d;
-  q1 = n1 / d;
-}
+__device__ __forceinline__ double prt_sqrt_clamped(double x) { return sqrt(0.0 > x ? 0.0 : x); }
