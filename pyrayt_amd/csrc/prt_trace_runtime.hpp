@@ -1,0 +1,719 @@
+// prt_trace_runtime.hpp -- the host runtime of a whole trace: workspace layout, the four asynchronous tickets of a
+// scene and device (prt_trace_begin / prt_trace_end, prt_trace = begin + end, prt_trace_batch), how generations are
+// launched in batches without a host round trip, which compaction form each launch is offered from what the scene's
+// previous trace did (hints, per-tile records, dead lists) and what happens when a tile refutes it, the three-kernel
+// fallback, statistics and telemetry.  Host code; included by prt_kernels.hip.
+#pragma once
+// workspace of prt_trace:
+//   ctrl | fused ctrl | generation slots | rows_per_generation (device) | tile words A | B
+//   | block counts | block offsets | hit_t (n f64) | hit_prim (n i32)      [unfused path only]
+//   | ray buffer A (13 n) | ray buffer B (13 n)
+struct TraceLayout {
+  size_t ctrl, fctrl, gen, dead_lists, tile_hints, gen_rows, tiles_a, tiles_b, counts, offsets, hit_t, hit_prim, rays_a,
+      rays_b, total;
+};
+static TraceLayout trace_layout(int64_t n) {
+  const size_t nb = blocks_for(n) + 1;
+  const size_t nn = (size_t)(n < 1 ? 1 : n);
+  TraceLayout l;
+  size_t at = 0;
+  auto take = [&](size_t bytes) { size_t here = at; at += align_up(bytes, 256); return here; };
+  l.ctrl = take(sizeof(TraceCtrl));
+  // the fused path's control header sits right in front of its generation slots so that the
+  // host reads both back with one copy
+  l.fctrl = take(sizeof(GenCtrl) + (kMaxGenerationSlots + 1) * sizeof(GenCtrl));
+  l.gen = l.fctrl + sizeof(GenCtrl);
+  l.dead_lists = take(3 * sizeof(DeadList));                                   // (at kDeadListOffset from gen[0]: dead_list())
+  l.tile_hints = take((size_t)kTileHintGenerations * nb * sizeof(TileHint));  // (at kTileHintOffset from gen[0]: tile_hints())
+  l.gen_rows = take(kMaxGenerationSlots * sizeof(int64_t));
+  l.tiles_a = take(nb * sizeof(unsigned long long));
+  l.tiles_b = take(nb * sizeof(unsigned long long));
+  l.counts = take(nb * 2 * sizeof(int32_t));
+  l.offsets = take(nb * 2 * sizeof(int64_t));
+  l.hit_t = take(nn * sizeof(double));
+  l.hit_prim = take(nn * sizeof(int32_t));
+  l.rays_a = take(nn * PRT_RAY_ROWS * sizeof(double));
+  l.rays_b = take(nn * PRT_RAY_ROWS * sizeof(double));
+  l.total = at;
+  if (l.tile_hints - l.gen != kTileHintOffset || l.dead_lists - l.gen != kDeadListOffset) abort();  // (the kernel finds them by these constants)
+  return l;
+}
+
+extern "C" int64_t prt_trace_workspace_bytes(int64_t n) {
+  return (int64_t)trace_layout(n < 0 ? 0 : n).total;
+}
+
+static int64_t trace_error(int error) {
+  if (error == PRT_ERR_ROWS_CAP) return fail(PRT_ERR_ROWS_CAP, "rows_cap too small");
+  if (error == PRT_ERR_UNTRACABLE)
+    return fail(PRT_ERR_UNTRACABLE, "a ray hit a surface whose material has no trace() (or one shaded by the caller: "
+                                    "PRT_MAT_HOST surfaces are served by prt_propagate / prt_gather_hits / prt_interact)");
+  if (error == PRT_ERR_WAVELENGTH)
+    return fail(PRT_ERR_WAVELENGTH, "a ray's wavelength is not in the index table of the glass it hit "
+                                    "(prt_scene_set_index_tables)");
+  if (error == PRT_ERR_STALL) return PRT_ERR_STALL;
+  return fail(error, "device error during trace");
+}
+
+// Who traced last with a given workspace address: a ticket skips re-initialising the control words only
+// if nobody else used the block since its own last trace (another scene, another ticket, or the other
+// trace path of the same one marks the block as theirs before touching it).
+static std::mutex g_workspace_mutex;
+static std::unordered_map<const void*, unsigned long long> g_workspace_user;
+static std::atomic<unsigned long long> g_next_user{1};
+static bool workspace_taken_over(const void* w, unsigned long long user) {
+  std::lock_guard<std::mutex> lock(g_workspace_mutex);
+  // (addresses that were freed long ago would stay in here for ever: forgetting everybody is always safe,
+  // a forgotten owner just re-initialises its control words once)
+  if (g_workspace_user.size() > 4096) g_workspace_user.clear();
+  unsigned long long& last = g_workspace_user[w];
+  const bool same = last == user;
+  last = user;
+  return !same;
+}
+
+// three kernels per generation + a host round trip (kept for A/B runs and cross-checks)
+static int64_t trace_unfused(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t* rows_per_generation) {
+  const int64_t n = t->n;
+  const int generation_limit = t->limit;
+  char* w = t->w;
+  hipStream_t st = t->st;
+  const TraceLayout l = trace_layout(n);
+  TraceCtrl* ctrl = (TraceCtrl*)(w + l.ctrl);
+  int64_t* gen_rows = (int64_t*)(w + l.gen_rows);
+  int32_t* counts = (int32_t*)(w + l.counts);
+  int64_t* offsets = (int64_t*)(w + l.offsets);
+  double* hit_t = (double*)(w + l.hit_t);
+  int32_t* hit_prim = (int32_t*)(w + l.hit_prim);
+  double* buf[2] = {(double*)(w + l.rays_a), (double*)(w + l.rays_b)};
+  const int keep_absorbed = (t->flags & PRT_TRACE_KEEP_ABSORBED) ? 1 : 0;
+  // PRT_TRACE_COUNT_PATHS: the nearest-hit kernel of this path counts (one ray per lane only: the k-lanes
+  // kernels evaluate components per lane and would count a ray once per lane group member)
+  const bool count_paths = (t->flags & PRT_TRACE_COUNT_PATHS) != 0 && s->options.hit_lanes <= 1 && !s->options.hit_staged;
+  if (t->user == 0) t->user = g_next_user.fetch_add(1);
+  (void)workspace_taken_over(w, t->user);  // the block is ours now: a fused trace behind this one re-initialises
+  t->ready_workspace = nullptr;
+
+  SceneDev sd = trace_scene_dev(s, c);
+  hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, st, ctrl, n, t->rows_cap);
+
+  const double* src = t->rays;
+  int64_t src_ld = t->ld;
+  int64_t n_cur = n, total_rows = 0;
+  int error = 0;
+  for (int g = 0; g < generation_limit && n_cur > 0; ++g) {
+    double* dst = buf[g & 1];
+    const unsigned nb = blocks_for(n_cur);
+    const int relaunch = (g + 1 != generation_limit) ? 1 : 0;
+    HIP_TRY(hipEventRecord(t->ev0, st));
+    {
+      int rc_hit = launch_hit(s, c, sd, st, src, src_ld, (const TraceCtrl*)ctrl, (int64_t)0, n_cur, hit_t, hit_prim,
+                              (int64_t*)nullptr, counts, keep_absorbed, count_paths ? ctrl->paths : nullptr);
+      if (rc_hit) return rc_hit;
+    }
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, (const int32_t*)counts, offsets, ctrl);
+    hipLaunchKernelGGL(k_shade, dim3(nb), dim3(PRT_BLOCK), 0, st, sd, src, src_ld,
+                       (const TraceCtrl*)ctrl, (int64_t)0, (const double*)hit_t,
+                       (const int32_t*)hit_prim, (const int64_t*)nullptr, (const int64_t*)offsets,
+                       dst, n, t->rows_out, t->rows_cap, (int64_t)0, (double)(g + 1), relaunch,
+                       t->ray_offset, keep_absorbed, ctrl, (const double*)nullptr, (int64_t)0);
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, st, ctrl, gen_rows, g);
+    HIP_TRY(hipEventRecord(t->ev1, st));
+    // the host needs the new ray count to size the next launch
+    HIP_TRY(hipMemcpyAsync(t->host_pinned, ctrl, sizeof(TraceCtrl), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(t->host_pinned + 12, gen_rows + g, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, t->ev0, t->ev1));
+    const TraceCtrl* h = (const TraceCtrl*)t->host_pinned;
+    t->stats[0] += 1;
+    t->stats[1] += (double)n_cur;
+    t->stats[2] += ms;
+    t->stats[3] += 4;
+    if (h->error) { error = h->error; break; }
+    const int64_t live = t->host_pinned[12];
+    rows_per_generation[g] = live;
+    total_rows += live;
+    t->stats[4] += (double)live;
+    t->stats[5] += (double)h->n_cur;
+    n_cur = h->n_cur;
+    src = dst;
+    src_ld = n;
+  }
+  if (error) return trace_error(error);
+  if (count_paths) {  // (the control block of the last generation is on the host: the counters are cumulative)
+    const TraceCtrl* h = (const TraceCtrl*)t->host_pinned;
+    s->path_counts[0] += 1;
+    for (int k = 1; k < 4; ++k) s->path_counts[k] += (long long)h->paths[k];
+  }
+  return total_rows;
+}
+
+// one kernel per generation; generations are launched in batches with no host round trip in
+// between (a generation whose predecessor left no rays exits in its prologue)
+static const int kGenerationBatch = 4;
+
+// add the HIP-event time of the ticket's last batch to its kernel-time statistic (waits for ev1 if
+// need be: by the time anybody asks, the batch has long finished)
+static int settle_timing(TraceTicket* t) {
+  if (!t->timing_pending) return PRT_OK;
+  t->timing_pending = false;
+  HIP_TRY(hipEventSynchronize(t->ev1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, t->ev0, t->ev1));
+  t->stats[2] += ms;
+  return PRT_OK;
+}
+
+// spin on the epoch word of the host mirror; gives up after ~2 s of polling and lets the stream
+// synchronisation report whatever went wrong
+static int await_epoch(TraceTicket* t, unsigned long long epoch) {
+  volatile unsigned long long* word = &t->mirror->epoch;
+  for (long spins = 0; __atomic_load_n(word, __ATOMIC_ACQUIRE) != epoch; ++spins) {
+    __builtin_ia32_pause();
+    if (spins > (1l << 28)) {
+      HIP_TRY(hipStreamSynchronize(t->st));
+      if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != epoch) return fail(PRT_ERR_HIP, "trace batch never published its counts");
+      break;
+    }
+  }
+  return PRT_OK;
+}
+
+#ifdef PRT_HOST_PROFILE
+#include <time.h>
+static double g_hp[8]; static long g_hp_n;
+static inline double hp_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+#define HP(k) g_hp_t[k] = hp_now()
+static double g_hp_t[8];
+extern "C" void prt_debug_host_profile(double* out9) { for (int k = 0; k < 8; ++k) out9[k] = g_hp[k]; out9[8] = (double)g_hp_n; }
+#else
+#define HP(k)
+#endif
+
+// enqueue generations [t->g, t->g + t->batch) of the ticket's trace (one launch each, no host round trip
+// in between) and whatever has to run behind them; they publish t->epoch to the ticket's mirror
+static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
+  const int64_t n = t->n;
+  const TraceLayout l = trace_layout(n);
+  char* w = t->w;
+  FusedCtrl* ctrl = (FusedCtrl*)(w + l.fctrl);
+  GenCtrl* gen = (GenCtrl*)(w + l.gen);
+  unsigned long long* tiles[2] = {(unsigned long long*)(w + l.tiles_a), (unsigned long long*)(w + l.tiles_b)};
+  double* buf[2] = {(double*)(w + l.rays_a), (double*)(w + l.rays_b)};
+  const int keep_absorbed = (t->flags & PRT_TRACE_KEEP_ABSORBED) ? 1 : 0;
+  const SceneDev sd = trace_scene_dev(s, c);
+  // (shading from an LDS copy of the primitive table was tried in two forms -- per lane without the
+  // waterfall, and inside the waterfall -- and measured 2-17 % slower than the batched L1 reads)
+  size_t lds = lds_bytes_fused(sd.lds_slots);
+  hipStream_t st = t->st;
+  int rc = settle_timing(t);
+  if (rc) return rc;
+  HP(2);
+  const unsigned long long epoch = ++t->epoch;
+  const bool timed = !(t->flags & PRT_TRACE_NO_TIMING);
+  if (timed) HIP_TRY(hipEventRecord(t->ev0, st));
+  HP(3);
+  const bool culls = s->has_cull_steps;
+  auto kernel = t->compact ? (culls ? k_generation<true, true> : k_generation<false, true>)
+                           : (culls ? k_generation<true, false> : k_generation<false, false>);
+  for (int b = 0; b < t->batch; ++b) {
+    const int gg = t->g + b;
+    const double* src = (gg == 0) ? t->rays : buf[(gg - 1) & 1];
+    const int64_t src_ld = (gg == 0) ? t->ld : n;
+    // dense-mode hint of the previous trace for this generation (the kernel reads the generation's
+    // ray count on the device and checks the assumption tile by tile)
+    int assume = 0;
+    if (t->use_hints && gg < (int)s->hint_mode.size()) assume = s->hint_mode[gg];
+    // (a generation whose dense hint was refuted lately keeps compacting for a while: see hint_rest)
+    if (assume && gg < (int)s->hint_rest.size() && s->hint_rest[gg] > 0) assume = 0;
+    // a generation that compacts on the per-tile record its last run left in this workspace (exact, and it leaves
+    // nothing behind: preferred to mode 4 below when the trace is of the same ray buffer again)
+    const bool on_record = (assume == 0 || assume == 4) && t->use_tile_records && !t->records_off &&
+                           gg < kTileHintGenerations && t->tile_record[gg];
+    const bool kept_then = t->launch_mode[gg] == 4;  // in the ticket's last trace (meaningful where it left records)
+    // Mode 4 (sparse loss): last time every ray of this generation was recorded and all but a few of them -- absorbed
+    // ones -- were carried on.  Compacting those few away costs every tile a look-back, and the tiles that hold such a
+    // ray are as a rule the slow ones (a ray that misses the part it was expected to hit visits the parts behind it):
+    // with 1 tile in 60 slow and 1280 in flight, every tile waits for a straggler (profiles/r4/lookback_stragglers.txt).
+    // Such a generation runs dense instead, keeping its absorbed rays the way upstream does (PRT_TRACE_KEEP_ABSORBED
+    // for this launch only: _pyrayt.py:415-428 carries them, direction zeroed, and drops them a generation later);
+    // the next generation finds them dead on arrival, records nothing for them and drops them when it compacts.
+    int keep = keep_absorbed;
+    if (assume == 4) {
+      // (a trace of the ticket's last ray buffer without a record of this generation -- it ran dense last time --
+      // compacts once to leave one: from then on such traces run on records, which leave the next generation alone)
+      const bool wants_record = t->use_tile_records && gg < kTileHintGenerations;
+      if (on_record || wants_record || (t->flags & PRT_TRACE_NO_SPARSE_KEEP)) assume = 0;
+      else { assume = 1; keep = 1; }
+    }
+    // Modes 5 / 6: the generation behind one that keeps its absorbed rays and loses none of its own (5: carries the
+    // live ones on, 6: carries none) takes its offsets from the dead list its predecessor wrote (k_generation) --
+    // no look-back for a handful of dead rays.  Only right behind such a launch of this attempt (generation 0 keeps
+    // rays without listing them); behind anything else nothing dead arrives and the plain dense forms apply.
+    if (assume == 5 || assume == 6) {
+      const bool kept_before = gg > 0 && t->launch_mode[gg - 1] == 4;
+      if (!kept_before) assume -= 4;
+      else if (gg == 1) assume = 0;
+    }
+    t->launch_mode[gg] = (char)(keep && !keep_absorbed ? 4 : assume);
+    // (a generation that keeps its absorbed rays this time and did not last time, or the other way round, hands the
+    // generations behind it other rays than their records were taken on)
+    if ((t->launch_mode[gg] == 4) != kept_then) t->records_off = true;
+    s->dense_launches += assume ? 1 : 0;
+    s->sparse_keep_launches += keep && !keep_absorbed ? 1 : 0;
+    if (on_record && assume == 0) {
+      assume = 3;
+      t->launch_mode[gg] = 3;
+      t->used_tile_hints = true;
+      s->tile_hint_launches += 1;
+    }
+    // launches, not generations, alternate between the two status buffers, across traces too: every
+    // launch works on the one the launch before it left clean and cleans the other (k_generation)
+    hipLaunchKernelGGL(kernel, dim3(blocks_for(n)), dim3(PRT_BLOCK), lds, st, sd, src, src_ld, buf[gg & 1], n,
+                       t->rows_out, t->rows_cap, ctrl, gen, gg, tiles[t->flip], tiles[t->flip ^ 1], (double)(gg + 1),
+                       t->limit, t->ray_offset, keep,
+                       t->publish_in_kernel ? t->mirror_dev : (HostMirror*)nullptr, epoch, b,
+                       b + 1 == t->batch ? 1 : 0, assume);
+    t->flip ^= 1;
+    if (b == 0) HP(4);
+  }
+  if (timed) {
+    HIP_TRY(hipEventRecord(t->ev1, st));
+    t->timing_pending = true;
+  }
+  // Behind the batch, only when the generation kernels did not tell the host themselves: a one-block
+  // kernel that does (and re-arms the control words if the batch turns out to end the trace).  In
+  // the usual case nothing runs behind the batch: the status buffers recycle each other, a
+  // generation slot is always written by the launch before the one that reads it, and the error
+  // word of a trace that succeeded is still zero.
+  if (!t->publish_in_kernel) {
+    hipLaunchKernelGGL(k_fused_reinit, dim3(1), dim3(1024), 0, st, ctrl, gen, t->limit + 1, t->g + t->batch,
+                       t->limit, tiles[0], (int64_t)blocks_for(n), n, t->test_stall, t->mirror_dev, epoch,
+                       t->g, t->batch + 1);
+  }
+  HIP_TRY(hipGetLastError());
+  HP(5);
+  t->launched = true;
+  return PRT_OK;
+}
+
+// start an attempt of the ticket's trace on the fused path: control words, hints, first batch
+static int fused_start(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
+  const int64_t n = t->n;
+  const TraceLayout l = trace_layout(n);
+  char* w = t->w;
+  const int n_slots = t->limit + 1;
+  const int keep_absorbed = (t->flags & PRT_TRACE_KEEP_ABSORBED) ? 1 : 0;
+  t->test_stall = (t->flags & PRT_TRACE_TEST_STALL) ? 1 : 0;
+  // A trace leaves the control words (generation slots, tile status buffers, error word) as the next
+  // trace of the same shape needs them (see the launch loop); only a first trace, one with another
+  // workspace / ray count / limit, or one behind a trace that failed clears them here.
+  if (t->user == 0) t->user = g_next_user.fetch_add(1);
+  const bool others = workspace_taken_over(w, t->user);
+  if (others || !(t->ready_workspace == w && t->ready_n == n && t->ready_slots == n_slots &&
+                  t->ready_stall == t->test_stall)) {
+    hipLaunchKernelGGL(k_fused_init, dim3(64), dim3(256), 0, t->st, (FusedCtrl*)(w + l.fctrl), (GenCtrl*)(w + l.gen),
+                       n_slots, (unsigned long long*)(w + l.tiles_a), (int64_t)blocks_for(n), n, t->test_stall);
+    t->flip = 0;
+    for (bool& kept : t->tile_record) kept = false;  // (the slots the records are checked against are cleared)
+  }
+  t->ready_workspace = nullptr;
+  // the generation kernels tell the host themselves unless an error can still be raised after the
+  // last tile has its totals (only PRT_ERR_UNTRACABLE, at store time) or an experiment kernel runs
+  // (the stall test hook raises its fake error from a tile that no successor waits for: same path)
+  t->publish_in_kernel = !s->has_untracable && !t->test_stall && !(t->flags & PRT_TRACE_PUBLISH_KERNEL);
+  // Hints from the previous trace of this scene with this many rays (PRT_TRACE_NO_HINTS turns them off).
+  // After a miss the hints rest for 2, 4, 8 ... 64 traces (a caller that alternates between ray sets of
+  // different shapes must not pay a repeat every time).
+  for (int& rest : s->hint_rest) rest -= rest > 0 ? 1 : 0;  // (counted in traces of this scene)
+  bool allow_hints = t->allow_hints;
+  if (allow_hints && s->hint_holdoff > 0) {
+    s->hint_holdoff -= 1;
+    allow_hints = false;
+  }
+  // (the hints say how the scene treated the previous ray set -- which generations lost no ray -- and each
+  // tile checks them on its own rays, so they serve a ray set of another SIZE as well: a design loop that
+  // changes its ray count from call to call keeps them)
+  t->use_hints = allow_hints && s->hint_n >= 0 && s->hint_keep_absorbed == keep_absorbed && !t->test_stall;
+  // The per-tile records of this ticket's last trace (TileHint) serve the generations that compact: offered with
+  // the other hints, to a trace that publishes from its kernels (the slots the records lean on are then never
+  // cleared between traces), and rested after a miss like them.
+  // ... and only to a trace of the very buffer the records were taken from: another ray set loses its rays in other
+  // tiles, every offer would be a miss and a repeat (a caller that refills one buffer with new rays is still offered
+  // them -- and every tile checks)
+  bool allow_tiles = t->allow_tile_hints && t->use_hints && t->publish_in_kernel && t->record_rays == t->rays;
+  if (allow_tiles && s->tile_hint_holdoff > 0) {
+    s->tile_hint_holdoff -= 1;
+    allow_tiles = false;
+  }
+  t->use_tile_records = allow_tiles;
+  t->records_off = false;
+  t->used_tile_hints = false;
+  t->g = 0;
+  t->n_seen = 0;
+  t->total_rows = 0;
+  // Generations are launched blind, a batch at a time, and the host looks at the counts once per
+  // batch.  A scene traced before most likely runs as many generations as last time: launching
+  // exactly that many first means neither a launch that finds no rays nor a second round trip.
+  int want = kGenerationBatch;
+  if (s->last_generations > 0) want = std::min(s->last_generations, kMaxBatch);
+  t->batch = std::min(want, t->limit);
+  HP(1);
+  return fused_launch_batch(s, c, t);
+}
+
+// wait for the attempt's batch, look at its counts, enqueue further batches until the trace is over.
+// Returns the number of rows, or an error (the internal ones included: the caller repeats the attempt).
+static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t* rows_per_generation) {
+  const int keep_absorbed = (t->flags & PRT_TRACE_KEEP_ABSORBED) ? 1 : 0;
+  int error = 0;
+  bool done = false;
+  while (true) {
+    int rc = await_epoch(t, t->epoch);
+    if (rc) return rc;
+    HP(6);
+    const GenCtrl* host_gen = t->mirror->gen;
+    t->stats[3] += t->batch;
+    error = t->mirror->error;
+    if (error) break;
+    for (int b = 0; b < t->batch; ++b) {
+      if (host_gen[b].n_in == 0) { done = true; break; }
+      t->stats[0] += 1;
+      t->stats[1] += (double)host_gen[b].n_in;
+      t->stats[4] += (double)host_gen[b].n_live;
+      t->stats[5] += (double)host_gen[b].n_carry;
+      rows_per_generation[t->g + b] = host_gen[b].n_live;
+      t->total_rows += host_gen[b].n_live;
+      const bool all_live = host_gen[b].n_live == host_gen[b].n_in;
+      const int64_t lost = host_gen[b].n_in - host_gen[b].n_carry;
+      // (bit 0, sparse loss: every ray recorded, at most 1 in 64 absorbed; bit 1: ... at least one such ray in 128
+      // tiles, enough to stall a look-back; bit 2: ... few enough for the generation behind to read them off the dead
+      // list -- a tile reads the whole list, and from a few hundred entries on that costs what a look-back without
+      // stragglers costs: ab_round4.txt, "mode 7")
+      t->seen_sparse[t->n_seen] = !(all_live && host_gen[b].n_carry > 0 && lost > 0 && lost * 64 <= host_gen[b].n_in) ? 0
+                                  : (char)(1 | (lost * 128 * PRT_BLOCK >= host_gen[b].n_in ? 2 : 0) | (lost <= 256 ? 4 : 0));
+      // (bits 3, 4: more than 1 ray in 32 / in 16 arrived dead or hit nothing.  The first keeps the generation before
+      // from starting to keep its absorbed rays -- this one would carry too many dead lanes --, the second makes one
+      // that does keep them stop: it is keeping too many by now.  Two thresholds, a sparse loss apart: no flip-flop.)
+      if ((host_gen[b].n_in - host_gen[b].n_live) * 32 > host_gen[b].n_in) t->seen_sparse[t->n_seen] |= 8;
+      if ((host_gen[b].n_in - host_gen[b].n_live) * 16 > host_gen[b].n_in) t->seen_sparse[t->n_seen] |= 16;
+      t->seen_mode[t->n_seen++] = all_live && lost == 0 ? 1 : all_live && host_gen[b].n_carry == 0 ? 2 : 0;
+    }
+    if (!done && host_gen[t->batch].n_in == 0) done = true;
+    t->g += t->batch;
+    if (done || t->g >= t->limit) break;
+    t->batch = std::min(kGenerationBatch, t->limit - t->g);
+    rc = fused_launch_batch(s, c, t);
+    if (rc) return rc;
+  }
+  t->launched = false;
+  if (error) for (bool& kept : t->tile_record) kept = false;  // (whatever the attempt overwrote before it failed)
+  if (!error) {
+    // Which generations keep their absorbed rays next time (mode 4, see the launch loop).  It moves the compaction to
+    // the generation behind: free when that one compacts anyway, worth it when the loss is dense enough for its
+    // stragglers to hold up most of the tiles in flight (config 3: one lost ray in 61 tiles, -6.6 % on the trace), a
+    // loss when it turns a dense generation into a compacting one for a handful of rays (config 2: one in 434 tiles,
+    // +3.4 %; profiles/r4/ab_round4.txt).
+    const bool sparse_ok = !keep_absorbed && !(t->flags & PRT_TRACE_NO_SPARSE_KEEP);
+    // (raw: what the counts say -- 1 every ray recorded and carried, 2 every ray recorded, none carried, 0 neither)
+    char raw_next = t->n_seen ? t->seen_mode[0] : 0;
+    for (int g = 0; g < t->n_seen; ++g) {
+      const char raw = raw_next, was = g < (int)s->hint_mode.size() && t->use_hints ? s->hint_mode[g] : 0;
+      raw_next = g + 1 < t->n_seen ? t->seen_mode[g + 1] : 0;
+      char mode = raw;
+      if (t->launch_mode[g] == 4) {
+        // (kept its absorbed rays: how many there were cannot be told from its own counts -- the generation behind
+        // tells: when a thirty-second of what it received is dead, this one goes back to compacting and is judged anew)
+        const bool flooded = g + 1 < t->n_seen && (t->seen_sparse[g + 1] & 16);
+        mode = raw == 1 && !flooded ? 4 : 0;
+      } else if (sparse_ok && (t->seen_sparse[g] & 1) && g + 1 < t->n_seen && !(t->seen_sparse[g + 1] & 8) &&
+                 ((t->seen_sparse[g] & 2) || raw_next == 0 || (t->seen_sparse[g + 1] & 1) || (g > 0 && (t->seen_sparse[g] & 4)))) {
+        // (g > 0 and few: whatever the generation behind looks like, it can take the dead list -- modes 5 / 6)
+        mode = 4;
+      } else if (sparse_ok && was == 4 && raw == 1) {
+        mode = 4;  // nothing absorbed this time: the form that covers both stays
+      }
+      // The generation behind one that keeps its absorbed rays finds them dead among its own.  If it loses none of
+      // its own it runs on the dead list (5 / 6; generation 0 writes no list); otherwise it compacts.
+      if (g > 0 && t->seen_mode[g - 1] == 4) {
+        // (the list is worth reading when it is short: known when the generation before was seen without keeping)
+        const bool listed = g > 1 && t->launch_mode[g - 1] != 4 && (t->seen_sparse[g - 1] & 4);
+        if (t->launch_mode[g] == 5 || t->launch_mode[g] == 6) mode = t->launch_mode[g];  // held, tile by tile
+        else if (listed && raw == 1) mode = 5;
+        else if (listed && raw == 2) mode = 6;
+        else mode = 0;
+      }
+      t->seen_mode[g] = mode;
+    }
+  }
+  if (error == PRT_ERR_SPECULATION || error == PRT_ERR_FULL_ROWS || error == PRT_ERR_TILE_HINT) return error;
+  // a record block that looked too small to a generation launched on a hint may only have been too small
+  // for the hint: the caller repeats without hints before it reports it
+  if (error == PRT_ERR_ROWS_CAP && t->used_tile_hints) return PRT_ERR_TILE_HINT;
+  if (error == PRT_ERR_ROWS_CAP && t->use_hints) return PRT_ERR_SPECULATION;
+  if (error == PRT_ERR_STALL) return PRT_ERR_STALL;
+  if (error) return trace_error(error);
+  if (!t->publish_in_kernel) t->flip = 0;  // (k_fused_reinit cleared buffer 0; the next launch cleans buffer 1)
+  s->last_generations = (int)t->stats[0];
+  s->hint_n = t->n;
+  s->hint_keep_absorbed = keep_absorbed;
+  if (!s->missed_mode.empty()) {
+    // This trace is the repeat of an attempt whose dense hints did not hold: the generations that were offered a
+    // hint and turned out otherwise are the ones whose rays are lost differently from trace to trace (a ray set
+    // that loses a near-axial ray in one generation where the previous one lost none).  Such a generation is not
+    // offered its dense hint for the next 32, 64 ... 4096 traces (it compacts, by look-back or on its per-tile
+    // record); the hints of the other generations were not refuted and stay in use -- a loop that alternates
+    // between such ray sets pays one repeat per rest, not one every other trace.
+    bool found = false;
+    if (s->hint_rest.size() < s->missed_mode.size()) { s->hint_rest.resize(s->missed_mode.size(), 0); s->hint_rest_span.resize(s->missed_mode.size(), 0); }
+    for (size_t g = 0; g < s->missed_mode.size(); ++g) {
+      const char now = g < (size_t)t->n_seen ? t->seen_mode[g] : 0;
+      const char offered = s->missed_mode[g];
+      // (offered a plain dense form, found to absorb a few rays or to sit behind a generation that does: the hint it
+      // gets now covers both cases, nothing to rest)
+      if ((offered == 1 && (now == 4 || now == 5)) || (offered == 2 && now == 6)) { found = true; continue; }
+      // (offered a form that also covers what the repeat saw: not the one that missed)
+      if ((offered == 4 && now == 1) || (offered == 5 && now == 1) || (offered == 6 && now == 2)) continue;
+      if (offered != 0 && offered != now) {
+        s->hint_rest_span[g] = s->hint_rest_span[g] ? std::min(s->hint_rest_span[g] * 2, 4096) : 32;
+        s->hint_rest[g] = s->hint_rest_span[g];
+        found = true;
+      }
+    }
+    if (!found) {
+      // Nobody looks different in the repeat: if generations ran on a dead list, the list it is (more tiles kept
+      // rays than it holds -- a reader cannot tell from the counts of a trace without hints): those rest.
+      for (size_t g = 0; g < s->missed_mode.size(); ++g) {
+        if (s->missed_mode[g] != 5 && s->missed_mode[g] != 6) continue;
+        s->hint_rest_span[g] = s->hint_rest_span[g] ? std::min(s->hint_rest_span[g] * 2, 4096) : 32;
+        s->hint_rest[g] = s->hint_rest_span[g];
+        found = true;
+      }
+    }
+    if (found) { s->hint_holdoff = 0; s->hint_misses_in_a_row = 0; }  // (the culprit rests by itself)
+    s->missed_mode.clear();
+  }
+  s->hint_mode.assign(t->seen_mode, t->seen_mode + t->n_seen);
+  if (t->use_hints) s->hint_misses_in_a_row = 0;
+  if (t->used_tile_hints) s->tile_hint_misses_in_a_row = 0;
+  // which generations left (or confirmed) a per-tile record in this workspace: those that compacted
+  // (a trace that published through k_fused_reinit had its generation slots -- the ray count and totals the records
+  // are checked against -- cleared behind it: its records are not offered)
+  for (int g = 0; g < kTileHintGenerations; ++g)
+    t->tile_record[g] = t->publish_in_kernel && g < t->n_seen && (t->launch_mode[g] == 0 || t->launch_mode[g] == 3) &&
+                        (t->seen_mode[g] == 0 || t->seen_mode[g] == 4);
+  t->record_rays = t->rays;
+  // the control words are as a next trace of this shape needs them (see the launch loop)
+  t->ready_workspace = t->w;
+  t->ready_n = t->n;
+  t->ready_slots = t->limit + 1;
+  t->ready_stall = t->test_stall;
+  return t->total_rows;
+}
+
+static void reset_stats(prt_scene* s, TraceTicket* t, int variant) {
+  for (double& v : t->stats) v = 0;
+  t->stats[6] = (double)s->lookback_fallbacks;
+  t->stats[7] = variant;
+}
+
+extern "C" int prt_trace_begin(prt_scene* s, int device, int ticket, const double* rays, int64_t n, int64_t ld,
+                               int generation_limit, double ray_offset, double* rows_out, int64_t rows_cap,
+                               void* workspace, int flags, void* stream) {
+  HP(0);
+  DeviceCopy* c;
+  int rc = on_device(s, device, &c);
+  if (rc) return rc;
+  if (ticket < 0 || ticket >= PRT_TRACE_TICKETS) return fail(PRT_ERR_ARG, "ticket out of range");
+  TraceTicket* t = &c->ticket[ticket];
+  if (t->active) return fail(PRT_ERR_ARG, "this ticket has a trace in flight (prt_trace_end it first)");
+  if (n < 0 || ld < n || generation_limit < 0 || generation_limit > kMaxGenerationSlots ||
+      rows_cap < 0 || !workspace || (n && !rays) || (rows_cap && !rows_out))
+    return fail(PRT_ERR_ARG, "bad buffers (generation_limit must be <= 1024)");
+  if (n >= (1ll << 31)) return fail(PRT_ERR_ARG, "at most 2^31-1 rays per call");
+  for (int k = 0; k < PRT_TRACE_TICKETS; ++k)
+    if (k != ticket && c->ticket[k].active && n && c->ticket[k].n &&
+        (c->ticket[k].w == (char*)workspace || c->ticket[k].rows_out == rows_out))
+      return fail(PRT_ERR_ARG, "traces in flight together need their own workspace and record block");
+  rc = settle_timing(t);  // events of the ticket's previous trace, before they are recorded again
+  if (rc) return rc;
+  t->rays = rays; t->n = n; t->ld = ld; t->limit = generation_limit; t->ray_offset = ray_offset;
+  t->rows_out = rows_out; t->rows_cap = rows_cap; t->w = (char*)workspace; t->flags = flags;
+  t->st = (hipStream_t)stream;
+  t->launched = false;
+  t->allow_hints = !(flags & PRT_TRACE_NO_HINTS);
+  t->allow_tile_hints = t->allow_hints && !(flags & PRT_TRACE_NO_TILE_RECORDS);
+  t->compact = !s->full_rows && !(flags & PRT_TRACE_FULL_ROWS);
+  t->active = true;
+  if (n == 0 || generation_limit == 0) { reset_stats(s, t, PRT_VARIANT_FUSED); return PRT_OK; }
+  if (flags & PRT_TRACE_COUNT_PATHS) t->flags |= PRT_TRACE_UNFUSED;  // the counting nearest-hit kernel lives on that path
+  if (t->flags & PRT_TRACE_UNFUSED) {  // host round trip per generation: everything happens in prt_trace_end
+    reset_stats(s, t, s->options.hit_lanes > 1 ? PRT_VARIANT_KLANES : PRT_VARIANT_UNFUSED);
+    return PRT_OK;
+  }
+  reset_stats(s, t, PRT_VARIANT_FUSED);
+  rc = fused_start(s, c, t);
+  if (rc) t->active = false;
+  return rc;
+}
+
+extern "C" int64_t prt_trace_end(prt_scene* s, int device, int ticket, int64_t* rows_per_generation) {
+  DeviceCopy* c;
+  int rc = on_device(s, device, &c);
+  if (rc) return rc;
+  if (ticket < 0 || ticket >= PRT_TRACE_TICKETS || !rows_per_generation)
+    return fail(PRT_ERR_ARG, "bad ticket / null rows_per_generation");
+  TraceTicket* t = &c->ticket[ticket];
+  if (!t->active) return fail(PRT_ERR_ARG, "no trace in flight on this ticket");
+  t->active = false;
+  s->stats_device = device;
+  s->stats_ticket = ticket;
+  for (int g = 0; g < t->limit; ++g) rows_per_generation[g] = 0;
+  if (t->n == 0 || t->limit == 0) return 0;
+  int64_t rc64 = 0;
+  if (t->flags & PRT_TRACE_UNFUSED) {
+    rc64 = trace_unfused(s, c, t, rows_per_generation);
+  } else {
+    for (int attempt = 0;; ++attempt) {
+      rc64 = fused_finish(s, c, t, rows_per_generation);
+      if ((rc64 != PRT_ERR_SPECULATION && rc64 != PRT_ERR_FULL_ROWS && rc64 != PRT_ERR_TILE_HINT) || attempt == 4) break;
+      if (rc64 == PRT_ERR_TILE_HINT) {
+        // a generation found other counts in a tile than its last run left on record (other rays, or a scene
+        // that treats them differently): again without the records -- the dense hints stay, they were not refuted
+        s->tile_hint_misses += 1;
+        s->tile_hint_misses_in_a_row = std::min(s->tile_hint_misses_in_a_row + 1, 6);
+        s->tile_hint_holdoff = 1 << s->tile_hint_misses_in_a_row;
+        t->allow_tile_hints = false;
+      } else if (rc64 == PRT_ERR_SPECULATION) {
+        // a generation assumed dense was not (the rays or the scene changed since the hints were taken):
+        // nothing of this attempt is kept; run again without assumptions, which also renews the hints
+        s->speculation_misses += 1;
+        s->missed_mode = s->hint_mode;  // (which generations were offered what: compared with the repeat's outcome)
+        s->hint_misses_in_a_row = std::min(s->hint_misses_in_a_row + 1, 6);
+        s->hint_holdoff = 1 << s->hint_misses_in_a_row;
+        s->hint_n = -1;
+        t->allow_hints = false;
+      } else {
+        // a ray needs the state rows the compact form leaves out (homogeneous w other than 1 / +0, or a
+        // ray set that does not start at generation 0): this scene traces with all 13 rows from now on
+        s->full_rows = true;
+        s->full_rows_fallbacks += 1;
+        t->compact = false;
+      }
+      for (int g = 0; g < t->limit; ++g) rows_per_generation[g] = 0;
+      rc = settle_timing(t);
+      if (rc) return rc;
+      reset_stats(s, t, PRT_VARIANT_FUSED);
+      rc = fused_start(s, c, t);
+      if (rc) return rc;
+    }
+    if (rc64 == PRT_ERR_SPECULATION || rc64 == PRT_ERR_FULL_ROWS || rc64 == PRT_ERR_TILE_HINT)
+      rc64 = fail(PRT_ERR_HIP, "trace kept failing its own assumptions");
+    if (rc64 == PRT_ERR_STALL) {  // never observed outside the test hook; see lookback()
+      for (int g = 0; g < t->limit; ++g) rows_per_generation[g] = 0;
+      rc = settle_timing(t);
+      if (rc) return rc;
+      s->lookback_fallbacks += 1;  // telemetry: a box that falls back silently would just look 2x slow
+      reset_stats(s, t, PRT_VARIANT_UNFUSED);
+      rc64 = trace_unfused(s, c, t, rows_per_generation);
+    }
+  }
+  if (rc64 >= 0 && (t->flags & PRT_TRACE_SYNC)) HIP_TRY(hipStreamSynchronize(t->st));
+#ifdef PRT_HOST_PROFILE
+  HP(7);
+  for (int k = 1; k < 8; ++k) g_hp[k] += g_hp_t[k] - g_hp_t[0];
+  g_hp_n += 1;
+#endif
+  return rc64;
+}
+
+extern "C" int64_t prt_trace(prt_scene* s, int device, const double* rays, int64_t n, int64_t ld,
+                             int generation_limit, double ray_offset, double* rows_out,
+                             int64_t rows_cap, int64_t* rows_per_generation, void* workspace,
+                             int flags, void* stream) {
+  if (!rows_per_generation) return fail(PRT_ERR_ARG, "rows_per_generation is null");
+  const int rc = prt_trace_begin(s, device, 0, rays, n, ld, generation_limit, ray_offset, rows_out, rows_cap,
+                                 workspace, flags, stream);
+  if (rc) return rc;
+  return prt_trace_end(s, device, 0, rows_per_generation);
+}
+
+// A sequence of traces of one scene, `depth` of them in flight (ticket k % depth, its workspace, its
+// stream): the loop DeviceScene.trace_many runs in Python, as one call.  (Measured with a host pause between
+// collecting a trace and starting the next, profiles/r3/batch_issue.txt: the pace of the host is not what
+// bounds overlapped traces -- a tight Python loop reaches the same step time down to 125k rays.)
+static_assert(sizeof(prt_trace_job) == 56, "prt_trace_job is part of the ABI (engine.JOB_DTYPE, INTEGRATION.md)");
+extern "C" int64_t prt_trace_batch(prt_scene* s, int device, prt_trace_job* jobs, int64_t count, int generation_limit,
+                                   double ray_offset, int depth, void* const* workspaces, void* const* streams,
+                                   int flags) {
+  DeviceCopy* c;
+  int rc = on_device(s, device, &c);
+  if (rc) return rc;
+  if (count < 0 || (count && !jobs) || depth < 1 || depth > PRT_TRACE_TICKETS || !workspaces)
+    return fail(PRT_ERR_ARG, "bad job list / depth out of range (1..PRT_TRACE_TICKETS) / null workspaces");
+  for (int64_t k = 0; k < count; ++k) {
+    if (!jobs[k].rows_per_generation) return fail(PRT_ERR_ARG, "a job has no rows_per_generation");
+    jobs[k].total = 0;
+  }
+  for (int k = 0; k < depth; ++k)
+    if (c->ticket[k].active) return fail(PRT_ERR_ARG, "a ticket this batch needs has a trace in flight");
+  int64_t sum = 0, first_error = 0;
+  std::string message;
+  for (int64_t k = 0; k < count + depth; ++k) {
+    const int lane = (int)(k % depth);
+    if (k >= depth && c->ticket[lane].active) {  // the ticket about to be reused: collect its trace first
+      prt_trace_job& done = jobs[k - depth];
+      done.total = prt_trace_end(s, device, lane, done.rows_per_generation);
+      if (done.total < 0 && !first_error) { first_error = done.total; message = g_error; }
+      if (done.total > 0) sum += done.total;
+    }
+    if (k < count && !first_error) {  // (after an error nothing new is started; what is in flight is collected)
+      const prt_trace_job& job = jobs[k];
+      rc = prt_trace_begin(s, device, lane, job.rays, job.n, job.ld, generation_limit, ray_offset, job.rows_out,
+                           job.rows_cap, workspaces[lane], flags, streams ? streams[lane] : nullptr);
+      if (rc) { jobs[k].total = rc; first_error = rc; message = g_error; }
+    }
+  }
+  if (first_error) return fail((int)first_error, message.c_str());
+  return sum;
+}
+
+
+extern "C" int prt_trace_telemetry(const prt_scene* s, int64_t* out12) {
+  int64_t* out8 = out12;
+  if (!s || !out8) return fail(PRT_ERR_ARG, "null argument");
+  out12[8] = s->tile_hint_launches;
+  out12[9] = s->tile_hint_misses;
+  out12[10] = s->sparse_keep_launches;
+  out12[11] = 0;
+  out8[0] = s->lookback_fallbacks;
+  out8[1] = s->speculation_misses;
+  out8[2] = s->dense_launches;
+  out8[3] = s->full_rows_fallbacks;
+  for (int k = 0; k < 4; ++k) out8[4 + k] = s->path_counts[k];
+  return PRT_OK;
+}
+
+extern "C" int prt_trace_stats(const prt_scene* s, double* out8) {
+  if (!s || !out8) return fail(PRT_ERR_ARG, "null argument");
+  for (int k = 0; k < 8; ++k) out8[k] = 0;
+  if (s->stats_device < 0 || s->stats_device >= (int)s->per_device.size()) return PRT_OK;  // nothing traced yet
+  TraceTicket* t = &const_cast<prt_scene*>(s)->per_device[s->stats_device].ticket[s->stats_ticket];
+  if (!t->active) {  // (begun again already: its events belong to the new trace; the time stays out)
+    HIP_TRY(hipSetDevice(s->stats_device));
+    int rc = settle_timing(t);  // the last batch's event time is collected on demand
+    if (rc) return rc;
+  }
+  for (int k = 0; k < 8; ++k) out8[k] = t->stats[k];
+  return PRT_OK;
+}
+
+#ifdef PRT_TIMING
+// experiment build: the s_memtime stamps of generation 0's waves (tools/lookback_analysis.py)
+extern "C" int prt_debug_wave_stamps(long long* out, int64_t count) {
+  if (!out || count < 0 || count > 16384 * 4 * 8) return PRT_ERR_ARG;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), (size_t)count * sizeof(long long)) != hipSuccess) return PRT_ERR_HIP;
+  return PRT_OK;
+}
+#endif
