@@ -24,27 +24,35 @@ region and reported under "gather" and "value_with_gather" -- it is not part of 
 
 The timed steps ROTATE through four distinct seeded ray sets of the workload (config 2: seeds 1234 ... 1237, all
 resident in HBM before the timed region), so that no step re-traces its predecessor's rays: the per-tile
-compaction records of the previous trace never apply and every step reads its input from HBM.  That is `value`.
-The round-3 headline -- the same ray set traced again and again, dense hints AND per-tile records of the previous
-trace active -- is reported as `value_replay`; `value_synchronous` is one blocking `prt_trace` at a time (what one
-`RayTracer.trace()`, pyrayt/_pyrayt.py:329-339, costs in a running design loop), `value_cold` a fresh scene's
-first trace.  After the timed region the rows of the seed-1234 set are compared with the reference's own summary of
-that run (tests/golden/config2_1m_summary.npz: rows per generation x surface, the ids of the near-axial rays of
-SURVEY Q5, a checksum of the surface column, column sums, 4096 sampled rows) -> "verified"; a false verdict exits
-non-zero.
+compaction records of the previous trace never apply and every step reads its input from HBM.  They are issued with
+2-3 traces in flight, each ticket of the library on its own HIP stream (prt_trace_batch: the loop over
+prt_trace_begin / prt_trace_end, run by the library; --python-loop runs it from here): the host enqueues ahead and the
+kernels of different traces overlap on the device.
 
-They are issued with 2-3 traces in flight, each ticket of the library on its own HIP stream
-(prt_trace_batch: the loop over prt_trace_begin / prt_trace_end, run by the library; --python-loop runs it
-from here): the host enqueues ahead and the kernels of different traces overlap on the device.  `value` is that throughput.  The kernel's own launch duration -- what `roofline` prices --
-is measured on one stream, same steps, right behind the timed region (`roofline.measured_on`);
-`roofline.device_aggregate` says what the whole device sustains while the traces overlap.
+ONE regime describes the line.  The region of K steps (barrier + synchronize on both sides) is timed --reps times
+(default 5); `value` / `ms_per_step` are those of the MEDIAN repetition, `repetitions` carries all of them with min
+and max.  `roofline` prices that same repetition: every trace of the region is bracketed by a pair of HIP events of
+its own on its own stream (PRT_TRACE_BUSY), and behind the region the library merges the intervals
+(prt_trace_batch_busy): `kernel_ms_per_step` = the time the device had at least one of the region's traces in
+flight, per step -- never more than `ms_per_step` -- and `avg_launch_ms` = that time per generation launch.  The
+kernel's duration when it has the device to itself (what `rocprofv3 --stats` averages when the steps run on one
+stream) is `roofline.one_stream`, measured right behind the timed region, with `value_one_stream` next to it.
 
-rank 0 prints ONE JSON line.  `roofline` is for the generation kernel(s): algorithmic bytes
-(328 B per ray alive at generation entry that is recorded and goes on) over the
-HIP-event time of those launches measured inside the library on the launch stream; the bytes the
-kernel actually moves (it carries 10 of the 13 state rows between generations) are reported next
-to it as `moved_bytes_per_launch` / `moved_frac`.  `cpu_baseline` is the numpy
-oracle (a port of the reference's path, validated against it) timed on this host, rank 0, N=1.
+After the timed region the rows of the LAST timed step of EACH of the four ray sets are compared with the reference's
+own summary of that run (tests/golden/config2_1m_summary*.npz, written by the genuine reference: rows per generation x
+surface, the ids of the near-axial rays of SURVEY Q5, a checksum of the surface column, column sums, sampled rows to
+1e-6) -> "verified" / `verification.seeds`; a false verdict exits non-zero.  With --gpus N the ranks' shards are
+checked together (counts and sums are additive), BEFORE the timed region.
+
+Other kinds of step, untimed side runs: `value_replay` (the same ray set again and again: round 3's headline),
+`value_synchronous` (one blocking prt_trace at a time: what one RayTracer.trace(), pyrayt/_pyrayt.py:329-339, costs in
+a running design loop), `value_cold` (a fresh scene's first trace), `value_no_hints`, `value_first_trace`.
+
+rank 0 prints ONE JSON line.  `roofline` is for the generation kernel(s): algorithmic bytes (328 B per ray alive at
+generation entry that is recorded and goes on) over the busy time above; the bytes the kernel
+actually moves (it carries 10 of the 13 state rows between generations) are reported next to it as
+`moved_bytes_per_launch` / `moved_frac`.  `cpu_baseline` is the numpy oracle (a port of the reference's path,
+validated against it) timed on this host, rank 0, N=1.
 """
 import argparse
 import json
@@ -79,6 +87,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--reps", type=int, default=5,
+                    help="how many times the region of --steps steps is timed: value / ms_per_step are the median "
+                         "repetition's, min and max are reported next to them")
     ap.add_argument("--spinup-ms", type=float, default=60.0,
                     help="untimed traces before the warmup steps until this much wall time has passed: a GPU "
                          "that has been idle runs its first ~10 ms of work at lower clocks (measured: 7 %% on "
@@ -112,6 +123,31 @@ def parse_args():
     ap.add_argument("--side-steps", type=int, default=40,
                     help="steps of each untimed side measurement (synchronous / no hints / changing ray count)")
     return ap.parse_args()
+
+
+def summary_file(seed):
+    """The reference's own summary of the 1M-ray config-2 job for one seed of the rotation (tests/golden/generate_golden.py)."""
+    name = "config2_1m_summary.npz" if seed == 1234 else f"config2_1m_summary_seed{seed}.npz"
+    return os.path.join(ROOT, "tests", "golden", name)
+
+
+def summary_checks(frame, want):
+    """Rows of a whole 1M-ray config-2 trace, (R, 15) on the host, against the reference's summary of that run:
+    rows per generation x surface, the ids of the near-axial rays of SURVEY Q5, a checksum of the surface column,
+    column sums, sampled rows to 1e-6."""
+    import numpy as np
+
+    gens, surf = frame[:, 0].astype(np.int64), frame[:, 5].astype(np.int64)
+    checks = {"rows": frame.shape[0] == int(want["rows"])}
+    if checks["rows"]:
+        pairs, pair_counts = np.unique(np.stack((gens, surf)), axis=1, return_counts=True)
+        checks["rows_per_generation_x_surface"] = bool(np.array_equal(pairs, want["gen_surface_pairs"]) and
+                                                       np.array_equal(pair_counts, want["gen_surface_counts"]))
+        checks["q5_ids"] = bool(np.array_equal(frame[(gens == 1) & (surf == surf.max()), 4].astype(np.int64), want["q5_ids"]))
+        checks["surface_checksum"] = int((surf * (gens + 1)).sum()) == int(want["surface_checksum"])
+        checks["column_sums"] = bool(np.allclose(frame.sum(axis=0), want["column_sums"], rtol=1e-9, atol=1e-3))
+        checks["sample_rows_1e-6"] = bool(np.allclose(frame[want["sample_index"]], want["sample_rows"], rtol=0, atol=1e-6))
+    return checks
 
 
 def _free_port():
@@ -187,14 +223,12 @@ def main():
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     # The HIP runtime maps streams onto hardware queues, four by default (the null stream holds one): a fourth
     # ticket stream would share a queue with another and serialise with it.  Small shards gain from a fourth trace
-    # in flight (profiles/r3/streams.txt: 125k rays 24.7 -> 23.1 us per step), so this process asks for eight queues
-    # -- before the runtime is loaded; a setting the user made stays.
-    # (pyrayt_amd.engine does that when it is imported before torch -- a plain script gets it too; here explicitly, for
-    # the record the line carries)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # in flight (profiles/r3/streams.txt: 125k rays 24.7 -> 23.1 us per step), so the package asks for eight queues
+    # when it is imported (pyrayt_amd/_runtime.py: in force as long as no HIP call has been made yet, whichever of
+    # torch and pyrayt_amd comes first); a setting the user made stays.
     import numpy as np
-    from pyrayt_amd import engine  # before torch: see engine._ask_for_hardware_queues
     import torch
+    from pyrayt_amd import engine
 
     import scenes
     from pyrayt_amd import distributed as pdist
@@ -283,8 +317,10 @@ def main():
     depth = streams_wanted if mode == "overlap" else 2  # traces in flight, the one being collected included
     # record blocks handed back to every step (what a design loop does once it has consumed the previous
     # frame); n * limit columns always suffice; every ticket in flight records into its own block
+    # (... and one per ray set of the rotation, so that the LAST timed step of every ray set is still there to be
+    # verified behind the timed region)
     blocks = [torch.empty((engine.RECORD_COLS, max(n, 1) * limit), dtype=torch.float64, device=device)
-              for _ in range(max(depth, 2))]
+              for _ in range(max(depth, 2, n_sets))]
     block = blocks[0]
 
     def step(flags=args.flags, rays_in=None):
@@ -300,6 +336,7 @@ def main():
         def __init__(self):
             self.kernel_ms = self.launches = self.ray_generations = self.rows_recorded = self.rays_carried = 0.0
             self.rows_returned = 0  # rows of every step of the region, summed from what the traces returned
+            self.busy = None        # overlapped regions issued by prt_trace_batch: the merged busy intervals
 
         def add(self, times=1):
             st = scene.trace_stats()
@@ -323,8 +360,11 @@ def main():
         """The job table of `count` overlapped steps (built once per region size, outside the timed region)."""
         key = (count, flags, rotate)
         if key not in batches:
+            # (every trace bracketed by its own pair of HIP events on its own stream, merged behind the region by the
+            # library: PRT_TRACE_BUSY -> batch.busy())
             batches[key] = engine.TraceBatch(scene, [ray_set(k, rotate) for k in range(count)], limit, depth=depth,
-                                             outs=blocks[:depth], flags=flags | engine.TRACE_NO_TIMING)
+                                             outs=blocks[:max(depth, len(ray_sets) if rotate else 1)],
+                                             flags=flags | engine.TRACE_NO_TIMING | engine.TRACE_BUSY)
         return batches[key]
 
     def run_steps(count, totals=None, flags=args.flags, how=None, rotate=True):
@@ -347,6 +387,7 @@ def main():
             batch = prepared_batch(count, flags, rotate)
             batch.run()
             if totals is not None:
+                totals.busy = batch.busy()
                 for k in range(min(count, len(ray_sets))):  # steps k, k + n_sets, ... trace set k
                     totals.add_set(k if rotate else 0, len(range(k, count, len(ray_sets))))
                 totals.rows_returned += int(batch.totals.sum())
@@ -386,6 +427,85 @@ def main():
         step(args.flags, ray_sets[k])
         step(args.flags, ray_sets[k])  # (the second trace of a set launches exactly its working generations)
         set_stats.append(scene.trace_stats())
+    # ---- several GPUs: before anything is timed, the shards together against the reference's summaries --------------
+    # Every rank traces its shard of each ray set; the frame is re-assembled on rank 0 through the path a user takes
+    # (RCCL all-gathers + placement kernel inside the library when the group is RCCL-backed) and compared like a
+    # single-GPU frame.  A mismatch ends the run, non-zero, on every rank: a scaling number for wrong rows is worth
+    # nothing.  If the re-assembly itself fails (first contact with a new node), the shards are checked through their
+    # additive statistics instead -- per generation x surface counts, checksum, column sums, Q5 ids -- and the line
+    # says so.  `rccl_ranks` is what ncclCommCount reports for the library's communicator.
+    pre_verification, rccl_ranks, bench_comm = None, None, None
+    verifiable_job = (args.workload == "config2" and n_job == RAYS_PER_GPU and limit == GENERATION_LIMIT and strong)
+    if distributed:
+        if backend == "nccl":
+            try:
+                bench_comm = pdist.LibraryComm.from_group(dist.group.WORLD, device)
+                rccl_ranks = bench_comm.info()["ranks"]
+            except Exception as exc:  # noqa: BLE001
+                rccl_ranks = f"{type(exc).__name__}: {exc}"[:200]
+                bench_comm = None
+        if verifiable_job:
+            per_seed, how, failed = {}, "frame re-assembled on rank 0 (pyrayt_amd.distributed.assemble_rows)", None
+            for k in range(len(ray_sets)):
+                seed = base_seed + k
+                if not os.path.exists(summary_file(seed)):
+                    continue
+                want = np.load(summary_file(seed))
+                got, got_counts = scene.trace(ray_sets[k], limit, flags=args.flags)
+                checks = None
+                if failed is None:
+                    try:
+                        full, _ = pdist.assemble_rows(got, got_counts, limit, dist.group.WORLD, "root", comm=bench_comm)
+                        torch.cuda.synchronize(device)
+                        if rank == 0:
+                            checks = summary_checks(engine.to_host(full).T, want)
+                        del full
+                    except Exception as exc:  # noqa: BLE001
+                        failed = f"{type(exc).__name__}: {exc}"[:200]
+                    # (every rank takes the same path from here: one that failed tells the others)
+                    flag = torch.tensor([0.0 if failed is None else 1.0], dtype=torch.float64, device=comm_device)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                    if float(flag[0]) > 0:
+                        failed = failed or "another rank's re-assembly failed"
+                        how = f"additive statistics of the shards (the re-assembly failed: {failed})"
+                        checks = None
+                if failed is not None:
+                    frame = engine.to_host(got).T
+                    gens, surf = frame[:, 0].astype(np.int64), frame[:, 5].astype(np.int64)
+                    pairs, pair_counts = np.unique(np.stack((gens, surf)), axis=1, return_counts=True)
+                    mine = {"rows": frame.shape[0], "pairs": {tuple(p): int(c) for p, c in zip(pairs.T.tolist(), pair_counts)},
+                            "checksum": int((surf * (gens + 1)).sum()), "sums": frame.sum(axis=0),
+                            "q5": frame[(gens == 1) & (surf == int(want["gen_surface_pairs"][1].max())), 4].astype(np.int64)}
+                    everyone = [None] * world
+                    dist.all_gather_object(everyone, mine)
+                    if rank == 0:
+                        merged = {}
+                        for part in everyone:
+                            for key, c in part["pairs"].items():
+                                merged[key] = merged.get(key, 0) + c
+                        want_pairs = {tuple(p): int(c) for p, c in zip(want["gen_surface_pairs"].T.tolist(), want["gen_surface_counts"])}
+                        checks = {"rows": sum(p["rows"] for p in everyone) == int(want["rows"]),
+                                  "rows_per_generation_x_surface": merged == want_pairs,
+                                  "q5_ids": bool(np.array_equal(np.sort(np.concatenate([p["q5"] for p in everyone])), want["q5_ids"])),
+                                  "surface_checksum": sum(p["checksum"] for p in everyone) == int(want["surface_checksum"]),
+                                  "column_sums": bool(np.allclose(sum(p["sums"] for p in everyone), want["column_sums"], rtol=1e-9, atol=1e-3))}
+                if rank == 0:
+                    per_seed[seed] = checks
+            verdict = [None]
+            if rank == 0 and per_seed:
+                ok = all(all(c.values()) for c in per_seed.values())
+                verdict[0] = (ok, {"against": "tests/golden/config2_1m_summary*.npz (written by the genuine reference)",
+                                   "of": f"every ray set of the rotation, all {world} shards together, BEFORE the timed region: " + how,
+                                   "seeds": sorted(per_seed), "checks": {str(k): v for k, v in sorted(per_seed.items())}})
+            dist.broadcast_object_list(verdict, src=0)
+            pre_verification = verdict[0]
+            if pre_verification is not None and not pre_verification[0]:
+                if rank == 0:
+                    print(json.dumps({"metric": "ray-surface intersections/sec, 1M-ray biconvex lens", "value": None, "n_gpus": world,
+                                      "verified": False, "verification": pre_verification[1]}), flush=True)
+                dist.barrier()
+                dist.destroy_process_group()
+                raise SystemExit("bench.py: the shards' rows do NOT match the reference's summary: nothing was timed")
     spinup_steps = 0
     t_spin = time.perf_counter()
     while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
@@ -393,38 +513,79 @@ def main():
         spinup_steps += 4
     rows, counts = run_steps(max(args.warmup, 1)) if args.warmup else step()
     if mode == "overlap" and not args.python_loop:
-        prepared_batch(args.steps)
-    torch.cuda.synchronize(device)
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    timed = Totals()
-    rows, counts = run_steps(args.steps, timed)
-    torch.cuda.synchronize(device)
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    elapsed = time.perf_counter() - t0
+        prepared_batch(args.steps).run()  # (untimed: the region's job table and its pool of HIP events exist from here on)
+    # ---- the timed region: --steps steps between barrier + synchronize, --reps times; the median repetition is the line
+    repetitions = []
+    for _ in range(max(1, args.reps)):
+        torch.cuda.synchronize(device)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        region = Totals()
+        rows, counts = run_steps(args.steps, region)
+        torch.cuda.synchronize(device)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        region.elapsed = time.perf_counter() - t0
+        repetitions.append(region)
+    if distributed:  # a repetition takes as long as its slowest rank
+        slowest = torch.tensor([r.elapsed for r in repetitions], dtype=torch.float64, device=comm_device)
+        dist.all_reduce(slowest, op=dist.ReduceOp.MAX)
+        for r, took in zip(repetitions, slowest.tolist()):
+            r.elapsed = took
+    # the rows the LAST repetition's last steps left: one step per ray set of the rotation (verified further down,
+    # before anything else records into those blocks)
+    last_timed = {}
+    if mode == "overlap" and not args.python_loop:
+        done = prepared_batch(args.steps)
+        for k in range(max(0, args.steps - len(ray_sets)), args.steps):
+            last_timed[k % len(ray_sets)] = done.result(k)
+    verifiable = verifiable_job
+    if verifiable and world == 1:  # to the host now (one DMA each); looked at behind the side measurements
+        last_timed = {k: (engine.to_host(r).T, c) for k, (r, c) in last_timed.items()}
+    by_time = sorted(repetitions, key=lambda r: r.elapsed)
+    timed = by_time[(len(by_time) - 1) // 2]  # the median (the faster of the middle two for an even count)
+    elapsed = timed.elapsed
     ray_generations, rows_recorded, rays_carried = timed.ray_generations, timed.rows_recorded, timed.rays_carried
     launches = timed.launches
-    # The generation kernel's own duration -- what the roofline prices -- is measured on ONE stream: with
-    # traces overlapping on the device the HIP events around a trace's launches also see the other trace's
-    # kernels (each launch looks ~1.6x longer while two run side by side).  Same steps, same process, right
-    # behind the timed region; `value` stays the overlapped throughput.
-    kernel_region = timed
+    # What the roofline prices is the timed region itself.  Overlapped traces (prt_trace_batch): every trace carries
+    # its own pair of HIP events on its own stream and the library merges the intervals -- `kernel_ms` is the time the
+    # device had at least one of the region's traces in flight.  One stream / synchronous: the HIP-event time of the
+    # traces' launches (prt_trace_stats), which do not overlap.
+    busy = timed.busy if (mode == "overlap" and timed.busy and timed.busy["traces"] > 0) else None
+    if busy is not None:
+        kernel_ms, kernel_launches = busy["union_ms"], launches
+    else:
+        kernel_ms, kernel_launches = timed.kernel_ms, launches
+    # The generation kernel with the device to itself -- what `rocprofv3 --stats` averages when the same steps run on
+    # one stream -- right behind the timed region (same process, same clocks): `roofline.one_stream`.
+    def respin(how=None):
+        """The GPU has been idle while the host looked at something (a copy to the host, a scene being built): untimed
+        steps until the clocks are back up, as in front of the timed region."""
+        r0 = time.perf_counter()
+        while (time.perf_counter() - r0) * 1e3 < args.spinup_ms:
+            run_steps(4, how=how)
+        torch.cuda.synchronize(device)
+
     one_stream = None
     if mode == "overlap":
+        respin("one_stream")
         run_steps(3, how="one_stream")
         torch.cuda.synchronize(device)
-        kernel_region = Totals()
+        alone = Totals()
         k0 = time.perf_counter()
-        run_steps(args.steps, kernel_region, how="one_stream")
+        run_steps(args.steps, alone, how="one_stream")
         torch.cuda.synchronize(device)
-        one_stream = {"ms_per_step": (time.perf_counter() - k0) / args.steps * 1e3,
-                      "kernel_ms_per_step": kernel_region.kernel_ms / args.steps, "rows": kernel_region.rows_returned}
+        alone_s = time.perf_counter() - k0
+        one_stream = {"ms_per_step": alone_s / args.steps * 1e3, "kernel_ms_per_step": alone.kernel_ms / args.steps,
+                      "avg_launch_ms": alone.kernel_ms / alone.launches if alone.launches else 0.0,
+                      "rows": alone.rows_returned,
+                      "_bytes": 104.0 * alone.ray_generations + 120.0 * alone.rows_recorded + 104.0 * alone.rays_carried}
+        if busy is None:  # (--python-loop: no merged intervals; the one-stream figures stand in, and the line says so)
+            kernel_ms, kernel_launches = alone.kernel_ms, alone.launches
         run_steps(2)
-    kernel_ms, kernel_launches = kernel_region.kernel_ms, kernel_region.launches
 
     # side measurements (untimed region, every rank so that the ranks stay in step): the same step
     # (a) synchronous: one trace at a time through prt_trace, host and GPU strictly alternating;
@@ -436,6 +597,7 @@ def main():
     def side(label, fn, count):
         if count <= 0:
             return None
+        respin()
         fn(3)
         torch.cuda.synchronize(device)
         tot = Totals()
@@ -494,29 +656,30 @@ def main():
         cold = {"ms": min(cold_times) * 1e3, "rows_per_s_this_gpu": cold_count / min(cold_times),
                 "what": "DeviceScene(snapshot) + its first trace (no hints, control words initialised), best of 3; "
                         "kernels already loaded by this process"}
-    rows, counts = run_steps(1, how="sync", rotate=False)  # the BASELINE ray set (seed 1234): verified below
-
-    # --- in-run correctness tie: the rows of the timed workload against the reference's own summary of it -----
-    verified, verify_note = None, "only BASELINE config 2 at 1M rays, generation_limit 10, on one GPU has a reference summary"
-    summary_file = os.path.join(ROOT, "tests", "golden", "config2_1m_summary.npz")
-    if (args.workload == "config2" and world == 1 and n == RAYS_PER_GPU and limit == GENERATION_LIMIT
-            and os.path.exists(summary_file)):
-        want = np.load(summary_file)
-        frame = engine.to_host(rows).T
-        gens, surf = frame[:, 0].astype(np.int64), frame[:, 5].astype(np.int64)
-        checks = {"rows": frame.shape[0] == int(want["rows"])}
-        if checks["rows"]:
-            pairs, pair_counts = np.unique(np.stack((gens, surf)), axis=1, return_counts=True)
-            checks["rows_per_generation_x_surface"] = (np.array_equal(pairs, want["gen_surface_pairs"]) and
-                                                       np.array_equal(pair_counts, want["gen_surface_counts"]))
-            checks["q5_ids"] = np.array_equal(frame[(gens == 1) & (surf == surf.max()), 4].astype(np.int64), want["q5_ids"])
-            checks["surface_checksum"] = int((surf * (gens + 1)).sum()) == int(want["surface_checksum"])
-            checks["column_sums"] = bool(np.allclose(frame.sum(axis=0), want["column_sums"], rtol=1e-9, atol=1e-3))
-            checks["sample_rows_1e-6"] = bool(np.allclose(frame[want["sample_index"]], want["sample_rows"], rtol=0, atol=1e-6))
-        verified = all(checks.values())
-        verify_note = {"against": "tests/golden/config2_1m_summary.npz (written by the genuine reference, "
-                                  "tests/golden/generate_golden.py config2_summary)", "checks": checks}
-        del frame
+    # --- in-run correctness tie: the rows of the timed workload against the reference's own summaries of it ---------
+    # One GPU: the rows the last timed step of EACH ray set of the rotation left in its record block (brought to the
+    # host right behind the timed region).  Several GPUs: checked before the timed region, see `pre_verification`.
+    verified, verify_note = None, ("only BASELINE config 2 at 1M rays, generation_limit 10 (strong scaling) has "
+                                   "reference summaries")
+    if verifiable and world == 1:
+        per_seed, what = {}, "the last timed step of each ray set (rows of the timed region's final repetition)"
+        if not last_timed:  # (issue modes that do not keep a block per ray set: a synchronous trace of each set instead)
+            what = "a synchronous trace of each ray set behind the timed region (this issue mode keeps no block per ray set)"
+            for k in range(len(ray_sets)):
+                got, got_counts = scene.trace(ray_sets[k], limit, flags=args.flags)
+                last_timed[k] = (engine.to_host(got).T, got_counts)
+        for k, (frame, _) in sorted(last_timed.items()):
+            seed = base_seed + k
+            if os.path.exists(summary_file(seed)):
+                per_seed[seed] = summary_checks(frame, np.load(summary_file(seed)))
+        if per_seed:
+            verified = all(all(c.values()) for c in per_seed.values())
+            verify_note = {"against": "tests/golden/config2_1m_summary*.npz (written by the genuine reference, "
+                                      "tests/golden/generate_golden.py config2_summary)", "of": what,
+                           "seeds": sorted(per_seed), "checks": {str(k): v for k, v in sorted(per_seed.items())}}
+        last_timed.clear()
+    elif pre_verification is not None:
+        verified, verify_note = pre_verification
     rows, counts = run_steps(2)  # (leave the scene with the hints of the rotation for what follows)
 
     rows_per_step = int(rows.shape[1])
@@ -554,7 +717,7 @@ def main():
     gather = None
     if distributed:
         try:  # an extra: its failure must not cost the benchmark line
-            comm = pdist.LibraryComm.from_group(dist.group.WORLD, device) if backend == "nccl" else None
+            comm = bench_comm  # (the library's RCCL communicator made before the timed region; None on a gloo group)
             times = []
             for _ in range(3):  # the first pass also builds RCCL's channels
                 torch.cuda.synchronize(device)
@@ -581,10 +744,28 @@ def main():
             gather["stats_ms"] = float(agg[0])
             gather["stats_transport"] = ("ncclAllReduce inside libprt_hip (prt_frame_stats_sharded)" if comm is not None
                                          else f"torch.distributed {backend} between prt_frame_reduce passes")
+            # ... and the re-assembly PIPELINED behind the traces: the frame of trace k is gathered on a communication
+            # stream while trace k + 1 runs (pyrayt_amd.distributed.trace_and_gather): the steady state of a loop that
+            # wants every frame whole on every GPU
             if comm is not None:
+                piped = []
+                for _ in range(2):
+                    torch.cuda.synchronize(device)
+                    dist.barrier()
+                    p0 = time.perf_counter()
+                    frames = 0
+                    for full, _ in pdist.trace_and_gather(scene, (ray_set(k) for k in range(args.steps)), limit, comm,
+                                                          flags=args.flags):
+                        frames += 1
+                    torch.cuda.synchronize(device)
+                    dist.barrier()
+                    piped.append((time.perf_counter() - p0) / max(frames, 1))
+                agg = torch.tensor([min(piped)], dtype=torch.float64, device=comm_device)
+                dist.all_reduce(agg, op=dist.ReduceOp.MAX)
+                gather["pipelined_ms_per_step"] = float(agg[0]) * 1e3
                 comm.close()
         except Exception as exc:  # noqa: BLE001
-            gather = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            gather = dict(gather or {}, error=f"{type(exc).__name__}: {exc}"[:300])
     result_sink = None
     if not distributed:
         try:
@@ -595,7 +776,9 @@ def main():
 
     # PCIe-inclusive end-to-end trace() on rank 0 (H2D rays, trace, D2H rows, DataFrame)
     end_to_end = None
-    if rank == 0:
+    if rank == 0 and float(n) * limit * 120 > 16e9:
+        end_to_end = {"skipped": "the frame of this job is tens of GB: not brought to the host three times for a side figure"}
+    elif rank == 0:
         from pyrayt_amd.tracer import rows_to_frame
 
         try:
@@ -699,6 +882,7 @@ def main():
             "rays_per_gpu": n,
             "devices_visible_per_rank_process": n_devices,
             "dist_backend": backend if distributed else None,
+            "rccl_ranks": rccl_ranks,  # ncclCommCount of the library's communicator (None on one GPU / a gloo group)
             "rows_per_step_per_gpu": rows_per_step,
             "rows_per_generation": counts,
             # secondary metric of SURVEY.md section 8d: rays alive at generation entry x primitives
@@ -722,9 +906,15 @@ def main():
             "traffic_source": traffic_note,
             "library_sha16": library_sha16,
             "kernel": "k_generation" if not (args.flags & 2) else "k_hit + k_scan + k_shade + k_advance",
-            "measured_on": ("one stream, the same steps right behind the timed region (HIP events per trace; with "
-                            "traces overlapping on the device an event pair also sees the other trace's kernels)"
-                            if mode == "overlap" else "the timed region (HIP events per trace on the launch stream)"),
+            "measured_on": ("the timed region (its median repetition): every trace bracketed by its own pair of HIP events on "
+                            "its own stream, intervals merged by the library (PRT_TRACE_BUSY / prt_trace_batch_busy) -- "
+                            "kernel_ms_per_step is the time per step during which at least one of the region's traces "
+                            "had launches in flight, avg_launch_ms that time per generation launch; the kernel with the "
+                            "device to itself is `one_stream`"
+                            if busy is not None else
+                            "one stream, the same steps right behind the timed region (HIP events per trace): this issue "
+                            "mode has no merged intervals" if mode == "overlap" else
+                            "the timed region (HIP events per trace on the launch stream; the traces do not overlap)"),
             "algorithmic_bytes_per_launch": algorithmic_bytes / launches if launches else 0,
             "avg_launch_ms": kernel_ms / kernel_launches if kernel_launches else 0,
             "launches_per_step": launches / args.steps,
@@ -742,12 +932,26 @@ def main():
                                                          "state form transfers"},
             "bytes_per_ray_generation_if_all_survive": BYTES_PER_RAY_GENERATION,
             "moved_bytes_per_launch": moved_bytes / launches if launches else 0,
-            "one_stream_region": one_stream,
+            # the traces' own intervals before merging: their sum per launch is what one launch takes on its stream while
+            # another trace shares the device (about what `rocprofv3 --stats` averages for the overlapped command)
+            "busy": None if busy is None else dict(busy, avg_launch_ms_on_its_stream=busy["sum_ms"] / launches if launches else 0.0),
+            "one_stream": one_stream,
             "moved_frac": moved_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms > 0 else 0.0,
             "state_rows": "all 13" if full_rows else "10 of 13 between generations (w rows and generation row implied)",
         },
         "end_to_end_trace": end_to_end,
     }
+    # every repetition of the timed region (`value` / `ms_per_step` are the median one's)
+    line["repetitions"] = {"n": len(repetitions), "ms_per_step": [r.elapsed / args.steps * 1e3 for r in repetitions],
+                           "value_min": rows_timed / max(r.elapsed for r in repetitions),
+                           "value_max": rows_timed / min(r.elapsed for r in repetitions),
+                           "kernel_ms_per_step": [r.busy["union_ms"] / args.steps if r.busy else None for r in repetitions]}
+    if one_stream:
+        bytes_alone = one_stream.pop("_bytes")
+        gbs = bytes_alone / (one_stream["kernel_ms_per_step"] * args.steps * 1e-3) / 1e9 if one_stream["kernel_ms_per_step"] > 0 else 0.0
+        one_stream["achieved"], one_stream["frac"] = gbs, gbs / HBM_PEAK_GBS
+        one_stream["what"] = ("the same steps on ONE stream right behind the timed region: the generation kernel with the device to "
+                              "itself (HIP events per trace; compare rocprofv3 --stats of `bench.py --streams 1`)")
 
     # the other kinds of step (this rank's GPU; untimed side runs of --side-steps traces each)
     def publish(kind):
@@ -797,8 +1001,10 @@ def main():
         line["result_sink"] = result_sink
     if gather:
         line["gather"] = gather
-        if "ms" in gather:
+        if "ms" in gather:  # a trace, then its re-assembly, one after the other
             line["value_with_gather"] = total_rows_per_step / (elapsed / args.steps + gather["ms"] * 1e-3)
+        if "pipelined_ms_per_step" in gather:  # re-assembly of trace k behind trace k + 1: the steady state
+            line["value_with_gather_pipelined"] = total_rows_per_step / (gather["pipelined_ms_per_step"] * 1e-3)
 
     if not args.no_cpu_baseline and world == 1:
         from oracle import prt_oracle

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PRT_VERSION 200 /* 0.2.0: prt_interact takes the caller-shaded state, PRT_MAT_TABLE / PRT_MAT_HOST,
+#define PRT_VERSION 210 /* 0.2.1: prt_frame_mean_square, PRT_TRACE_BUSY / prt_trace_batch_busy, prt_comm_info.  0.2.0: prt_interact takes the caller-shaded state, PRT_MAT_TABLE / PRT_MAT_HOST,
                            prt_scene_set_index_tables, prt_gather_hits / prt_scatter_shaded, prt_unique_values,
                            prt_frame_stats_sharded / prt_frame_pivots / prt_frame_finish, prt_trace_telemetry fills 12 slots.  A caller built against another version must not load this library:
                            prt_version() is there to be compared with this constant (pyrayt_amd.engine.library does). */
@@ -327,6 +327,7 @@ int prt_generate_rays(int device, const prt_source* source, int64_t n_total, int
                                      trace, which is most of what a 125k-ray trace costs the host */
 #define PRT_TRACE_NO_TILE_RECORDS 512 /* do not run compacting generations on the per-tile records of the ticket's
                                      previous trace (they then run their look-back, as in a first trace); A/B, tests */
+#define PRT_TRACE_BUSY 2048         /* prt_trace_batch only: bracket every job's launches with a pair of HIP events of its own (on the job's stream) and merge the intervals behind the batch: prt_trace_batch_busy */
 #define PRT_TRACE_NO_SPARSE_KEEP 1024 /* do not launch sparse-loss generations dense with their absorbed rays kept
                                      (see prt_trace_telemetry); A/B, tests */
 #define PRT_TRACE_COUNT_PATHS 128 /* count, in prt_trace_telemetry, the rays that are not well formed and
@@ -377,6 +378,14 @@ typedef struct prt_trace_job {
 } prt_trace_job;
 int64_t prt_trace_batch(prt_scene* scene, int device, prt_trace_job* jobs, int64_t count, int generation_limit,
                         double ray_offset, int depth, void* const* workspaces, void* const* streams, int flags);
+/* What the last prt_trace_batch of this scene on `device` that was given PRT_TRACE_BUSY measured (for bench.py's
+ * roofline: traces in flight together overlap on the device, so the sum of their kernel times says nothing about
+ * the region): out4[0] = milliseconds during which at least one of the batch's traces had launches in flight -- the
+ * union of the jobs' [first launch enqueued ... last launch finished] intervals, HIP events on each job's own
+ * stream --, out4[1] = the sum of those intervals, out4[2] = how many there were, out4[3] = from the earliest
+ * start to the latest end.  Zeros if no such batch ran.  (A job that had to repeat an attempt is represented by its
+ * last attempt.) */
+int prt_trace_batch_busy(const prt_scene* scene, int device, double* out4);
 
 /* ---- frame re-assembly across the GPUs of a node ----------------------------
  * No counterpart upstream (pyrayt/_pyrayt.py:329-339 is one Python thread).  Rank r traces the
@@ -397,6 +406,8 @@ typedef struct prt_comm prt_comm;
 int prt_comm_unique_id(char* id128);
 int prt_comm_create(int device, int world, int rank, const char* id128, prt_comm** out);
 void prt_comm_destroy(prt_comm* comm);
+/* what RCCL reports about the communicator: out3 = { ncclCommCount, ncclCommUserRank, device } */
+int prt_comm_info(const prt_comm* comm, int* out3);
 int prt_allgather_counts(prt_comm* comm, const int64_t* counts_local, int limit, int64_t* counts_all,
                          void* stream);
 int64_t prt_allgather_workspace_bytes(int world, int limit, int64_t pad_rows);

@@ -22,6 +22,8 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
@@ -43,6 +45,8 @@ static int rccl_load() {
   api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
   api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
   api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+  api.CommCount = (decltype(api.CommCount))dlsym(h, "ncclCommCount");
+  api.CommUserRank = (decltype(api.CommUserRank))dlsym(h, "ncclCommUserRank");
   api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
   api.AllReduce = (decltype(api.AllReduce))dlsym(h, "ncclAllReduce");
   api.GroupStart = (decltype(api.GroupStart))dlsym(h, "ncclGroupStart");
@@ -110,6 +114,18 @@ extern "C" int prt_comm_create(int device, int world, int rank, const char* id12
     return fail(PRT_ERR_HIP, "communicator buffers");
   }
   *out = c;
+  return PRT_OK;
+}
+
+// What RCCL itself says about the communicator (not what the caller asked for): out3 = ranks in it (ncclCommCount),
+// this process's rank (ncclCommUserRank), the device it was made on.  For run records: a bench line that claims N
+// GPUs shows that RCCL saw N ranks.
+extern "C" int prt_comm_info(const prt_comm* c, int* out3) {
+  if (!c || !out3) return fail(PRT_ERR_ARG, "null argument");
+  if (!g_rccl.CommCount || !g_rccl.CommUserRank) return fail(PRT_ERR_HIP, "librccl lacks ncclCommCount / ncclCommUserRank");
+  RCCL_TRY(g_rccl.CommCount(c->comm, &out3[0]));
+  RCCL_TRY(g_rccl.CommUserRank(c->comm, &out3[1]));
+  out3[2] = c->device;
   return PRT_OK;
 }
 

@@ -70,6 +70,7 @@ struct TraceTicket {
   unsigned long long epoch = 0;                 // number of batches published so far
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timing_pending = false;                  // ev0..ev1 of the last batch not yet added to stats[2]
+  hipEvent_t busy0 = nullptr, busy1 = nullptr;  // PRT_TRACE_BUSY: this trace's own pair (prt_trace_batch lends them)
   // control words already initialised on the stream for a next trace of this shape (see fused_start)
   const void* ready_workspace = nullptr;
   int64_t ready_n = -1;
@@ -92,6 +93,8 @@ struct DeviceCopy {
   DevInstr* render_code = nullptr;              // same with the renderers' selection rule
   std::vector<DevInstr*> component_code;        // one program per component, no I_ROOT
   TraceTicket ticket[PRT_TRACE_TICKETS];
+  std::vector<hipEvent_t> busy_events;          // PRT_TRACE_BUSY: two per job of the largest batch so far (kept, reused)
+  double busy[4] = {0, 0, 0, 0};                // prt_trace_batch_busy: what the last such batch measured
   bool ready = false;                           // everything above is in place (a copy whose upload failed half way is not)
 };
 
@@ -978,7 +981,9 @@ static void release_device_copy(DeviceCopy& c) {
     if (t.mirror) (void)hipHostFree(t.mirror);
     if (t.ev0) (void)hipEventDestroy(t.ev0);
     if (t.ev1) (void)hipEventDestroy(t.ev1);
+    t.busy0 = t.busy1 = nullptr;
   }
+  for (hipEvent_t e : c.busy_events) (void)hipEventDestroy(e);
   c = DeviceCopy();
 }
 

@@ -213,6 +213,9 @@ static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
   const unsigned long long epoch = ++t->epoch;
   const bool timed = !(t->flags & PRT_TRACE_NO_TIMING);
   if (timed) HIP_TRY(hipEventRecord(t->ev0, st));
+  // PRT_TRACE_BUSY: the trace's own pair, from in front of its first launch to behind its last (a further batch, or a
+  // repeated attempt, moves the end -- resp. both -- along)
+  if (t->busy0 && t->g == 0) HIP_TRY(hipEventRecord(t->busy0, st));
   HP(3);
   const bool culls = s->has_cull_steps;
   auto kernel = t->compact ? (culls ? k_generation<true, true> : k_generation<false, true>)
@@ -292,6 +295,7 @@ static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
                        t->limit, tiles[0], (int64_t)blocks_for(n), n, t->test_stall, t->mirror_dev, epoch,
                        t->g, t->batch + 1);
   }
+  if (t->busy1) HIP_TRY(hipEventRecord(t->busy1, st));
   HIP_TRY(hipGetLastError());
   HP(5);
   t->launched = true;
@@ -658,6 +662,17 @@ extern "C" int64_t prt_trace_batch(prt_scene* s, int device, prt_trace_job* jobs
   }
   for (int k = 0; k < depth; ++k)
     if (c->ticket[k].active) return fail(PRT_ERR_ARG, "a ticket this batch needs has a trace in flight");
+  // PRT_TRACE_BUSY: every job gets a pair of HIP events of its own around its launches, on its stream; behind the
+  // batch the intervals are merged -- how long the device had at least one of the batch's traces in flight
+  const bool busy = (flags & PRT_TRACE_BUSY) != 0 && count > 0;
+  if (busy) {
+    while ((int64_t)c->busy_events.size() < 2 * count) {
+      hipEvent_t e = nullptr;
+      HIP_TRY(hipEventCreate(&e));
+      c->busy_events.push_back(e);
+    }
+    for (double& v : c->busy) v = 0;
+  }
   int64_t sum = 0, first_error = 0;
   std::string message;
   for (int64_t k = 0; k < count + depth; ++k) {
@@ -670,13 +685,54 @@ extern "C" int64_t prt_trace_batch(prt_scene* s, int device, prt_trace_job* jobs
     }
     if (k < count && !first_error) {  // (after an error nothing new is started; what is in flight is collected)
       const prt_trace_job& job = jobs[k];
+      c->ticket[lane].busy0 = busy ? c->busy_events[2 * k] : nullptr;
+      c->ticket[lane].busy1 = busy ? c->busy_events[2 * k + 1] : nullptr;
       rc = prt_trace_begin(s, device, lane, job.rays, job.n, job.ld, generation_limit, ray_offset, job.rows_out,
                            job.rows_cap, workspaces[lane], flags, streams ? streams[lane] : nullptr);
       if (rc) { jobs[k].total = rc; first_error = rc; message = g_error; }
     }
   }
+  for (int k = 0; k < depth; ++k) c->ticket[k].busy0 = c->ticket[k].busy1 = nullptr;
   if (first_error) return fail((int)first_error, message.c_str());
+  if (busy) {
+    // intervals relative to the first job's start (a float of milliseconds resolves ~2 ns over a 30 ms region)
+    std::vector<std::pair<double, double>> spans;
+    for (int64_t k = 0; k < count; ++k) {
+      if (jobs[k].n == 0 || generation_limit == 0) continue;  // (nothing was launched for it)
+      HIP_TRY(hipEventSynchronize(c->busy_events[2 * k + 1]));
+      float t0 = 0, t1 = 0;
+      HIP_TRY(hipEventElapsedTime(&t0, c->busy_events[0], c->busy_events[2 * k]));
+      HIP_TRY(hipEventElapsedTime(&t1, c->busy_events[0], c->busy_events[2 * k + 1]));
+      spans.emplace_back((double)t0, (double)t1);
+    }
+    std::sort(spans.begin(), spans.end());
+    double merged = 0, each = 0, open_from = 0, open_to = 0;
+    bool open = false;
+    for (const auto& sp : spans) {
+      each += sp.second - sp.first;
+      if (open && sp.first <= open_to) { open_to = std::max(open_to, sp.second); continue; }
+      if (open) merged += open_to - open_from;
+      open = true; open_from = sp.first; open_to = sp.second;
+    }
+    if (open) merged += open_to - open_from;
+    c->busy[0] = merged;
+    c->busy[1] = each;
+    c->busy[2] = (double)spans.size();
+    double first = 0, last = 0;
+    for (size_t k = 0; k < spans.size(); ++k) {
+      first = k ? std::min(first, spans[k].first) : spans[k].first;
+      last = k ? std::max(last, spans[k].second) : spans[k].second;
+    }
+    c->busy[3] = last - first;
+  }
   return sum;
+}
+
+extern "C" int prt_trace_batch_busy(const prt_scene* s, int device, double* out4) {
+  if (!s || !out4) return fail(PRT_ERR_ARG, "null argument");
+  if (device < 0 || device >= (int)s->per_device.size()) return fail(PRT_ERR_ARG, "no trace of this scene ran on that device");
+  for (int k = 0; k < 4; ++k) out4[k] = s->per_device[device].busy[k];
+  return PRT_OK;
 }
 
 

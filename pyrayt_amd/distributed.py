@@ -69,16 +69,54 @@ class LibraryComm:
     ``LibraryComm.from_group(group, device)`` bootstraps it over an initialised
     ``torch.distributed`` group of any backend: rank 0 draws the id, everybody receives it."""
 
-    def __init__(self, device, world, rank, unique_id):
+    INIT_TIMEOUT_S = 180.0  # how long ncclCommInitRank may take before the rank gives up (all ranks must arrive)
+
+    def __init__(self, device, world, rank, unique_id, timeout=None):
+        """timeout (seconds, default INIT_TIMEOUT_S): ncclCommInitRank blocks until every rank of the communicator has
+        called it -- a rank that died, was never started or sits on another id makes the others wait for ever.  The
+        call therefore runs on a helper thread and is abandoned with a clear error when the time is up (the process is
+        then expected to exit: the thread cannot be cancelled)."""
+        import threading
+
         from . import engine
 
         self._lib = engine.library()
         self.world, self.rank = int(world), int(rank)
         self.device = torch.device("cuda", device) if isinstance(device, int) else device
         self._handle = ctypes.c_void_p()
-        engine._check(self._lib.prt_comm_create(self.device.index or 0, self.world, self.rank,
-                                                ctypes.c_char_p(bytes(unique_id)), ctypes.byref(self._handle)))
         self._work = None
+        limit = self.INIT_TIMEOUT_S if timeout is None else float(timeout)
+        handle, outcome = ctypes.c_void_p(), {}
+
+        def create():
+            try:
+                outcome["rc"] = self._lib.prt_comm_create(self.device.index or 0, self.world, self.rank,
+                                                          ctypes.c_char_p(bytes(unique_id)), ctypes.byref(handle))
+                outcome["message"] = self._lib.prt_last_error().decode("utf-8", "replace")
+            except BaseException as exc:  # noqa: BLE001
+                outcome["exc"] = exc
+
+        worker = threading.Thread(target=create, name="prt_comm_create", daemon=True)
+        worker.start()
+        worker.join(limit)
+        if worker.is_alive():
+            raise TimeoutError(f"rank {self.rank} of {self.world}: ncclCommInitRank did not return within {limit:.0f} s -- not "
+                               "every rank of the communicator called it (a rank that failed earlier, fewer processes than "
+                               "WORLD_SIZE, ranks holding different unique ids, or no path between the GPUs: check "
+                               "HSA_ENABLE_IPC_MODE_LEGACY=0 and NCCL_DEBUG=INFO)")
+        if "exc" in outcome:
+            raise outcome["exc"]
+        if outcome["rc"] < 0:  # (the error text is thread-local to the helper: carried over by hand)
+            raise RuntimeError(f"libprt_hip error {outcome['rc']}: {outcome['message']}")
+        self._handle = handle
+
+    def info(self):
+        """What RCCL reports about the communicator (``prt_comm_info``): ranks in it, this rank, device."""
+        from . import engine
+
+        out = (ctypes.c_int * 3)()
+        engine._check(self._lib.prt_comm_info(self._handle, out))
+        return {"ranks": int(out[0]), "rank": int(out[1]), "device": int(out[2])}
 
     @staticmethod
     def unique_id():
@@ -89,14 +127,16 @@ class LibraryComm:
         return buf.raw
 
     @classmethod
-    def from_group(cls, group, device):
+    def from_group(cls, group, device, timeout=None):
+        """Bootstrap over an initialised ``torch.distributed`` group (any backend): rank 0 draws the 128-byte id,
+        everybody receives it, every rank creates -- within ``timeout`` seconds (see ``__init__``) or not at all."""
         import torch.distributed as dist
 
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         box = [cls.unique_id() if rank == 0 else None]
         src = dist.get_global_rank(group, 0) if hasattr(dist, "get_global_rank") else 0
         dist.broadcast_object_list(box, src=src, group=group)
-        return cls(device, world, rank, box[0])
+        return cls(device, world, rank, box[0], timeout=timeout)
 
     def close(self):
         if self._handle:
@@ -250,3 +290,77 @@ def assemble_rows(rows, counts, generation_limit, group=None, gather="all", comm
     if on_gpu:
         return _place_on_device(blocks.to(rows.device).contiguous(), matrix_host, limit, total), merged_counts
     return _place_with_torch(list(blocks.unbind(0)), matrix_host, total), merged_counts
+
+
+def trace_and_gather(scene, ray_sets, generation_limit, comm, depth=2, flags=0, ray_offset=1e-6):
+    """Trace a sequence of (this rank's shards of) ray sets and re-assemble every frame on every rank, with the
+    re-assembly of frame k running behind trace k + 1: traces go out on the scene's ticket streams (``depth`` in
+    flight), the RCCL all-gathers and the placement kernel of ``prt_allgather_rows`` on a communication stream of their
+    own.  At N = 8 the gather of the north-star job moves 315 MB into every GPU and takes several times as long as the
+    trace; pipelined, a loop that wants whole frames pays max(trace, gather) per step instead of their sum.
+
+    Yields ``(frame, rows_per_generation)`` per ray set, in order: ``frame`` is the whole (15, total) frame in reference
+    order on this rank's GPU, complete on the CURRENT stream when it is handed out (the generator makes the current
+    stream wait for the communication stream).  Frames are assembled into two blocks used in turn: frame k is
+    overwritten when frame k + 2 is asked for.  Collective: every rank iterates, with ray sets of the same count.
+    The one host synchronisation per step is the all-gather of the small count matrix (the ranks must agree on the
+    frame's layout)."""
+    from . import engine
+
+    torch_mod = torch
+    limit = int(generation_limit)
+    depth = max(1, min(int(depth), engine.TRACE_TICKETS))
+    device = comm.device
+    streams = scene.ticket_streams(device, depth)
+    comm_stream = getattr(comm, "_stream", None)
+    if comm_stream is None:
+        comm_stream = comm._stream = torch_mod.cuda.Stream(device)
+    blocks = [None] * (depth + 1)   # record blocks of the traces: one more than are in flight (a gather may still read one)
+    gathered = [None] * (depth + 1)  # event per record block: the gather that read it last has finished
+    frames = [None, None]
+    pending = []                     # (lane, slot) of traces begun and not yet collected
+    current = torch_mod.cuda.current_stream(device)
+    source = iter(ray_sets)
+    begun = 0
+
+    def begin_next():
+        nonlocal begun
+        try:
+            rays = next(source)
+        except StopIteration:
+            return False
+        lane, slot = begun % depth, begun % len(blocks)
+        need = max(rays.shape[1], 1) * limit
+        if blocks[slot] is None or blocks[slot].shape[1] < need:
+            blocks[slot] = torch_mod.empty((engine.RECORD_COLS, need), dtype=torch_mod.float64, device=device)
+        streams[lane].wait_stream(current)              # whatever produced the ray set
+        if gathered[slot] is not None:
+            streams[lane].wait_event(gathered[slot])    # the gather that last read this record block
+        scene.trace_begin(lane, rays, limit, blocks[slot], ray_offset=ray_offset, flags=flags, stream=streams[lane])
+        pending.append((lane, slot))
+        begun += 1
+        return True
+
+    for _ in range(depth):
+        if not begin_next():
+            break
+    k = 0
+    while pending:
+        lane, slot = pending.pop(0)
+        rows, counts = scene.trace_end(lane)
+        begin_next()                                    # trace k + depth goes out before frame k is assembled
+        with torch_mod.cuda.stream(comm_stream):
+            comm_stream.wait_stream(streams[lane])      # the rows are ordered on the ticket's stream
+            matrix = comm.gather_counts(counts, limit)  # (host sync of the communication stream only)
+            per_rank = matrix.sum(dim=1)
+            total = int(per_rank.sum())
+            which = k % 2
+            if frames[which] is None or frames[which].shape[1] < total:
+                frames[which] = torch_mod.empty((engine.RECORD_COLS, max(total, 1)), dtype=torch_mod.float64, device=device)
+            frame = comm.gather_rows(blocks[slot], matrix, limit, out=frames[which])
+            done = torch_mod.cuda.Event()
+            done.record(comm_stream)
+            gathered[slot] = done
+        current.wait_event(done)
+        yield frame, _merged_counts(matrix)
+        k += 1

@@ -17,7 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PRT_LIB", os.path.join(_HERE, "csrc", "libprt_hip.so"))
 
 
-from ._runtime import HW_QUEUES  # (set when the package is imported, before anything loads the HIP runtime)
+from . import _runtime
+from ._runtime import HW_QUEUES  # (set when the package is imported, before the HIP runtime initialises)
 
 RAY_ROWS = 13
 RECORD_COLS = 15
@@ -34,6 +35,7 @@ TRACE_COUNT_PATHS = 128
 TRACE_NO_TIMING = 256
 TRACE_NO_TILE_RECORDS = 512
 TRACE_NO_SPARSE_KEEP = 1024
+TRACE_BUSY = 2048
 TRACE_TICKETS = 4
 
 # prt_scene_options (include/prt.h): how a scene is compiled / which nearest-hit kernel serves
@@ -65,7 +67,7 @@ def options_record(options=None):
 ERR_ROWS_CAP = -4
 ERR_UNTRACABLE = -5
 ERR_WAVELENGTH = -6
-PRT_VERSION = 200  # include/prt.h: the ABI this binding was written for
+PRT_VERSION = 210  # include/prt.h: the ABI this binding was written for
 TABLE_KEEP_FACTOR, TABLE_KEEP_MIN = 4, 64  # index tables keep earlier wavelengths up to this multiple of a ray set's own
 UNIQUE_CAP = 4096  # distinct wavelengths looked for on the device before the host sorts the whole row
 
@@ -109,6 +111,7 @@ def _declare(lib):
         "prt_trace_begin": (c_int, [c_p, c_int, c_int, c_p, c_i64, c_i64, c_int, c_d, c_p, c_i64, c_p, c_int, c_p]),
         "prt_trace_end": (c_i64, [c_p, c_int, c_int, c_p]),
         "prt_trace_batch": (c_i64, [c_p, c_int, c_p, c_i64, c_int, c_d, c_int, c_p, c_p, c_int]),
+        "prt_trace_batch_busy": (c_int, [c_p, c_int, c_p]),
         "prt_trace_stats": (c_int, [c_p, c_p]),
         "prt_trace_telemetry": (c_int, [c_p, c_p]),
         "prt_generate_rays": (c_int, [c_int, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p]),
@@ -130,6 +133,7 @@ def _declare(lib):
         "prt_comm_unique_id": (c_int, [c_p]),
         "prt_comm_create": (c_int, [c_int, c_int, c_int, c_p, ctypes.POINTER(c_p)]),
         "prt_comm_destroy": (None, [c_p]),
+        "prt_comm_info": (c_int, [c_p, c_p]),
         "prt_allgather_counts": (c_int, [c_p, c_p, c_int, c_p, c_p]),
         "prt_allgather_workspace_bytes": (c_i64, [c_int, c_int, c_i64]),
         "prt_allgather_rows": (c_int, [c_p, c_p, c_i64, c_p, c_int, c_p, c_i64, c_p, c_p]),
@@ -155,11 +159,11 @@ EXPORTED_SYMBOLS = (
     "prt_scene_component_rows", "prt_scene_info", "prt_intersect", "prt_propagate", "prt_world_normals",
     "prt_material_trace", "prt_interact_workspace_bytes", "prt_interact", "prt_scene_set_index_tables",
     "prt_gather_hits", "prt_scatter_shaded", "prt_unique_workspace_bytes", "prt_unique_values",
-    "prt_trace_workspace_bytes", "prt_trace", "prt_trace_begin", "prt_trace_end", "prt_trace_batch", "prt_trace_stats", "prt_trace_telemetry", "prt_generate_rays",
+    "prt_trace_workspace_bytes", "prt_trace", "prt_trace_begin", "prt_trace_end", "prt_trace_batch", "prt_trace_batch_busy", "prt_trace_stats", "prt_trace_telemetry", "prt_generate_rays",
     "prt_camera_rays", "prt_render_hits", "prt_gooch_shade", "prt_gooch_mix", "prt_render",
     "prt_edge_workspace_bytes", "prt_edge_canvas", "prt_reflect", "prt_refract", "prt_binomial_root",
     "prt_smallest_positive_root", "prt_dot", "prt_array_csg", "prt_primitive_intersect",
-    "prt_primitive_normal", "prt_comm_unique_id", "prt_comm_create", "prt_comm_destroy",
+    "prt_primitive_normal", "prt_comm_unique_id", "prt_comm_create", "prt_comm_destroy", "prt_comm_info",
     "prt_allgather_counts", "prt_allgather_workspace_bytes", "prt_allgather_rows",
     "prt_place_workspace_bytes", "prt_place_rows", "prt_frame_reduce", "prt_frame_stats_workspace_bytes",
     "prt_frame_stats", "prt_frame_stats_sharded", "prt_frame_pivots", "prt_frame_finish", "prt_frame_mean_square",
@@ -606,18 +610,27 @@ class DeviceScene:
         runtime maps streams onto a handful of hardware queues -- four by default -- and two streams that
         land on one queue run their kernels one after the other, so a program should not keep making new ones)."""
         torch = _torch()
-        limit = 4 if HW_QUEUES == "late" else int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
-        if depth + 1 > limit and not getattr(DeviceScene, "_warned_queues", False):
-            DeviceScene._warned_queues = True
-            warnings.warn(f"{depth} traces in flight need {depth + 1} hardware queues (one is the null stream's) but the HIP "
-                          f"runtime has {limit}: streams that share a queue serialise.  Import pyrayt_amd before torch (it "
-                          "then sets GPU_MAX_HW_QUEUES=8) or set the variable yourself.", RuntimeWarning, stacklevel=3)
         made = getattr(self, "_ticket_streams", None)
         if made is None or made[0] != device:
             made = self._ticket_streams = (device, [])
         while len(made[1]) < depth:
             made[1].append(torch.cuda.Stream(device))
-        return made[1][:depth]
+        streams = made[1][:depth]
+        # more streams than the runtime's default of four hardware queues covers (one is the null stream's): fine when
+        # the queue setting was in place before the runtime initialised.  A user's own setting is taken at its word;
+        # one made late (_runtime: torch was imported first, and possibly used) is checked once, by running something
+        if depth + 1 > 4 and not getattr(DeviceScene, "_warned_queues", False):
+            if HW_QUEUES == "user":
+                short = depth + 1 > int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
+            else:
+                short = HW_QUEUES == "set-late" and not _runtime.queues_overlap(torch, streams, device)
+            if short:
+                DeviceScene._warned_queues = True
+                warnings.warn(f"{depth} traces in flight need {depth + 1} hardware queues (one is the null stream's) and the "
+                              "HIP runtime of this process has fewer: streams that share a queue serialise.  Set "
+                              "GPU_MAX_HW_QUEUES=8 before the first HIP call of the process (importing pyrayt_amd does, "
+                              "unless the runtime is already initialised).", RuntimeWarning, stacklevel=3)
+        return streams
 
     def _collect(self, torch, lane, streams):
         rows, counts = self.trace_end(lane)
@@ -948,6 +961,14 @@ class TraceBatch:
             current.wait_stream(stream)
         self.totals = self.jobs["total"].copy()
         return total
+
+    def busy(self):
+        """What a run with ``TRACE_BUSY`` in its flags measured (``prt_trace_batch_busy``): milliseconds the device
+        had at least one of the batch's traces in flight (``union_ms``), the sum of the traces' own intervals, how
+        many there were, and first start to last end."""
+        out = (ctypes.c_double * 4)()
+        _check(library().prt_trace_batch_busy(self.scene.handle, self.device.index or 0, out))
+        return {"union_ms": float(out[0]), "sum_ms": float(out[1]), "traces": int(out[2]), "span_ms": float(out[3])}
 
     def result(self, k):
         """(rows, counts) of ray set `k` in the last run."""

@@ -108,6 +108,66 @@ def test_rccl_leg_with_a_one_rank_communicator():
         comm.close()
 
 
+def test_communicator_reports_what_rccl_sees_and_gives_up_on_a_missing_rank():
+    """prt_comm_info = ncclCommCount / ncclCommUserRank (bench.py prints it as config.rccl_ranks); a communicator whose
+    other rank never arrives ends with a TimeoutError that says so, not with a hang (the attempt stays blocked on a helper
+    thread, so this runs in a process of its own that exits right away)."""
+    import subprocess
+    import sys
+
+    from pyrayt_amd import distributed as pdist
+
+    comm = pdist.LibraryComm(0, 1, 0, pdist.LibraryComm.unique_id())
+    try:
+        assert comm.info() == {"ranks": 1, "rank": 0, "device": 0}
+    finally:
+        comm.close()
+    code = ("import os, sys, torch\n"
+            "from pyrayt_amd import distributed as pdist\n"
+            "try:\n"
+            "    pdist.LibraryComm(0, 2, 0, pdist.LibraryComm.unique_id(), timeout=5)\n"
+            "    print('created')\n"
+            "except TimeoutError as exc:\n"
+            "    print('timeout:', 'ncclCommInitRank did not return' in str(exc))\n"
+            "sys.stdout.flush(); os._exit(0)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    done = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=300)
+    assert done.returncode == 0 and "timeout: True" in done.stdout, (done.stdout, done.stderr[-1500:])
+
+
+def test_gather_pipelined_behind_the_next_trace_gives_the_same_frames():
+    """pyrayt_amd.distributed.trace_and_gather: frame k is re-assembled on a communication stream while trace k + 1
+    runs.  With a one-rank RCCL communicator every assembled frame must be the trace's own rows, for ray sets that
+    differ from step to step (two frames are handed out from two blocks in turn)."""
+    from pyrayt_amd import distributed as pdist
+    from pyrayt_amd import engine
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    CountedObject.reset_ids()
+    sets = []
+    for seed in range(7):
+        CountedObject.reset_ids()
+        parts, rays = scenes.config2(scenes.product_api(), 20_000 + 1000 * (seed % 3), seed=40 + seed)
+        sets.append(torch.from_numpy(rays).to("cuda:0"))
+    scene = engine.DeviceScene(SceneSnapshot(parts))
+    want = []
+    for rays in sets:
+        rows, counts = scene.trace(rays, LIMIT)
+        want.append((rows.cpu().numpy().copy(), counts))
+    comm = pdist.LibraryComm(0, 1, 0, pdist.LibraryComm.unique_id())
+    try:
+        for depth in (1, 2, 3):
+            got = 0
+            for k, (frame, counts) in enumerate(pdist.trace_and_gather(scene, iter(sets), LIMIT, comm, depth=depth)):
+                assert counts == want[k][1], (depth, k)
+                assert np.array_equal(frame.cpu().numpy(), want[k][0]), (depth, k)
+                got += 1
+            assert got == len(sets)
+    finally:
+        comm.close()
+
+
 def test_placement_kernel_against_the_indexed_copy():
     """prt_place_rows == the torch placement on a ragged count matrix with empty segments."""
     from pyrayt_amd import distributed as pdist

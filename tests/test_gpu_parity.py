@@ -495,7 +495,8 @@ def test_device_frame_selections_match_pandas():
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,args,limit", [
     ("config3", (4_000_000,), 10),          # Cooke triplet, 12 primitives, 4M rays
-    ("config4", (1_000_000,), 10),          # prism, 8 wavelengths x 1M rays
+    ("config4", (1_000_000,), 10),          # prism, 8 wavelengths x 1M rays: one GPU's share of the job
+    ("config4", (8_000_000,), 4),           # ... and the WHOLE job on one GPU: 8 wavelengths x 8M = 64M rays, 192M rows (23 GB)
     ("config5", (2_000_000,), 10),          # 16M rays / 8 GPUs
     ("config5", (16_000_000,), 10),         # ... and all 16M of them on one GPU (the largest BASELINE job)
 ])
@@ -1066,6 +1067,43 @@ def test_ticket_edges_update_in_flight_bad_ticket_varying_sizes():
         assert counts_k == want_counts_k, k
         helpers.assert_frames_match(rows_k.T, want_k, what=f"trace_many set {k}")
     ds.close()
+
+
+def test_four_traces_in_flight_get_their_queues_whichever_import_came_first():
+    """This module imported torch before pyrayt_amd: the package set GPU_MAX_HW_QUEUES late, which the runtime honours
+    as long as no HIP call preceded it (profiles/r5/queue_probe.txt).  Four ticket streams must come without the
+    serialisation warning, and must really overlap; in a process where the setting came too late they warn."""
+    import os
+    import subprocess
+    import sys
+    import warnings as _warnings
+
+    from pyrayt_amd import _runtime
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    CountedObject.reset_ids()
+    parts, rays = scenes.config2(scenes.product_api(), 4096)
+    ds = engine.DeviceScene(SceneSnapshot(parts))
+    device = torch.device("cuda", 0)
+    if _runtime.HW_QUEUES != "user":
+        with _warnings.catch_warnings():
+            _warnings.simplefilter("error")
+            streams = ds.ticket_streams(device, 4)
+        assert len(streams) == 4 and _runtime.queues_overlap(torch, streams, device)
+    ds.close()
+    # a process that initialised the runtime before the package could ask: four streams on the default four queues
+    code = ("import os, sys, warnings; os.environ.pop('GPU_MAX_HW_QUEUES', None); import torch; torch.cuda.is_available();"
+            "sys.path.insert(0, 'tests'); import scenes; from pyrayt_amd import engine; from pyrayt_amd.scene import SceneSnapshot;"
+            "parts, _ = scenes.config2(scenes.product_api(), 64); ds = engine.DeviceScene(SceneSnapshot(parts));"
+            "warnings.simplefilter('error');\n"
+            "try:\n    ds.ticket_streams(torch.device('cuda', 0), 4); print(engine.HW_QUEUES, 'quiet')\n"
+            "except RuntimeWarning: print(engine.HW_QUEUES, 'warned')")
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    done = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+    assert done.returncode == 0, done.stderr[-1500:]
+    assert done.stdout.split()[-2:] == ["set-late", "warned"], done.stdout
 
 
 def test_trace_many_abandoned_midway_frees_its_tickets():
