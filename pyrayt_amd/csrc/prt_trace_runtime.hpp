@@ -697,12 +697,14 @@ extern "C" int64_t prt_trace_batch(prt_scene* s, int device, prt_trace_job* jobs
   if (busy) {
     // intervals relative to the first job's start (a float of milliseconds resolves ~2 ns over a 30 ms region)
     std::vector<std::pair<double, double>> spans;
+    int64_t base = -1;  // the first job that launched anything: every interval is measured from its start
     for (int64_t k = 0; k < count; ++k) {
-      if (jobs[k].n == 0 || generation_limit == 0) continue;  // (nothing was launched for it)
+      if (jobs[k].n == 0 || generation_limit == 0 || (flags & (PRT_TRACE_UNFUSED | PRT_TRACE_COUNT_PATHS))) continue;  // (no launch bracketed)
+      if (base < 0) base = k;
       HIP_TRY(hipEventSynchronize(c->busy_events[2 * k + 1]));
       float t0 = 0, t1 = 0;
-      HIP_TRY(hipEventElapsedTime(&t0, c->busy_events[0], c->busy_events[2 * k]));
-      HIP_TRY(hipEventElapsedTime(&t1, c->busy_events[0], c->busy_events[2 * k + 1]));
+      HIP_TRY(hipEventElapsedTime(&t0, c->busy_events[2 * base], c->busy_events[2 * k]));
+      HIP_TRY(hipEventElapsedTime(&t1, c->busy_events[2 * base], c->busy_events[2 * k + 1]));
       spans.emplace_back((double)t0, (double)t1);
     }
     std::sort(spans.begin(), spans.end());

@@ -1113,6 +1113,41 @@ def test_four_traces_in_flight_get_their_queues_whichever_import_came_first():
     assert done.stdout.split()[-2] == "set-late" and done.stdout.split()[-1] in ("quiet", "warned"), done.stdout
 
 
+def test_batch_reports_how_long_the_device_was_busy_with_it():
+    """PRT_TRACE_BUSY / prt_trace_batch_busy (bench.py's roofline): every job of a batch bracketed by its own pair of HIP
+    events on its own stream, the intervals merged by the library.  The union can never exceed first-start-to-last-end
+    nor the sum of the intervals; with two traces in flight the sum exceeds the union (they overlap); a job without
+    rays and the unfused path contribute nothing; the rows are the rows of a batch without the flag."""
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    CountedObject.reset_ids()
+    parts, rays = scenes.config2(scenes.product_api(), 200_000)
+    ds = engine.DeviceScene(SceneSnapshot(parts))
+    full = dev(rays)
+    sets = [full, full[:, :0], full[:, :150_000].contiguous(), full, full[:, :70_000].contiguous(), full]
+    plain = engine.TraceBatch(ds, sets, 10, depth=2)
+    plain.run()
+    want = [(r.cpu().numpy().copy(), c) for r, c in plain.results()]
+    timed = engine.TraceBatch(ds, sets, 10, depth=2, flags=engine.TRACE_BUSY | engine.TRACE_NO_TIMING)
+    for _ in range(3):
+        timed.run()
+        busy = timed.busy()
+        assert busy["traces"] == 5  # (the empty job launched nothing)
+        assert 0 < busy["union_ms"] <= busy["span_ms"] * (1 + 1e-6) and busy["union_ms"] <= busy["sum_ms"] * (1 + 1e-6)
+        assert busy["sum_ms"] > 1.05 * busy["union_ms"], busy  # two traces in flight do overlap
+        for (rows, counts), (want_rows, want_counts) in zip(timed.results(), want):
+            assert counts == want_counts and np.array_equal(rows.cpu().numpy(), want_rows)
+    one = engine.TraceBatch(ds, [full, full, full], 10, depth=1, flags=engine.TRACE_BUSY)
+    one.run()
+    alone = one.busy()
+    assert alone["traces"] == 3 and abs(alone["sum_ms"] - alone["union_ms"]) <= 1e-3 * alone["sum_ms"] + 1e-4  # one at a time
+    slow = engine.TraceBatch(ds, [full], 10, depth=1, flags=engine.TRACE_BUSY | engine.TRACE_UNFUSED)
+    slow.run()
+    assert slow.busy()["traces"] == 0
+    ds.close()
+
+
 def test_trace_many_abandoned_midway_frees_its_tickets():
     fx = helpers.load("scene_config2.npz")
     limit = int(fx["generation_limit"])

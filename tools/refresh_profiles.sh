@@ -12,8 +12,14 @@ rm -rf $out $R/gpurun_out/traffic $R/gpurun_out/sq; mkdir -p $out
 cd $R
 (cd tools/ubench && make -s copy_f64 >/dev/null 2>&1)
 python3 bench.py > $out/bench.json 2> $out/bench.err
+# ... and as the round driver launches it
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_form.json 2>> $out/bench.err
 cd /tmp
+# the same command under rocprofv3: per-kernel stats, and from the per-dispatch timestamps the UNION of the overlapping
+# k_generation dispatches (tools/busy_union.py) -- what roofline.kernel_ms_per_step / avg_launch_ms have to agree with
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace -- python3 $R/bench.py --no-cpu-baseline --side-steps 0 > $out/trace.log 2>&1
+python3 $R/tools/busy_union.py $(find $out -name "trace_kernel_trace.csv" | head -1) > $out/busy_union.txt 2>&1
+grep "^{" $out/trace.log | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('bench.py under rocprofv3 (this run): ms_per_step %.4f kernel_ms_per_step %.4f avg_launch_ms %.5f (= union / launches); its traces\' own intervals per launch %.5f; one stream %.5f' % (d['ms_per_step'], r['kernel_ms_per_step'], r['avg_launch_ms'], r['busy']['avg_launch_ms_on_its_stream'], r['one_stream']['avg_launch_ms']))" >> $out/busy_union.txt
 # the same steps on ONE stream: the generation kernel's own duration (what roofline.avg_launch_ms is measured on)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace_one_stream -- python3 $R/bench.py --no-cpu-baseline --side-steps 0 --streams 1 > $out/trace_one_stream.log 2>&1
 for cfg in "config3 4000000" "config4 8000000" "config5 2000000"; do
@@ -21,6 +27,8 @@ for cfg in "config3 4000000" "config4 8000000" "config5 2000000"; do
   python3 $R/bench.py --workload $1 --rays $2 --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_$1.json 2>> $out/bench.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace_$1 -- python3 $R/bench.py --workload $1 --rays $2 --steps 50 --warmup 5 --no-cpu-baseline --side-steps 0 --streams 1 > $out/trace_$1.log 2>&1
 done
+# BASELINE config 4 WHOLE on one GPU: 8 wavelengths x 8M rays = 64M rays, 192M rows (generation_limit 4: the job has three generations)
+python3 $R/bench.py --workload config4 --rays 64000000 --generation-limit 4 --steps 6 --warmup 2 --reps 3 --side-steps 2 --no-cpu-baseline > $out/bench_config4_full.json 2>> $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o render -- python3 $R/tools/render_bench.py --width 640 8192 --cpu-pixels 20000 > $out/render.log 2>&1
 cd $R
 bash tools/traffic.sh > $out/traffic.log 2>&1
