@@ -825,7 +825,7 @@ def main():
     with open(engine.LIB_PATH, "rb") as fh:
         library_sha16 = hashlib.sha256(fh.read()).hexdigest()[:16]
     traffic, traffic_note = None, None
-    traffic_file = next((f for f in (os.path.join(ROOT, "profiles", r, "traffic.json") for r in ("r4", "r3", "r2"))
+    traffic_file = next((f for f in (os.path.join(ROOT, "profiles", r, "traffic.json") for r in ("r5", "r4", "r3", "r2"))
                          if os.path.exists(f)), None)
     if traffic_file and args.flags == 0 and n == RAYS_PER_GPU and args.workload == "config2":
         with open(traffic_file) as fh:

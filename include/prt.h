@@ -152,7 +152,9 @@ typedef struct prt_scene_options {
   int32_t one_direction;     /* 1: a grouped trace program is stored once, not also in mirror image */
   int32_t no_intervals;      /* 1: chain steps whose nodes are all INTERSECT run the general CSG node algebra instead of
                                 the interval form (an intersection of the leaves' [enter, exit] intervals) */
-  int32_t reserved[5];
+  int32_t no_clearance;      /* 1: the cylinder that cuts a lens chain to its aperture is evaluated for every wave (0: not for a
+                                wave all of whose chords run inside it by a margin: a convexity argument) */
+  int32_t reserved[4];
 } prt_scene_options;
 
 /* Build a scene from a snapshot.  roots[] lists the node index of every top-level component

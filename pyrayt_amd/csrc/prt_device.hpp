@@ -87,7 +87,7 @@ struct DevChain {
   int32_t op1, op2;      // CSG_*
   int32_t prim[3];
   int32_t implied1, implied2;  // cull box implied by the survivors (see csg_keep)
-  int32_t shared_rows;         // the leaves' M^-1 agree bit for bit in their linear part (recorded by the compiler; no kernel uses it)
+  int32_t clearance;           // a third leaf that is a cylinder may be skipped for a wave whose chords it provably leaves alone (chord_inside_cylinder)
   int32_t intervals;           // every node INTERSECT with an implied box: the interval form applies (chain_candidate)
   double box1[6], box2[6];     // upstream cull boxes of the two nodes (csg.py:126-128)
   double leaf[3][18];          // params[0..5], M^-1 rows 0..2 [6..17]
@@ -996,14 +996,91 @@ __device__ __forceinline__ bool segment_meets(const double* __restrict__ box, co
 // values at every level, so ties resolve as in csg_node.  When no lane of the wave holds a positive
 // survivor after the first node, the third leaf is not evaluated (an INTERSECT / DIFFERENCE result
 // lies inside its left operand: the same argument as the interpreter's right-leaf skip).
+// Third leaf of a lens chain, a CYLINDER (every lens factory cuts its two spherical faces to the aperture with one,
+// components.py:73-198): can it change the chord [lo, hi] the first two leaves left?  Not if the ray is inside the
+// cylinder's solid over a slightly longer stretch: the solid is convex, so two points inside it -- the ray at
+// lo - m and at hi + m, m = 1e-6 (1 + |lo| + |hi|) -- put every point between them inside, the cylinder's own interval
+// [enter, exit] then contains [lo - m, hi + m], and `enter >= lo` / `exit < hi` (chain_candidate) are both false
+// whatever the last bits of enter and exit are: upstream's roots carry absolute errors of ~1e-16 of the magnitudes
+// involved, ten orders below m.  The points are tested in the leaf's own object space, on the ray exactly as
+// surface_pair hands it to the primitive, against the solid shrunk by 1e-9 of those magnitudes (the test's own
+// rounding); a ray on one of upstream's degenerate branches (|dx^2 + dy^2| <= 1e-8: operations.py:43, SURVEY Q5 -- such
+// a ray MISSES the cylinder it runs through --, or |dz| <= 1e-8) is not cleared, and the thresholds are evaluated on
+// the very numbers primitive_pair evaluates them on.  About 70 instructions against the leaf's 190.
+__device__ __forceinline__ bool chord_inside_cylinder(const double* __restrict__ q, const double* __restrict__ m,
+                                                      const Ray8& r, double lo, double hi) {
+  const double ox = row_dot(m, 0, r.ox, r.oy, r.oz, r.ow), oy = row_dot(m, 1, r.ox, r.oy, r.oz, r.ow),
+               oz = row_dot(m, 2, r.ox, r.oy, r.oz, r.ow);
+  const double dx = row_dot(m, 0, r.dx, r.dy, r.dz, r.dw), dy = row_dot(m, 1, r.dx, r.dy, r.dz, r.dw),
+               dz = row_dot(m, 2, r.dx, r.dy, r.dz, r.dw);
+  const double a = dx * dx + dy * dy;  // (as primitive_pair computes it)
+  const double margin = 1e-6 * ((1.0 + fabs(lo)) + fabs(hi));
+  const double rr = q[0] * q[0];
+  // |x| <= 2 |ox| + |x'| for x' = ox + t dx: the magnitudes that went into a point bound its rounding
+  const double radial_room = rr - 1e-9 * (8.0 * (ox * ox + oy * oy) + rr);
+  const double axial_slack = 1e-9 * ((2.0 * fabs(oz) + fabs(q[1])) + fabs(q[2]));
+  bool inside = !near0(a) && !near0(dz);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const double t = k == 0 ? lo - margin : hi + margin;
+    const double x = fma(t, dx, ox), y = fma(t, dy, oy), z = fma(t, dz, oz);
+    const double rho2 = x * x + y * y;
+    const double slack = axial_slack + 1e-9 * fabs(z);
+    inside = inside && rho2 * (1.0 + 2e-9) <= radial_room && z >= q[1] + slack && z <= q[2] - slack;  // (NaN: not inside)
+  }
+  return inside;
+}
+
+// what an interval chain offers the running nearest hit: its chord's entry if that lies ahead, else its exit
+__device__ __forceinline__ void offer_chord(const Ray8& ray, bool some, double lo, double hi, int id_lo, int id_hi,
+                                            double& best_t, int& best_prim) {
+  const bool first = some && lo > 0;  // (lo < hi: finite)
+  const bool second = some && hi > 0 && hi < PRT_INF;
+  const double t = first ? lo : (second ? hi : PRT_INF);
+  const int prim = first ? id_lo : (second ? id_hi : -1);
+  if (beats(ray, t, prim, best_t, best_prim)) {
+    best_t = t;
+    best_prim = prim;
+  }
+}
+
 template <int T0, int T1, int T2>
 __device__ __forceinline__ void chain_candidate(const DevChain* __restrict__ ch, const Ray8& ray,
                                                 double& best_t, int& best_prim) {
   double lv[2], rv[2], r2[2] = {PRT_INF, PRT_INF};
-  surface_pair(T0, ch->leaf[0], ch->leaf[0] + 6, ray, lv[0], lv[1]);
-  surface_pair(T1, ch->leaf[1], ch->leaf[1] + 6, ray, rv[0], rv[1]);
   const int id0 = ch->prim[0], id1 = ch->prim[1];
   bool have_third = false;
+  // ---- the aperture cylinder as FIRST leaf (thick_lens: (stock & face) & face, components.py:73-127) ----------------
+  // An interval chain is an intersection of intervals, so the two faces can be intersected first: [lo, hi] of leaves 1
+  // and 2 alone, left before right as the chain has them.  If the cylinder's own interval contains that chord with a
+  // margin (chord_inside_cylinder), none of its entries is the later enter or the earlier exit at either node, nor
+  // tied with one, and the chain's result is this chord with these ids; the two cull boxes are functions of the ray
+  // alone (implied_touch only chooses how to evaluate them), the final chord lies inside both nodes' solids.  A wave
+  // with a lane that is not cleared -- a chord near the rim, a tie between the faces, a degenerate branch -- evaluates
+  // the cylinder and runs the chain in its own order with the pairs it already has.  No wanted chord at all (no lane's
+  // faces overlap ahead of the ray): the chain, a subset of that overlap, has nothing to offer either.
+  if (T0 == PRIM_CYLINDER && T2 >= 0 && ch->intervals != 0 && ch->clearance != 0) {  // (uniform)
+    surface_pair(T1, ch->leaf[1], ch->leaf[1] + 6, ray, rv[0], rv[1]);
+    surface_pair(T2 < 0 ? 0 : T2, ch->leaf[2], ch->leaf[2] + 6, ray, r2[0], r2[1]);
+    have_third = true;
+    const int id2 = ch->prim[2];
+    const bool b_in = r2[0] >= rv[0], b_out = r2[1] < rv[1];
+    const double lo = b_in ? r2[0] : rv[0], hi = b_out ? r2[1] : rv[1];
+    const bool tie = lo == hi && hi < PRT_INF;
+    bool some = lo < hi;
+    const bool wanted = (some && hi > 0) || tie;
+    if (__ballot(wanted) == 0ull) return;
+    if (__ballot(wanted && (tie || !chord_inside_cylinder(ch->leaf[0], ch->leaf[0] + 6, ray, lo, hi))) == 0ull) {
+      some = some && implied_touch(ch->box1, ray, some, lo, hi);
+      some = some && implied_touch(ch->box2, ray, some, lo, hi);
+      offer_chord(ray, some, lo, hi, b_in ? id2 : id1, b_out ? id2 : id1, best_t, best_prim);
+      return;
+    }
+    surface_pair(T0, ch->leaf[0], ch->leaf[0] + 6, ray, lv[0], lv[1]);
+  } else {
+    surface_pair(T0, ch->leaf[0], ch->leaf[0] + 6, ray, lv[0], lv[1]);
+    surface_pair(T1, ch->leaf[1], ch->leaf[1] + 6, ray, rv[0], rv[1]);
+  }
   // ---- the interval form ------------------------------------------------------------------------------------
   // Every leaf reports ONE interval [enter, exit] of the ray inside its solid.  array_csg's INTERSECT of two
   // such lists keeps, for values in general position, exactly the later of the two enters and the earlier of the
@@ -1023,26 +1100,27 @@ __device__ __forceinline__ void chain_candidate(const DevChain* __restrict__ ch,
     some = some && implied_touch(ch->box1, ray, some, lo, hi);
     if (T2 >= 0) {
       // (a chord that ends behind the ray leaves nothing positive for the third leaf to cut: see below)
-      if (__ballot((some && hi > 0) || undecided) == 0ull) return;
-      surface_pair(T2 < 0 ? 0 : T2, ch->leaf[2], ch->leaf[2] + 6, ray, r2[0], r2[1]);
-      have_third = true;
-      const int id2 = ch->prim[2];
-      const bool c_in = r2[0] >= lo, c_out = r2[1] < hi;
-      lo = c_in ? r2[0] : lo; hi = c_out ? r2[1] : hi;
-      id_lo = c_in ? id2 : id_lo; id_hi = c_out ? id2 : id_hi;
-      undecided = undecided || (some && lo == hi && hi < PRT_INF);
+      const bool wanted = (some && hi > 0) || undecided;
+      if (__ballot(wanted) == 0ull) return;
+      // (a cylinder that provably leaves every wanted chord of the wave as it is -- the beam runs well inside the
+      // aperture -- is not evaluated: chord_inside_cylinder)
+      bool cut = true;
+      if (T2 == PRIM_CYLINDER && ch->clearance != 0)  // (uniform)
+        cut = __ballot(wanted && (undecided || !chord_inside_cylinder(ch->leaf[2], ch->leaf[2] + 6, ray, lo, hi))) != 0ull;
+      if (cut) {
+        if (!have_third) surface_pair(T2 < 0 ? 0 : T2, ch->leaf[2], ch->leaf[2] + 6, ray, r2[0], r2[1]);
+        have_third = true;
+        const int id2 = ch->prim[2];
+        const bool c_in = r2[0] >= lo, c_out = r2[1] < hi;
+        lo = c_in ? r2[0] : lo; hi = c_out ? r2[1] : hi;
+        id_lo = c_in ? id2 : id_lo; id_hi = c_out ? id2 : id_hi;
+        undecided = undecided || (some && lo == hi && hi < PRT_INF);
+      }
       some = some && lo < hi;
       some = some && implied_touch(ch->box2, ray, some, lo, hi);
     }
     if (__ballot(undecided) == 0ull) {
-      const bool first = some && lo > 0;  // (lo < hi: finite)
-      const bool second = some && hi > 0 && hi < PRT_INF;
-      const double t = first ? lo : (second ? hi : PRT_INF);
-      const int prim = first ? id_lo : (second ? id_hi : -1);
-      if (beats(ray, t, prim, best_t, best_prim)) {
-        best_t = t;
-        best_prim = prim;
-      }
+      offer_chord(ray, some, lo, hi, id_lo, id_hi, best_t, best_prim);
       return;
     }
   }

@@ -478,14 +478,8 @@ static bool chain_record(const prt_scene* s, int root_node, const Compiler& c, D
     for (int j = 0; j < 6; ++j) out->leaf[k][j] = pr.params[j];
     for (int j = 0; j < 12; ++j) out->leaf[k][6 + j] = pr.minv[j];  // rows 0..2 of M^-1
   }
-  // leaves whose M^-1 agree bit for bit in the 3 x 3 linear part (a part moved as a whole): the device shares the
-  // partial sums of their transforms (SharedRows)
-  bool same = true;
-  for (int k = 1; k < n_leaves; ++k)
-    for (int r = 0; r < 3; ++r)
-      for (int col = 0; col < 3; ++col)
-        same = same && std::memcmp(&out->leaf[k][6 + 4 * r + col], &out->leaf[0][6 + 4 * r + col], sizeof(double)) == 0;
-  out->shared_rows = same ? 1 : 0;
+  // a cylinder as third leaf may be cleared without being evaluated (chain_candidate, chord_inside_cylinder)
+  out->clearance = s->options.no_clearance ? 0 : 1;
   // every node an INTERSECT whose cull box is implied: the chain is an intersection of intervals (chain_candidate)
   out->intervals = (out->op1 == PRT_NODE_INTERSECT && out->implied1 && (n_leaves == 2 || (out->op2 == PRT_NODE_INTERSECT && out->implied2))) ? 1 : 0;
   if (s->options.no_intervals) out->intervals = 0;

@@ -65,7 +65,7 @@ def test_trace_matches_reference(name, flags):
 
 
 @pytest.mark.parametrize("name", SCENE_FIXTURES)
-@pytest.mark.parametrize("knob", ["no_chain", "no_cull", "cull_min", "no_implied", "list_order_groups", "no_intervals"])
+@pytest.mark.parametrize("knob", ["no_chain", "no_cull", "cull_min", "no_implied", "list_order_groups", "no_intervals", "no_clearance"])
 def test_trace_matches_reference_on_every_program_form(name, knob):
     """The same goldens with the scene compiled to the other program forms (prt_scene_options): the step
     interpreter instead of chain steps, no component cull steps, cull steps from two components on, every
@@ -1111,6 +1111,72 @@ def test_four_traces_in_flight_get_their_queues_whichever_import_came_first():
     done = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300)
     assert done.returncode == 0, done.stderr[-1500:]
     assert done.stdout.split()[-2] == "set-late" and done.stdout.split()[-1] in ("quiet", "warned"), done.stdout
+
+
+@pytest.mark.parametrize("lens", ["biconvex", "thick_moved", "thick_tilted_scaled"])
+def test_rays_around_the_rim_of_a_lens_with_and_without_the_clearance_test(lens):
+    """chain_candidate skips the cylinder that cuts a lens to its aperture for a wave whose chords all run inside it by
+    a margin (chord_inside_cylinder: a convexity argument).  The rays that could tell a wrong skip apart are the ones
+    near the rim and the ones on upstream's degenerate branches: beams parallel to the axis (a = dx^2 + dy^2 <= 1e-8:
+    SURVEY Q5, such rays MISS the cylinder they run through), beams a hair off it, rays whose hit points sit within
+    1e-12 ... 1e-3 of the aperture radius on either side, rays perpendicular to the axis, zero directions -- mixed
+    into every wave with rays from the middle of the beam.  Rows bit for bit against the C oracle, with the test and
+    without (scene option no_clearance); every wave of the first holds a ray that forces the cut or none does."""
+    from oracle import c_oracle
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    api = scenes.product_api()
+    CountedObject.reset_ids()
+    if lens == "biconvex":
+        part, radius, axis_x = api.components.biconvex_lens(2, 2, 0.25, aperture=1), 0.5, 0.0
+    elif lens == "thick_moved":
+        part, radius, axis_x = api.components.thick_lens(40, -200, 5, aperture=25.4, material=api.materials.glass["BK7"]).move(3.0, 0.5, -0.25), 12.7, 3.0
+    else:
+        part = api.components.thick_lens(30, -45, 4, aperture=10.0, material=api.materials.glass["SF2"])
+        part.rotate_y(7).rotate_z(-11).scale(1.5, 1.3, 0.8).move(1.0, -2.0, 0.5)
+        radius, axis_x = 7.5, 1.0
+    detector = api.components.baffle((200, 200)).move_x(axis_x + 60)
+    rng = np.random.default_rng(77)
+    n = 64 * 600
+    rays = scenes.random_rays(n, seed=5, box=1.0)
+    centre = np.array([axis_x, 0.5 if lens == "thick_moved" else (-2.0 if lens == "thick_tilted_scaled" else 0.0),
+                       -0.25 if lens == "thick_moved" else (0.5 if lens == "thick_tilted_scaled" else 0.0)])
+    # every ray starts in front of the lens and aims at a point of the aperture plane at radius rho
+    offsets = np.array([0.0, 1e-12, -1e-12, 1e-9, -1e-9, 1e-7, -1e-7, 1e-6, -1e-6, 1e-5, -1e-5, 1e-3, -1e-3, 1e-2, -1e-2])
+    rho = np.where(rng.random(n) < 0.5, radius * rng.random(n) * 0.9, radius * (1 + rng.choice(offsets, n)))
+    phi = rng.uniform(0, 2 * np.pi, n)
+    target = centre[:, None] + np.stack([np.zeros(n), rho * np.cos(phi), rho * np.sin(phi)])
+    kind = rng.integers(0, 6, n)
+    start = target.copy()
+    start[0] -= rng.uniform(2.0, 50.0, n)                                  # kind 0, 1: parallel to the axis (a == 0: Q5)
+    tilt = np.where(kind >= 2, 10.0 ** rng.uniform(-9, -1, n), 0.0)          # kind >= 2: off the axis by 1e-9 ... 1e-1
+    start[1] += tilt * (target[0] - start[0]) * np.cos(phi * 3)
+    start[2] += tilt * (target[0] - start[0]) * np.sin(phi * 3)
+    d = target - start
+    d /= np.linalg.norm(d, axis=0)
+    rays[0:3], rays[3] = start, 1.0
+    rays[4:7], rays[7] = d, 0.0
+    side = kind == 5                                                          # perpendicular to the axis, through the rim zone
+    rays[4:7, side] = np.stack([np.zeros(side.sum()), np.cos(phi[side]), np.sin(phi[side])])
+    rays[0:3, side] = target[:, side] - 3 * radius * rays[4:7, side]
+    rays[4:7, ::997] = 0.0                                                    # a few zero directions
+    rays[8], rays[9], rays[10], rays[11] = 0.0, 100.0, 0.55, 1.0
+    rays[12] = np.arange(n)
+    snap = SceneSnapshot([part, detector])
+    want, want_counts = c_oracle.trace(helpers.flat_scene(snap), rays, 8)
+    assert len(want_counts) >= 3 and want.shape[0] > n
+    for options in ({}, {"no_clearance": 1}):
+        ds = engine.DeviceScene(snap, options=options)
+        rows, counts = ds.trace(dev(rays), 8)
+        assert counts == want_counts, options
+        assert np.array_equal(rows.cpu().numpy().T, want, equal_nan=True), options
+        # the middle of the beam alone: every wave clears its cylinder -- and the rows are those rows
+        calm = np.ascontiguousarray(rays[:, (rho < 0.8 * radius) & (kind >= 2) & (kind < 5) & (np.arange(n) % 997 != 0)])
+        calm_want, calm_counts = c_oracle.trace(helpers.flat_scene(snap), calm, 8)
+        rows, counts = ds.trace(dev(calm), 8)
+        assert counts == calm_counts and np.array_equal(rows.cpu().numpy().T, calm_want, equal_nan=True), options
+        ds.close()
 
 
 def test_batch_reports_how_long_the_device_was_busy_with_it():

@@ -358,7 +358,7 @@ def test_every_compiled_program_passes_the_library_own_walk():
     from pyrayt_amd.scene import SceneSnapshot
 
     api = scenes.product_api()
-    switches = ("no_chain", "no_cull", "no_groups", "no_implied", "list_order_groups", "one_direction", "no_intervals")
+    switches = ("no_chain", "no_cull", "no_groups", "no_implied", "list_order_groups", "one_direction", "no_intervals", "no_clearance")
     seen_groups = seen_mirror = 0
     for seed in range(120):
         rng = np.random.default_rng(9000 + seed)
