@@ -950,7 +950,13 @@ class TraceBatch:
             return 0
         torch = _torch()
         if self.scene._table_materials:  # (user-defined glasses: see DeviceScene._refresh_tables)
-            self.scene._refresh_tables(self.ray_sets[0])
+            if self.scene._tables is None and getattr(self.scene, "_stale_tables", None) is None:
+                # a first trace: the tables have to cover the wavelengths of EVERY ray set of the batch (a job that meets
+                # one they lack ends the batch with PRT_ERR_WAVELENGTH: nothing can rescan in the middle of it)
+                self.scene.ensure_tables(np.concatenate([self.scene.distinct_wavelengths(r) for r in self.ray_sets
+                                                         if r.shape[1]] or [np.zeros(0)]))
+            else:
+                self.scene._refresh_tables(self.ray_sets[0])
         current = torch.cuda.current_stream(self.device)
         for stream in self.streams:  # whatever produced the ray sets
             stream.wait_stream(current)

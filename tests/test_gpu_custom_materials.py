@@ -162,6 +162,15 @@ def test_a_changed_glass_is_picked_up_on_the_direct_scene_paths_too():
     batch.run()
     index, lam = inside_index(batch.result(-1)[0])
     assert np.allclose(index, 1.5046 + 0.013 / lam ** 2, rtol=0, atol=1e-12)
+    # a batch as a scene's FIRST trace: its tables cover the wavelengths of every ray set, not only the first one's
+    other = rays.copy()
+    other[10] = 0.5
+    fresh = engine.DeviceScene(SceneSnapshot(parts))
+    first_batch = engine.TraceBatch(fresh, [dev, torch.from_numpy(other).cuda()], 10, depth=2)
+    first_batch.run()
+    index, lam = inside_index(first_batch.result(1)[0])
+    assert np.all(lam == 0.5) and np.allclose(index, 1.5046 + 0.013 / 0.25, rtol=0, atol=1e-12)
+    fresh.close()
     # update() with a snapshot of the same parts whose glass changed again
     glass.b = 0.0042
     assert ds.update(SceneSnapshot(parts)) is True

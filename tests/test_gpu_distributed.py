@@ -295,6 +295,29 @@ def test_bench_launches_its_own_ranks_sharing_one_gpu():
     assert "ms" in line["gather"], line["gather"]
 
 
+def test_bench_checks_the_shards_against_the_reference_before_it_times_them():
+    """The north-star job itself (1M rays) on two ranks sharing GPU 0 over gloo: before anything is timed every ray set's
+    frame is re-assembled on rank 0 and compared with the reference's summary of that run (all four seeds); the line
+    carries the verdict.  (RCCL refuses two ranks per device; the re-assembly then goes through torch.distributed + the
+    placement kernel -- the checks are the same.)"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PRT_DIST_BACKEND"] = "gloo"
+    done = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                           "--reps", "2", "--side-steps", "0", "--no-cpu-baseline"], capture_output=True, text=True, env=env,
+                          timeout=900)
+    assert done.returncode == 0, done.stderr[-2000:]
+    line = json.loads([ln for ln in done.stdout.splitlines() if ln.strip()][-1])
+    assert line["n_gpus"] == 2 and line["verified"] is True, line.get("verification")
+    assert line["verification"]["seeds"] == [1234, 1235, 1236, 1237]
+    assert "BEFORE the timed region" in line["verification"]["of"]
+    assert line["config"]["rays_per_gpu"] == 500000 and line["repetitions"]["n"] == 2
+
+
 # ---- sharded result sink: statistics of the whole frame from the rows every rank kept ----------------------------
 def _stats_of(frame, detector, rays_per_source, **how):
     return frame.group_stats(surface=detector, rays_per_source=rays_per_source, **how)[
