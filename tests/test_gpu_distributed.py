@@ -344,6 +344,13 @@ def _stats_worker(rank, world, port, name, n, rays_per_source, result_dir):
         detector = float(snap.prims["surface_id"][-1])
         got = _stats_of(DeviceFrame(rows, counts), detector, rays_per_source, group=group)  # the rows stay where they are
         np.save(os.path.join(result_dir, f"stats_{rank}.npy"), got)
+        # the notebook's merit functions on the sharded frame: mean squares of the whole frame from every rank's rows
+        frame = DeviceFrame(rows, counts)
+        coma = frame.mean_square("y_tilt", about=0.05, transform="sin", generation="last", group=group)
+        per_source = frame.mean_square("axis_intercept", about=1.0, surface=detector, rays_per_source=rays_per_source,
+                                       group=group) if rays_per_source else None
+        np.save(os.path.join(result_dir, f"ms_{rank}.npy"),
+                np.concatenate([[coma], per_source.to_numpy(dtype=float).ravel() if per_source is not None else []]))
     finally:
         dist.destroy_process_group()
 
@@ -363,10 +370,18 @@ def test_sharded_group_stats_on_the_gpu(tmp_path, name, n, rays_per_source, worl
     rows, counts = engine.DeviceScene(snap).trace(torch.from_numpy(rays).to("cuda:0"), LIMIT)
     want = _stats_of(DeviceFrame(rows, counts), float(snap.prims["surface_id"][-1]), rays_per_source)
     assert np.isfinite(want[:, 1]).any()
+    whole = DeviceFrame(rows, counts)
+    detector = float(snap.prims["surface_id"][-1])
+    want_ms = [whole.mean_square("y_tilt", about=0.05, transform="sin", generation="last")]
+    if rays_per_source:
+        want_ms += whole.mean_square("axis_intercept", about=1.0, surface=detector,
+                                     rays_per_source=rays_per_source).to_numpy(dtype=float).ravel().tolist()
     for rank in range(world):
         got = np.load(tmp_path / f"stats_{rank}.npy")
         assert got.shape == want.shape and np.array_equal(got[:, 0], want[:, 0])
         assert np.allclose(got, want, rtol=0, atol=1e-12, equal_nan=True), (rank, np.nanmax(np.abs(got - want)))
+        got_ms = np.load(tmp_path / f"ms_{rank}.npy")
+        assert np.allclose(got_ms, want_ms, rtol=1e-10, atol=1e-300, equal_nan=True), (rank, got_ms, want_ms)
 
 
 def test_sharded_group_stats_over_a_one_rank_rccl_communicator():
