@@ -351,6 +351,7 @@ def trace_and_gather(scene, ray_sets, generation_limit, comm, depth=2, flags=0, 
         begin_next()                                    # trace k + depth goes out before frame k is assembled
         with torch_mod.cuda.stream(comm_stream):
             comm_stream.wait_stream(streams[lane])      # the rows are ordered on the ticket's stream
+            comm_stream.wait_stream(current)            # ... and whoever still reads the frame block about to be reused
             matrix = comm.gather_counts(counts, limit)  # (host sync of the communication stream only)
             per_rank = matrix.sum(dim=1)
             total = int(per_rank.sum())
