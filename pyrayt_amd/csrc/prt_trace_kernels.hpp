@@ -663,13 +663,30 @@ __device__ __forceinline__ bool w_is_trivial(double ow, double dw) {
   return ow == 1.0 && __double_as_longlong(dw) == 0ll;
 }
 
+// ---- lean segments of the compact state (round 5) ---------------------------------------------------------------
+// Three of the ten rows the generations hand on never change on the fused path -- intensity (9), wavelength (10), ray
+// id (12): no built-in material touches them -- and in a ray set as sources emit it they are redundant within a wave:
+// one intensity, one wavelength, ids that count up by one.  A wave whose 64 outputs land, in lane order, on the 64
+// columns that ONE wave of the next generation will read (its tile's first column is tile x 256 and the waves in front
+// of it carried every ray: dense launches, and compacting ones as long as nothing has died yet) checks exactly that --
+// bit-equal intensity and wavelength, id == id0 + lane with id0 an integer in [0, 2^48) -- and if it holds, lane 0 alone
+// writes the three rows: the id row's entry is id0 boxed into a NaN (tag in the top 16 bits), the other two are the
+// values.  The reader looks at the first id entry of its segment (one scalar load): tagged -> two more scalar loads
+// and `id0 + lane`, no vector loads of those rows; anything else -> the rows, as before.  24 B per ray less each way.
+// A genuine id that carries the tag would be misread: a ray with such an id makes the trace repeat with all 13 rows
+// (PRT_ERR_FULL_ROWS, like a non-trivial w), whose kernels know nothing of this.
+#define PRT_LEAN_TAG 0x7ffbll
+__device__ __forceinline__ bool lean_tagged(double v) { return (__double_as_longlong(v) >> 48) == PRT_LEAN_TAG; }
+
 // compact: the next state goes without its rows 3, 7 and 8 (see k_generation); returns false if a ray
 // that goes on does not have the values the reader will assume for them
+// lean: this wave's rows 9, 10 and 12 are written by its first lane alone (see above; `id0` = that lane's id)
 template <bool COMPACT>
 __device__ __forceinline__ bool interact_store_rows(const Shaded& s, const Ray8& r, bool carry, unsigned row_bytes,
                                                     unsigned next_bytes, double* __restrict__ nxt, int64_t ld_next,
                                                     double* __restrict__ rec, int64_t ld_rows,
-                                                    double next_generation, int relaunch, double ray_offset) {
+                                                    double next_generation, int relaunch, double ray_offset,
+                                                    bool lean = false, double id0 = 0.0) {
   row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_GENERATION * ld_rows, row_bytes, s.generation);
   row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_INTENSITY * ld_rows, row_bytes, s.intensity);
   row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_WAVELENGTH * ld_rows, row_bytes, s.wavelength);
@@ -702,11 +719,21 @@ __device__ __forceinline__ bool interact_store_rows(const Shaded& s, const Ray8&
       row_store<PRT_STORE_AUX_NEXT>(nxt + 7 * ld_next, next_bytes, s.dw);
       row_store<PRT_STORE_AUX_NEXT>(nxt + 8 * ld_next, next_bytes, next_generation);
     }
-    row_store<PRT_STORE_AUX_NEXT>(nxt + 9 * ld_next, next_bytes, s.intensity);
-    row_store<PRT_STORE_AUX_NEXT>(nxt + 10 * ld_next, next_bytes, s.wavelength);
     row_store<PRT_STORE_AUX_NEXT>(nxt + 11 * ld_next, next_bytes, s.index);
-    row_store<PRT_STORE_AUX_NEXT>(nxt + 12 * ld_next, next_bytes, s.id);
-    if (COMPACT && relaunch) return w_is_trivial(qw, s.dw);  // (!relaunch: nobody reads this state)
+    if (COMPACT && lean) {  // (wave-uniform)
+      if ((threadIdx.x & 63) == 0) {
+        row_store<PRT_STORE_AUX_NEXT>(nxt + 9 * ld_next, next_bytes, s.intensity);
+        row_store<PRT_STORE_AUX_NEXT>(nxt + 10 * ld_next, next_bytes, s.wavelength);
+        row_store<PRT_STORE_AUX_NEXT>(nxt + 12 * ld_next, next_bytes,
+                                      __longlong_as_double((PRT_LEAN_TAG << 48) | (long long)id0));
+      }
+    } else {
+      row_store<PRT_STORE_AUX_NEXT>(nxt + 9 * ld_next, next_bytes, s.intensity);
+      row_store<PRT_STORE_AUX_NEXT>(nxt + 10 * ld_next, next_bytes, s.wavelength);
+      row_store<PRT_STORE_AUX_NEXT>(nxt + 12 * ld_next, next_bytes, s.id);
+    }
+    // (!relaunch: nobody reads this state)
+    if (COMPACT && relaunch) return w_is_trivial(qw, s.dw) && !lean_tagged(s.id);
   }
   return true;
 }
@@ -781,9 +808,30 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
       r.dw = row_load(tile_rays + 7 * ld, lane_bytes);
       PARK(0) = row_load(tile_rays + 8 * ld, lane_bytes);
     }
-    PARK(1) = row_load(tile_rays + 9 * ld, lane_bytes);
-    PARK(2) = row_load(tile_rays + 10 * ld, lane_bytes); PARK(3) = row_load(tile_rays + 11 * ld, lane_bytes);
-    PARK(4) = row_load(tile_rays + 12 * ld, lane_bytes);
+    PARK(3) = row_load(tile_rays + 11 * ld, lane_bytes);
+    // rows 9, 10, 12: a lean segment (written by interact_store_rows of the generation before) or the rows themselves
+    bool lean_in = false;
+    if (COMPACT && g > 0) {  // (uniform)
+      const int64_t col0 = (int64_t)tile * PRT_BLOCK + (int64_t)(__builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u);
+      // (all three at once, whatever the first turns out to be: one round trip, in flight with the row loads above --
+      // fetched one after the other they cost a wave of an 8M-ray set, whose state comes from HBM, two more.  As
+      // broadcast VECTOR loads -- every lane asking for the same element -- they cost config 2 10 %: ab_round5.txt)
+      typedef const __attribute__((address_space(4))) double* ConstRow;  // (the state is not written by this launch: scalar loads)
+      const double first_id = ((ConstRow)(unsigned long long)(rays + 12 * ld + col0))[0];  // (col0 < n: this lane is in range)
+      const double first_intensity = ((ConstRow)(unsigned long long)(rays + 9 * ld + col0))[0];
+      const double first_wavelength = ((ConstRow)(unsigned long long)(rays + 10 * ld + col0))[0];
+      lean_in = lean_tagged(first_id);
+      if (lean_in) {
+        PARK(1) = first_intensity;
+        PARK(2) = first_wavelength;
+        PARK(4) = (double)(__double_as_longlong(first_id) & 0xffffffffffffll) + (double)(threadIdx.x & 63u);
+      }
+    }
+    if (!lean_in) {
+      PARK(1) = row_load(tile_rays + 9 * ld, lane_bytes);
+      PARK(2) = row_load(tile_rays + 10 * ld, lane_bytes);
+      PARK(4) = row_load(tile_rays + 12 * ld, lane_bytes);
+    }
     if (COMPACT) {
       if (g > 0) {  // uniform
         r.ow = 1.0;
@@ -825,11 +873,15 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   }
   __syncthreads();
   unsigned agg_live = 0, agg_carry = 0;
+  int wave_carry_base = 0;  // rays the waves in front of this one (in this tile) carry on
   for (int w = 0; w < PRT_BLOCK / 64; ++w) {
-    if (w < wave) { live_rank += s_wave_live[w]; carry_rank += s_wave_carry[w] & 0xffff; }
+    if (w < wave) { live_rank += s_wave_live[w]; wave_carry_base += s_wave_carry[w] & 0xffff; }
     agg_live += s_wave_live[w];
     agg_carry += s_wave_carry[w];
   }
+  carry_rank += wave_carry_base;
+  // (lanes of this wave that hold a ray at all: a lean segment needs every one of them carried on)
+  const unsigned long long m_held = __ballot(i < n && !failed);
   const unsigned agg_kept = agg_carry >> 16;
   agg_carry &= 0xffffu;
   // Launched on the dead list of the generation before (assume 5 / 6): the dead rays in front of this tile, in it,
@@ -1004,9 +1056,26 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   sh.generation = PARK(0); sh.intensity = PARK(1); sh.wavelength = PARK(2);
   sh.index_in = PARK(3); sh.id = PARK(4);
   r.ox = PARK(5); r.oy = PARK(6); r.oz = PARK(7);
+  // a lean segment (see interact_store_rows): this wave's outputs are the 64 columns one wave of the next generation
+  // reads, in lane order, and their three constant rows are redundant
+  bool lean_out = false;
+  double id0 = 0.0;
+  if (COMPACT && relaunch && m_carry == m_held && excl_carry == (int64_t)tile * PRT_BLOCK && wave_carry_base == 64 * wave) {  // (uniform)
+    // (every lane still here is live and carried; the wave's lanes are 0 .. k - 1)
+    const double intensity0 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(sh.intensity)),
+                                               __builtin_amdgcn_readfirstlane(__double2loint(sh.intensity)));
+    const double wavelength0 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(sh.wavelength)),
+                                                __builtin_amdgcn_readfirstlane(__double2loint(sh.wavelength)));
+    id0 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(sh.id)),
+                           __builtin_amdgcn_readfirstlane(__double2loint(sh.id)));
+    const bool redundant = __double_as_longlong(sh.intensity) == __double_as_longlong(intensity0) &&
+                           __double_as_longlong(sh.wavelength) == __double_as_longlong(wavelength0) &&
+                           sh.id == id0 + (double)lane && id0 >= 0.0 && id0 < 0x1p48 && id0 == (double)(long long)id0;
+    lean_out = __ballot(!redundant) == 0ull;
+  }
   if (!interact_store_rows<COMPACT>(sh, r, carry, (unsigned)live_rank * 8u, (unsigned)carry_rank * 8u,
                                     next + uniform64(excl_carry), ld_next, rows + uniform64(row_base + excl_live),
-                                    ld_rows, next_generation, relaunch, ray_offset))
+                                    ld_rows, next_generation, relaunch, ray_offset, lean_out, id0))
     atomicExch(&ctrl->error, PRT_ERR_FULL_ROWS);
   if (sh.err) raise_error(&ctrl->error, sh.err);
   STAMP(7);

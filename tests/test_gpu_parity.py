@@ -1179,6 +1179,53 @@ def test_rays_around_the_rim_of_a_lens_with_and_without_the_clearance_test(lens)
         ds.close()
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 255, 256, 257, 5000, 70_001])
+def test_lean_state_segments_and_the_ray_sets_that_do_not_qualify(n):
+    """Between generations a wave whose rays stay in place hands on intensity, wavelength and id as three numbers (one
+    intensity, one wavelength, ids counting up from an integer: interact_store_rows) instead of three rows.  Ray sets
+    that qualify, that qualify in some waves only, and that never do -- ids in any order, fractional, negative, beyond
+    2^48, wavelengths or intensities that change inside a wave -- must all give the oracle's rows bit for bit; an id that
+    carries the tag of a lean segment sends the scene to its 13-row kernels (telemetry: full_rows_fallbacks)."""
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    CountedObject.reset_ids()
+    parts, rays = scenes.config2(scenes.product_api(), n, seed=300 + n)
+    snap = SceneSnapshot(parts)
+    flat = helpers.flat_scene(snap)
+    rng = np.random.default_rng(n)
+    variants = {"as emitted": rays.copy()}
+    v = rays.copy(); v[12] = rng.permutation(n); variants["ids shuffled"] = v
+    v = rays.copy(); v[12] += 0.5; variants["fractional ids"] = v
+    v = rays.copy(); v[12] -= 7.0; variants["negative ids"] = v
+    v = rays.copy(); v[12] += 2.0 ** 48; variants["ids beyond 2^48"] = v
+    v = rays.copy(); v[12] += 2.0 ** 48 - 100; variants["ids across 2^48"] = v
+    v = rays.copy(); v[12, n // 2] += 1.0; variants["one id out of step"] = v
+    v = rays.copy(); v[10] = np.where(np.arange(n) % 64 == 63, 0.5, 0.633); variants["a wavelength per wave edge"] = v
+    v = rays.copy(); v[10] = 0.45 + 0.01 * (np.arange(n) // 64 % 7); variants["one wavelength per wave"] = v
+    v = rays.copy(); v[9, -1] = 7.0; variants["last intensity differs"] = v
+    v = rays.copy(); v[9] = -0.0; v[9, ::3] = 0.0; variants["signed zero intensities"] = v
+    v = rays.copy(); v[10, 0] = np.nan; variants["a NaN wavelength"] = v
+    ds = engine.DeviceScene(snap)
+    for name, block in variants.items():
+        want, want_counts = orc.trace(flat, block, 10)
+        for _ in range(2):  # (a first trace by look-back, a repeat on the hints: both write lean segments where they may)
+            rows, counts = ds.trace(dev(block), 10)
+            assert counts == want_counts, (name, n)
+            assert np.array_equal(rows.cpu().numpy().T, want, equal_nan=True), (name, n)
+    assert ds.telemetry()["full_rows_fallbacks"] == 0
+    ds.close()
+    # an id that looks like the head of a lean segment: the compact kernels must not hand it on
+    tagged = rays.copy()
+    tagged[12, n // 3] = np.frombuffer(np.array([(0x7ffb << 48) | 12345], dtype=np.uint64).tobytes(), dtype=np.float64)[0]
+    want, want_counts = orc.trace(flat, tagged, 10)
+    ds = engine.DeviceScene(snap)
+    rows, counts = ds.trace(dev(tagged), 10)
+    assert counts == want_counts and np.array_equal(rows.cpu().numpy().T.view(np.uint64), want.view(np.uint64))
+    assert ds.telemetry()["full_rows_fallbacks"] == 1
+    ds.close()
+
+
 def test_batch_reports_how_long_the_device_was_busy_with_it():
     """PRT_TRACE_BUSY / prt_trace_batch_busy (bench.py's roofline): every job of a batch bracketed by its own pair of HIP
     events on its own stream, the intervals merged by the library.  The union can never exceed first-start-to-last-end
