@@ -533,8 +533,9 @@ int prt_trace_stats(const prt_scene* scene, double* out8);
  * intensity, wavelength or id) and are redundant within a wave of a ray set as sources emit it.  A wave of a
  * generation whose 64 outputs land, in lane order, on the 64 columns one wave of the next generation reads checks that
  * its rays share one intensity and one wavelength (bit for bit) and that their ids count up by one from an integer
- * in [0, 2^48); then its first lane alone writes those rows -- the id row's entry holds that first id boxed into a
- * NaN with the tag 0x7ffb in its top 16 bits -- and the reader takes the three numbers from there (24 of the
+ * in [0, 2^48); then its first lane alone writes, into the first three entries of the segment's id row, that first id
+ * boxed into a NaN with the tag 0x7ffb in its top 16 bits, the intensity and the wavelength -- rows 9 and 10 of the
+ * segment are not written -- and the reader takes the three numbers from there with one scalar load (24 of the
  * remaining 80 B each way).  Any other wave hands the rows on as they are, so every ray set is served.  A ray whose
  * genuine id carries that tag would be misread: it raises the same repeat with all 13 rows. */
 int prt_trace_telemetry(const prt_scene* scene, int64_t* out12);

@@ -669,10 +669,12 @@ __device__ __forceinline__ bool w_is_trivial(double ow, double dw) {
 // one intensity, one wavelength, ids that count up by one.  A wave whose 64 outputs land, in lane order, on the 64
 // columns that ONE wave of the next generation will read (its tile's first column is tile x 256 and the waves in front
 // of it carried every ray: dense launches, and compacting ones as long as nothing has died yet) checks exactly that --
-// bit-equal intensity and wavelength, id == id0 + lane with id0 an integer in [0, 2^48) -- and if it holds, lane 0 alone
-// writes the three rows: the id row's entry is id0 boxed into a NaN (tag in the top 16 bits), the other two are the
-// values.  The reader looks at the first id entry of its segment (one scalar load): tagged -> two more scalar loads
-// and `id0 + lane`, no vector loads of those rows; anything else -> the rows, as before.  24 B per ray less each way.
+// bit-equal intensity and wavelength, id == id0 + lane with id0 an integer in [0, 2^48), at least three rays -- and if it
+// holds, lane 0 alone writes, into the first three entries of the segment's ID row: id0 boxed into a NaN (tag in the
+// top 16 bits), the intensity, the wavelength; rows 9 and 10 of the segment are not written at all.  The reader
+// fetches those three entries with one scalar load (one line: spread over the three rows they cost config 4 its gain,
+// 125 000 x 3 lines per generation through the scalar cache that holds the scene program): tagged -> `id0 + lane` and
+// the two values, no vector loads of those rows; anything else -> the rows, as before.  24 B per ray less each way.
 // A genuine id that carries the tag would be misread: a ray with such an id makes the trace repeat with all 13 rows
 // (PRT_ERR_FULL_ROWS, like a non-trivial w), whose kernels know nothing of this.
 #define PRT_LEAN_TAG 0x7ffbll
@@ -722,10 +724,10 @@ __device__ __forceinline__ bool interact_store_rows(const Shaded& s, const Ray8&
     row_store<PRT_STORE_AUX_NEXT>(nxt + 11 * ld_next, next_bytes, s.index);
     if (COMPACT && lean) {  // (wave-uniform)
       if ((threadIdx.x & 63) == 0) {
-        row_store<PRT_STORE_AUX_NEXT>(nxt + 9 * ld_next, next_bytes, s.intensity);
-        row_store<PRT_STORE_AUX_NEXT>(nxt + 10 * ld_next, next_bytes, s.wavelength);
         row_store<PRT_STORE_AUX_NEXT>(nxt + 12 * ld_next, next_bytes,
                                       __longlong_as_double((PRT_LEAN_TAG << 48) | (long long)id0));
+        row_store<PRT_STORE_AUX_NEXT>(nxt + 12 * ld_next, next_bytes + 8u, s.intensity);
+        row_store<PRT_STORE_AUX_NEXT>(nxt + 12 * ld_next, next_bytes + 16u, s.wavelength);
       }
     } else {
       row_store<PRT_STORE_AUX_NEXT>(nxt + 9 * ld_next, next_bytes, s.intensity);
@@ -813,13 +815,15 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     bool lean_in = false;
     if (COMPACT && g > 0) {  // (uniform)
       const int64_t col0 = (int64_t)tile * PRT_BLOCK + (int64_t)(__builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u);
-      // (all three at once, whatever the first turns out to be: one round trip, in flight with the row loads above --
-      // fetched one after the other they cost a wave of an 8M-ray set, whose state comes from HBM, two more.  As
-      // broadcast VECTOR loads -- every lane asking for the same element -- they cost config 2 10 %: ab_round5.txt)
+      // (the three entries at once, whatever the first turns out to be: one round trip, in flight with the row loads
+      // above -- fetched one after the other they cost a wave of an 8M-ray set, whose state comes from HBM, two more.
+      // As broadcast VECTOR loads -- every lane asking for the same element -- they cost config 2 10 %: ab_round5.txt)
       typedef const __attribute__((address_space(4))) double* ConstRow;  // (the state is not written by this launch: scalar loads)
-      const double first_id = ((ConstRow)(unsigned long long)(rays + 12 * ld + col0))[0];  // (col0 < n: this lane is in range)
-      const double first_intensity = ((ConstRow)(unsigned long long)(rays + 9 * ld + col0))[0];
-      const double first_wavelength = ((ConstRow)(unsigned long long)(rays + 10 * ld + col0))[0];
+      double first_id = 0.0, first_intensity = 0.0, first_wavelength = 0.0;
+      if (col0 + 2 < n) {  // (uniform; a segment of fewer than three columns is never lean)
+        const ConstRow head = (ConstRow)(unsigned long long)(rays + 12 * ld + col0);
+        first_id = head[0]; first_intensity = head[1]; first_wavelength = head[2];
+      }
       lean_in = lean_tagged(first_id);
       if (lean_in) {
         PARK(1) = first_intensity;
@@ -1060,7 +1064,8 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   // reads, in lane order, and their three constant rows are redundant
   bool lean_out = false;
   double id0 = 0.0;
-  if (COMPACT && relaunch && m_carry == m_held && excl_carry == (int64_t)tile * PRT_BLOCK && wave_carry_base == 64 * wave) {  // (uniform)
+  if (COMPACT && relaunch && m_carry == m_held && __popcll(m_held) >= 3 && excl_carry == (int64_t)tile * PRT_BLOCK &&
+      wave_carry_base == 64 * wave) {  // (uniform)
     // (every lane still here is live and carried; the wave's lanes are 0 .. k - 1)
     const double intensity0 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(sh.intensity)),
                                                __builtin_amdgcn_readfirstlane(__double2loint(sh.intensity)));
