@@ -1222,7 +1222,9 @@ def test_lean_state_segments_and_the_ray_sets_that_do_not_qualify(n):
     ds = engine.DeviceScene(snap)
     rows, counts = ds.trace(dev(tagged), 10)
     assert counts == want_counts and np.array_equal(rows.cpu().numpy().T.view(np.uint64), want.view(np.uint64))
-    assert ds.telemetry()["full_rows_fallbacks"] == 1
+    # (tools/run_matrix.sh: a scene forced onto the three-kernel path or onto all 13 rows has no compact state to leave)
+    forced = ds.trace_flags & (engine.TRACE_UNFUSED | engine.TRACE_FULL_ROWS | engine.TRACE_COUNT_PATHS)
+    assert ds.telemetry()["full_rows_fallbacks"] == (0 if forced else 1)
     ds.close()
 
 
