@@ -764,6 +764,18 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   // A ticket from one atomic word would also give start-ordered tile numbers, but a single
   // word hands out only ~80 tickets/us chip-wide: 4k tiles would cost ~50 us per generation.
   const int tile = blockIdx.x;
+  // The head of this wave's segment of the state (lean segments, interact_store_rows), asked for before anything else:
+  // its address needs nothing that is loaded, and what it says decides which rows the burst below asks for.  (Asked
+  // for behind the control words, with rows 9 / 10 / 12 fetched once it had answered, a ray set that does NOT qualify
+  // paid a second round trip in front of its hit phase: +6.5 % per trace; in this order +3 %, profiles/r5/ab_round5.txt.)
+  // (A state buffer's leading dimension is its ray count: three entries from col0 on are inside it or not asked for.)
+  typedef const __attribute__((address_space(4))) double* ConstRow;  // (the state is not written by this launch: scalar loads)
+  const int64_t col0 = (int64_t)tile * PRT_BLOCK + (int64_t)(__builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u);
+  double head_id = 0.0, head_intensity = 0.0, head_wavelength = 0.0;
+  if (COMPACT && g > 0 && col0 + 2 < ld) {  // (uniform)
+    const ConstRow head = (ConstRow)(unsigned long long)(rays + 12 * ld + col0);
+    head_id = head[0]; head_intensity = head[1]; head_wavelength = head[2];
+  }
   const int64_t n = gen[g].n_in;
   if ((int64_t)tile * PRT_BLOCK >= n) {  // uniform per workgroup; never a predecessor
     // The grid always covers the ray count the trace started with, so that every launch recycles the
@@ -801,6 +813,17 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     // reads the caller's 13 rows and checks; every generation checks the rays it hands on; a ray
     // that differs raises PRT_ERR_FULL_ROWS and the host repeats the trace with all rows in use.
     // (COMPACT is a template parameter: the form with all 13 rows is the kernel it was before.)
+    // rows 9, 10, 12: a lean segment (written by interact_store_rows of the generation before) or the rows
+    // themselves -- asked for FIRST, so that a ray set that does not qualify still fetches its ten rows in one burst
+    // (behind the other seven they were a second round trip in front of the hit phase: +7 % for such a ray set)
+    const bool lean_in = COMPACT && g > 0 && col0 + 2 < n && lean_tagged(head_id);  // (uniform; fewer than three rays: never lean)
+    double intensity_in = head_intensity, wavelength_in = head_wavelength;
+    double id_in = (double)(__double_as_longlong(head_id) & 0xffffffffffffll) + (double)(threadIdx.x & 63u);
+    if (!lean_in) {
+      intensity_in = row_load(tile_rays + 9 * ld, lane_bytes);
+      wavelength_in = row_load(tile_rays + 10 * ld, lane_bytes);
+      id_in = row_load(tile_rays + 12 * ld, lane_bytes);
+    }
     r.ox = row_load(tile_rays + 0 * ld, lane_bytes); r.oy = row_load(tile_rays + 1 * ld, lane_bytes);
     r.oz = row_load(tile_rays + 2 * ld, lane_bytes);
     if (!COMPACT) r.ow = row_load(tile_rays + 3 * ld, lane_bytes);
@@ -811,31 +834,9 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
       PARK(0) = row_load(tile_rays + 8 * ld, lane_bytes);
     }
     PARK(3) = row_load(tile_rays + 11 * ld, lane_bytes);
-    // rows 9, 10, 12: a lean segment (written by interact_store_rows of the generation before) or the rows themselves
-    bool lean_in = false;
-    if (COMPACT && g > 0) {  // (uniform)
-      const int64_t col0 = (int64_t)tile * PRT_BLOCK + (int64_t)(__builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u);
-      // (the three entries at once, whatever the first turns out to be: one round trip, in flight with the row loads
-      // above -- fetched one after the other they cost a wave of an 8M-ray set, whose state comes from HBM, two more.
-      // As broadcast VECTOR loads -- every lane asking for the same element -- they cost config 2 10 %: ab_round5.txt)
-      typedef const __attribute__((address_space(4))) double* ConstRow;  // (the state is not written by this launch: scalar loads)
-      double first_id = 0.0, first_intensity = 0.0, first_wavelength = 0.0;
-      if (col0 + 2 < n) {  // (uniform; a segment of fewer than three columns is never lean)
-        const ConstRow head = (ConstRow)(unsigned long long)(rays + 12 * ld + col0);
-        first_id = head[0]; first_intensity = head[1]; first_wavelength = head[2];
-      }
-      lean_in = lean_tagged(first_id);
-      if (lean_in) {
-        PARK(1) = first_intensity;
-        PARK(2) = first_wavelength;
-        PARK(4) = (double)(__double_as_longlong(first_id) & 0xffffffffffffll) + (double)(threadIdx.x & 63u);
-      }
-    }
-    if (!lean_in) {
-      PARK(1) = row_load(tile_rays + 9 * ld, lane_bytes);
-      PARK(2) = row_load(tile_rays + 10 * ld, lane_bytes);
-      PARK(4) = row_load(tile_rays + 12 * ld, lane_bytes);
-    }
+    PARK(1) = intensity_in;
+    PARK(2) = wavelength_in;
+    PARK(4) = id_in;
     if (COMPACT) {
       if (g > 0) {  // uniform
         r.ow = 1.0;
