@@ -443,9 +443,24 @@ def main():
             try:
                 bench_comm = pdist.LibraryComm.from_group(dist.group.WORLD, device)
                 rccl_ranks = bench_comm.info()["ranks"]
+            except TimeoutError as exc:
+                # fatal: the helper thread is still inside ncclCommInitRank and cannot be cancelled -- if the missing
+                # rank turned up later it would complete a communicator nobody owns, and the ranks would disagree
+                # about who has one.  Nothing is timed; the process leaves without running destructors behind it.
+                print(json.dumps({"metric": "ray-surface intersections/sec, 1M-ray biconvex lens", "value": None,
+                                  "n_gpus": world, "error": f"rank {rank}: {exc}"[:400]}), flush=True)
+                os._exit(3)
             except Exception as exc:  # noqa: BLE001
                 rccl_ranks = f"{type(exc).__name__}: {exc}"[:200]
                 bench_comm = None
+            # every rank uses the library's communicator or none does: a rank without one would answer the others'
+            # ncclAllGather with a torch.distributed collective and both would wait for ever
+            have = torch.tensor([1.0 if bench_comm is not None else 0.0], dtype=torch.float64, device=comm_device)
+            dist.all_reduce(have, op=dist.ReduceOp.MIN)
+            if float(have[0]) < 1.0 and bench_comm is not None:
+                bench_comm.close()
+                bench_comm = None
+                rccl_ranks = "dropped: another rank could not create the library's communicator"
         if verifiable_job:
             per_seed, how, failed = {}, "frame re-assembled on rank 0 (pyrayt_amd.distributed.assemble_rows)", None
             for k in range(len(ray_sets)):

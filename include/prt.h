@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PRT_VERSION 210 /* 0.2.1: prt_frame_mean_square, PRT_TRACE_BUSY / prt_trace_batch_busy, prt_comm_info.  0.2.0: prt_interact takes the caller-shaded state, PRT_MAT_TABLE / PRT_MAT_HOST,
+#define PRT_VERSION 220 /* 0.2.2: record plans (prt_record_plan, prt_trace_set_plan, prt_sink_bytes). 0.2.1: prt_frame_mean_square, PRT_TRACE_BUSY / prt_trace_batch_busy, prt_comm_info.  0.2.0: prt_interact takes the caller-shaded state, PRT_MAT_TABLE / PRT_MAT_HOST,
                            prt_scene_set_index_tables, prt_gather_hits / prt_scatter_shaded, prt_unique_values,
                            prt_frame_stats_sharded / prt_frame_pivots / prt_frame_finish, prt_trace_telemetry fills 12 slots.  A caller built against another version must not load this library:
                            prt_version() is there to be compared with this constant (pyrayt_amd.engine.library does). */
@@ -388,6 +388,54 @@ int64_t prt_trace_batch(prt_scene* scene, int device, prt_trace_job* jobs, int64
  * start to the latest end.  Zeros if no such batch ran.  (A job that had to repeat an attempt is represented by its
  * last attempt.) */
 int prt_trace_batch_busy(const prt_scene* scene, int device, double* out4);
+
+/* ---- record plans: what a trace records (round 6) ------------------------------------------------------
+ * The reference appends one row per live ray and generation (_RayTraceDataframe.insert, pyrayt/_pyrayt.py:168-186)
+ * and the very next line of its users throws most of them away: `results.loc[results['surface'] ==
+ * imager.get_id()]` (examples/lens_design.ipynb cells 11, 19, 38), `results.loc[results['generation'] ==
+ * np.max(results['generation'])]` (cells 12, 15, 20) -- to look at a spot size, a focus, a merit function.  A plan
+ * tells the generation kernel about it while the row is still in registers:
+ *   n_surfaces > 0    only rows whose surface id is one of surfaces[] pass (0: the rows of every surface pass);
+ *   store_rows        the rows that pass are stored in rows_out, generation-major / id-ascending as ever: the frame
+ *                     is exactly frame.loc[frame.surface.isin(surfaces)] of the unfiltered trace, and
+ *                     rows_per_generation / the return value count the stored rows.  0: nothing is stored at all
+ *                     (rows_out may be NULL, rows_cap 0; the counts are 0) -- the caller wants the sums only;
+ *   n_groups > 0      the rows that pass are also summed, per generation and per group (group = floor(id /
+ *                     rays_per_source), pyrayt/_pyrayt.py:349-354; rays_per_source <= 0: one group), into
+ *                     sums_out[(generation * n_groups + group) * PRT_SINK_STATS + k] (device memory, overwritten by
+ *                     every trace of the ticket, complete when the trace's stream reaches the end of prt_trace_end):
+ *                       k = 0..8  the sums of prt_frame_reduce -- count, sum (y1 - py), sum (z1 - pz), sum of their
+ *                                 squares, sum (f - pf), sum (f - pf)^2 with f = the axis intercept x0 - x_tilt y0 /
+ *                                 y_tilt over the rows that have one, sum wavelength, sum intensity, rows with an
+ *                                 intercept -- about the caller's pivots (device (n_groups, 3): py, pz, pf; NULL:
+ *                                 zeros.  A design loop passes the previous iteration's means: second moments about
+ *                                 a point near the mean are well conditioned);
+ *                       k = 9..11 the sums of prt_frame_mean_square for ms_quantity (a frame column 0..14 or
+ *                                 PRT_FRAME_AXIS_INTERCEPT; < 0: none), ms_transform (0 none, 1 sin) and ms_about:
+ *                                 rows with a finite v, sum v, sum v^2.
+ *                     Sums are additive over generations (one set of pivots): "the rows of the last generation" are
+ *                     the block of the highest generation whose count is not zero; prt_frame_finish turns a block's
+ *                     first nine into the statistics of prt_frame_stats.
+ * A plan belongs to a ticket (prt_trace = ticket 0) of a scene on a device and stays in force until replaced; NULL
+ * removes it.  Traces under a plan run on the fused path only (PRT_TRACE_UNFUSED / COUNT_PATHS: PRT_ERR_ARG) and
+ * learn their own dense-mode hints; without a plan nothing changes -- those kernels do not know about plans.
+ * generation_limit: the largest generation_limit a trace under this plan will be given (sizes sums_out). */
+#define PRT_SINK_STATS 12
+typedef struct prt_record_plan {
+  int32_t struct_size;     /* sizeof(prt_record_plan) */
+  int32_t n_surfaces;      /* 0 .. 8 */
+  int32_t store_rows;
+  int32_t n_groups;
+  int64_t surfaces[8];     /* surface ids (TracerSurface.get_id()) */
+  double rays_per_source;
+  double* sums_out;        /* DEVICE (generation_limit, n_groups, PRT_SINK_STATS) float64, or NULL when n_groups == 0 */
+  const double* pivots;    /* DEVICE (n_groups, 3) or NULL */
+  int32_t ms_quantity, ms_transform;
+  double ms_about;
+  int32_t generation_limit;
+  int32_t reserved;
+} prt_record_plan;
+int prt_trace_set_plan(prt_scene* scene, int device, int ticket, const prt_record_plan* plan);
 
 /* ---- frame re-assembly across the GPUs of a node ----------------------------
  * No counterpart upstream (pyrayt/_pyrayt.py:329-339 is one Python thread).  Rank r traces the

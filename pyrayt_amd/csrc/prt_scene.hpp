@@ -71,6 +71,7 @@ struct TraceTicket {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timing_pending = false;                  // ev0..ev1 of the last batch not yet added to stats[2]
   hipEvent_t busy0 = nullptr, busy1 = nullptr;  // PRT_TRACE_BUSY: this trace's own pair (prt_trace_batch lends them)
+  char* busy_recorded = nullptr;                // ... and where to note that the pair was recorded (a job that launches nothing leaves it 0)
   // control words already initialised on the stream for a next trace of this shape (see fused_start)
   const void* ready_workspace = nullptr;
   int64_t ready_n = -1;
@@ -83,6 +84,16 @@ struct TraceTicket {
   bool allow_tile_hints = true, use_tile_records = false, used_tile_hints = false;
   bool records_off = false;  // this attempt: the records of the generations still to come were taken on other rays (see launch_mode 4)
   unsigned long long user = 0;  // identity of this ticket in the workspace registry (0: not drawn yet)
+  // record plan of this ticket (prt_trace_set_plan; prt_trace_kernels.hpp PlanDev): what the PLAN kernels are told
+  bool plan_active = false;
+  bool plan_dirty = false;            // the device copy is older than plan_host
+  bool sink_unclean = false;          // the slotted sums hold what an attempt that was not folded left there
+  struct PlanDev* plan_host = nullptr;  // (owned; the device copy sits in plan_dev)
+  struct PlanDev* plan_dev = nullptr;
+  double* sink_slots = nullptr;       // (slots, limit, n_groups, SINK_STATS): where the waves add
+  size_t sink_slot_bytes = 0;
+  double* sums_out = nullptr;         // the caller's (limit, n_groups, SINK_STATS) block
+  unsigned long long plan_key = 0;    // identifies the plan the scene's plan hints were learnt under
 };
 
 struct DeviceCopy {
@@ -94,6 +105,7 @@ struct DeviceCopy {
   std::vector<DevInstr*> component_code;        // one program per component, no I_ROOT
   TraceTicket ticket[PRT_TRACE_TICKETS];
   std::vector<hipEvent_t> busy_events;          // PRT_TRACE_BUSY: two per job of the largest batch so far (kept, reused)
+  std::vector<char> busy_recorded;              // ... per job of the current batch: its pair was recorded by a launch
   double busy[4] = {0, 0, 0, 0};                // prt_trace_batch_busy: what the last such batch measured
   bool ready = false;                           // everything above is in place (a copy whose upload failed half way is not)
 };
@@ -110,6 +122,11 @@ struct prt_scene {
   std::vector<Program> component_programs;
   std::vector<Operand> component_result;        // where each component program leaves its list
   std::vector<DeviceCopy> per_device;
+  // dense-mode hints of traces under a record plan (their own: what a plan stores changes which generations are dense)
+  std::vector<char> plan_hint_mode;
+  unsigned long long plan_hint_key = 0;
+  int plan_hint_rest = 0, plan_hint_misses_in_a_row = 0;
+  long long plan_launches = 0, plan_dense_launches = 0, plan_misses = 0;
   int tile_hint_holdoff = 0, tile_hint_misses_in_a_row = 0;  // per-tile records rest after a miss like the dense hints do
   long long tile_hint_launches = 0, tile_hint_misses = 0;
   bool has_untracable = false;                  // a shading error can be raised at store time (a surface without a
@@ -976,6 +993,9 @@ static void release_device_copy(DeviceCopy& c) {
     if (t.ev0) (void)hipEventDestroy(t.ev0);
     if (t.ev1) (void)hipEventDestroy(t.ev1);
     t.busy0 = t.busy1 = nullptr;
+    free((void*)t.plan_host);  // (malloc'ed by prt_trace_set_plan)
+    if (t.plan_dev) (void)hipFree(t.plan_dev);
+    if (t.sink_slots) (void)hipFree(t.sink_slots);
   }
   for (hipEvent_t e : c.busy_events) (void)hipEventDestroy(e);
   c = DeviceCopy();

@@ -481,6 +481,34 @@ struct HostMirror {
 };
 static_assert(offsetof(HostMirror, gen) == 64, "mirror header");
 
+// ---- record plans (round 6; include/prt.h prt_record_plan) ------------------------------------------------------------
+// What a trace records, when the caller does not want every row.  The reference appends one row per live ray and
+// generation (pyrayt/_pyrayt.py:168-186) and its users drop most of them on the next line -- `results.loc[results[
+// 'surface'] == imager.get_id()]` (examples/lens_design.ipynb cells 11, 19, 38), the rows of the last generation (cells
+// 12, 15, 20) -- to look at a spot size or a focus.  A plan lets the generation kernel do that while the row is still in
+// registers: rows of other surfaces than the listed ones are not stored (the 15 stores are 52 % of what a config-2
+// trace moves), and / or the per-group sums k_frame_reduce / k_frame_mean_square would compute from the stored frame
+// are accumulated right here, per generation (the caller picks the generation -- "the last one" -- afterwards).
+// One of these per ticket, in device memory the library owns; the PLAN instantiations of k_generation read it through
+// the constant address space (scalar loads).  The other instantiations never look at it.
+enum { SINK_STATS = 12 };  // [0..8] as k_frame_reduce (prt_frame.hpp); [9] rows with a finite v, [10] sum v, [11] sum v^2 (k_frame_mean_square)
+struct PlanDev {
+  int32_t n_rec;          // 0: rows of every surface pass; else only those of rec_prims[0 .. n_rec)
+  int32_t store_rows;     // the rows that pass are stored in rows_out (0: nothing is stored -- sums only)
+  int32_t n_groups;       // > 0: the rows that pass go to the sink
+  int32_t slots;          // copies of the sums the waves spread their atomics over (a power of two)
+  int32_t rec_prims[8];
+  double rays_per_source; // group = floor(id / rays_per_source) (_pyrayt.py:349-354); <= 0: one group
+  double* sums;           // (slots, generation_limit, n_groups, SINK_STATS), zeroed by the library before the trace
+  const double* pivots;   // (n_groups, 3) subtracted from y1, z1 and the axis intercept before accumulating, or null
+  int32_t ms_quantity;    // a frame column 0..14, 15 = the axis intercept x0 - x_tilt y0 / y_tilt, < 0: no mean-square sums
+  int32_t ms_transform;   // 0 none, 1 sin
+  double ms_about;
+  int32_t limit;          // generation_limit the sums were sized for
+  int32_t pad;
+};
+typedef const __attribute__((address_space(4))) PlanDev* ConstPlan;
+
 #define PRT_ERR_SPECULATION (-101) /* internal: a generation launched in dense mode was not dense -> host re-runs without hints */
 #define PRT_ERR_STALL (-100) /* internal: look-back gave up -> host falls back to the unfused path */
 #define PRT_ERR_TILE_HINT (-103) /* internal: a generation launched on the per-tile record of its last run found other counts -> host re-runs without the records */
@@ -688,7 +716,10 @@ __device__ __forceinline__ bool interact_store_rows(const Shaded& s, const Ray8&
                                                     unsigned next_bytes, double* __restrict__ nxt, int64_t ld_next,
                                                     double* __restrict__ rec, int64_t ld_rows,
                                                     double next_generation, int relaunch, double ray_offset,
-                                                    bool lean = false, double id0 = 0.0) {
+                                                    bool lean = false, double id0 = 0.0, bool record = true) {
+  // (record == false: a PLAN launch whose record plan drops this ray's row -- see PlanDev; the default kernels pass
+  // the constant `true`)
+  if (record) {
   row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_GENERATION * ld_rows, row_bytes, s.generation);
   row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_INTENSITY * ld_rows, row_bytes, s.intensity);
   row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_WAVELENGTH * ld_rows, row_bytes, s.wavelength);
@@ -704,6 +735,7 @@ __device__ __forceinline__ bool interact_store_rows(const Shaded& s, const Ray8&
   row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_XTILT * ld_rows, row_bytes, s.tx);
   row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_YTILT * ld_rows, row_bytes, s.ty);
   row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_ZTILT * ld_rows, row_bytes, s.tz);
+  }
   if (carry) {
     double qx = s.px, qy = s.py, qz = s.pz, qw = s.pw;
     if (relaunch) {
@@ -740,6 +772,88 @@ __device__ __forceinline__ bool interact_store_rows(const Shaded& s, const Ray8&
   return true;
 }
 
+// The sink of a record plan: what k_frame_reduce and k_frame_mean_square (prt_frame.hpp) would read back out of the
+// stored frame, accumulated while the row is in registers.  Same per-row values (the operands are the very numbers the
+// record stores would have written: x0, y0 = the pre-hit origin, x1 .. z1 = the hit point, the unit tilts), summed per
+// wave with xor shuffles and added with one atomic per statistic to this generation's block of the caller's sums --
+// spread over `slots` copies (prt_sink_fold adds them up): a generation of a million rays is 16 000 waves, and that
+// many atomics on twelve words would take longer than the generation.  A wave's rows almost always fall into one
+// group (ids ascend along the tile); a wave that straddles groups works them off one after the other.
+__device__ __forceinline__ double sink_quantity(int quantity, const Shaded& s, double ox, double oy, double oz) {
+  switch (quantity) {  // (uniform)
+    case PRT_COL_GENERATION: return s.generation;
+    case PRT_COL_INTENSITY: return s.intensity;
+    case PRT_COL_WAVELENGTH: return s.wavelength;
+    case PRT_COL_INDEX: return s.index_in;
+    case PRT_COL_ID: return s.id;
+    case PRT_COL_SURFACE: return s.surface_id;
+    case PRT_COL_X0: return ox;
+    case PRT_COL_Y0: return oy;
+    case PRT_COL_Z0: return oz;
+    case PRT_COL_X1: return s.px;
+    case PRT_COL_Y1: return s.py;
+    case PRT_COL_Z1: return s.pz;
+    case PRT_COL_XTILT: return s.tx;
+    case PRT_COL_YTILT: return s.ty;
+    case PRT_COL_ZTILT: return s.tz;
+    default: return ox - s.tx * oy / s.ty;  // the axis intercept (k_frame_mean_square's FRAME_AXIS_INTERCEPT)
+  }
+}
+__device__ __forceinline__ void sink_accumulate(ConstPlan plan, int g, bool sunk, const Shaded& s, double ox, double oy,
+                                                double oz) {
+  if (__ballot(sunk) == 0ull) return;  // (uniform)
+  const int n_groups = plan->n_groups, lane = threadIdx.x & 63;
+  const double rays_per_source = plan->rays_per_source;
+  int group = -1;
+  if (sunk) {
+    group = 0;
+    if (rays_per_source > 0) {
+      const double q = floor(s.id / rays_per_source);  // _pyrayt.py:352
+      group = (q >= 0 && q < (double)n_groups) ? (int)q : -1;
+    }
+  }
+  double v[SINK_STATS];
+#pragma unroll
+  for (int k = 0; k < SINK_STATS; ++k) v[k] = 0.0;
+  if (group >= 0) {
+    double pivot_y = 0.0, pivot_z = 0.0, pivot_focus = 0.0;
+    const double* __restrict__ pivots = plan->pivots;
+    if (pivots) { pivot_y = pivots[3 * group]; pivot_z = pivots[3 * group + 1]; pivot_focus = pivots[3 * group + 2]; }
+    const double y = s.py - pivot_y, z = s.pz - pivot_z;
+    const double focus = ox - s.tx * oy / s.ty;
+    const double f = focus - pivot_focus;
+    const bool f_ok = f == f && fabs(f) < PRT_INF;  // a ray parallel to the axis has no intercept
+    v[0] = 1.0; v[1] = y; v[2] = z; v[3] = y * y + z * z;
+    v[4] = f_ok ? f : 0.0; v[5] = f_ok ? f * f : 0.0;
+    v[6] = s.wavelength; v[7] = s.intensity;
+    v[8] = f_ok ? 1.0 : 0.0;
+    const int quantity = plan->ms_quantity;
+    if (quantity >= 0) {  // (uniform)
+      double q = sink_quantity(quantity, s, ox, oy, oz);
+      if (plan->ms_transform == 1) q = sin(q);
+      const double w = q - plan->ms_about;
+      const bool w_ok = w == w && fabs(w) < PRT_INF;
+      v[9] = w_ok ? 1.0 : 0.0; v[10] = w_ok ? w : 0.0; v[11] = w_ok ? w * w : 0.0;
+    }
+  }
+  const int64_t wave_id = (int64_t)blockIdx.x * (PRT_BLOCK / 64) + (threadIdx.x >> 6);
+  double* const mine = plan->sums + ((size_t)(wave_id & (plan->slots - 1)) * plan->limit + g) * n_groups * SINK_STATS;
+  unsigned long long pending = __ballot(group >= 0);
+  while (pending) {  // one turn per group present in the wave: almost always exactly one
+    const int leader = __ffsll((long long)pending) - 1;
+    const int cur = __shfl(group, leader);
+    const bool take = group == cur;
+#pragma unroll
+    for (int k = 0; k < SINK_STATS; ++k) {
+      double t = take ? v[k] : 0.0;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+      if (lane == 0 && t != 0.0) atomicAdd(mine + (size_t)cur * SINK_STATS + k, t);
+    }
+    pending &= ~__ballot(take);
+  }
+}
+
 // Register-allocated for 5 waves per SIMD (96 VGPRs, no spills -- possible because the record
 // columns known before the shading wait in LDS, see PARK).  Measured on MI355X, same box,
 // interleaved: occupancy matters (identical code held to 3 workgroups/CU by LDS padding is 30 %
@@ -750,14 +864,20 @@ __device__ __forceinline__ bool interact_store_rows(const Shaded& s, const Ray8&
 #endif
 // CULL = the trace program carries component cull steps (scenes of three or more components);
 // the instantiation without them is the one the register budget above was tuned for.
-template <bool CULL, bool COMPACT>
+// PLAN = the trace runs under a record plan (PlanDev): which rows are stored is decided per ray, the sums of the rows
+// that pass may be accumulated in the kernel, and `assume` carries two fields -- bits 0..3 how the carried rays are
+// placed (0 look-back, 1 every ray goes on, 2 none does), bit 4 "no ray of this generation stores a row" (else, in a
+// dense form: every ray does).  The instantiations without a plan are the product kernels of round 5, instruction for
+// instruction (tools/kernel_isa.py): everything a plan adds sits behind `if (PLAN)`.
+template <bool CULL, bool COMPACT, bool PLAN = false>
 __global__ void __launch_bounds__(PRT_BLOCK, PRT_GEN_WAVES)
 k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double* __restrict__ next,
              int64_t ld_next, double* __restrict__ rows, int64_t ld_rows, FusedCtrl* __restrict__ ctrl,
              GenCtrl* __restrict__ gen, int g, unsigned long long* __restrict__ tiles_cur,
              unsigned long long* __restrict__ tiles_next, double next_generation, int generation_limit,
              double ray_offset, int keep_absorbed, HostMirror* mirror, unsigned long long epoch,
-             int mirror_slot, int batch_last, int assume) {
+             int mirror_slot, int batch_last, int assume, const PlanDev* plan_dev) {
+  const ConstPlan plan = (ConstPlan)(unsigned long long)plan_dev;
   const int relaunch = (g + 1 != generation_limit) ? 1 : 0;  // the state written here is traced further
   __shared__ int s_wave_live[4], s_wave_carry[4];
   __shared__ unsigned s_excl[3];
@@ -800,6 +920,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   double t = PRT_INF;
   int prim = -1;
   bool live = false, carry = false, absorbs = false;
+  bool stored = false, sunk = false;  // (PLAN: this ray's row is stored / goes to the sink)
   STAMP(0);
   if (i < n && !failed) {
     // all 13 rows in one burst; the five metadata rows go straight to the lane's parking slots in
@@ -863,11 +984,23 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     // (one scalar test instead of a per-lane table lookup in HBM)
     if (live) absorbs = prim < 64 ? ((scene.absorber_mask >> prim) & 1ull) != 0 : scene.prims[prim].mat_kind == MAT_ABSORBER;
     carry = live && (keep_absorbed || !absorbs);
+    if (PLAN) {
+      bool wanted = live;
+      const int n_rec = plan->n_rec;
+      if (n_rec > 0) {  // (uniform)
+        bool listed = false;
+        for (int k = 0; k < n_rec; ++k) listed = listed || prim == plan->rec_prims[k];
+        wanted = live && listed;
+      }
+      stored = wanted && plan->store_rows != 0;
+      sunk = wanted && plan->n_groups > 0;
+    }
   }
   // workgroup aggregate and ranks: wave ballots + popcounts, four waves combined through LDS
+  // (PLAN: "live" in everything that places or counts rows below means "stores a row")
   STAMP(2);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned long long m_live = __ballot(live), m_carry = __ballot(carry);
+  const unsigned long long m_live = __ballot(PLAN ? stored : live), m_carry = __ballot(carry);
   // (absorbed rays that go on, dead, because this launch keeps them: counted per tile for the dead list)
   const unsigned long long m_kept = keep_absorbed ? __ballot(absorbs) : 0ull;
   const unsigned long long below = (1ull << lane) - 1ull;
@@ -891,7 +1024,9 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   agg_carry &= 0xffffu;
   // Launched on the dead list of the generation before (assume 5 / 6): the dead rays in front of this tile, in it,
   // and in all; one wave reads the list (a handful of entries as a rule: that is when the host offers this mode)
-  if (assume >= 5 && wave == 0) {
+  const int carry_form = PLAN ? (assume & 15) : assume;  // (a plan's launches: 0, 1 or 2)
+  const bool rec_none = PLAN && (assume & 16) != 0;
+  if (!PLAN && assume >= 5 && wave == 0) {
     const DeadList* dead = dead_list(gen, g - 1);
     const unsigned entries = dead->count;
     unsigned before = 0, here = 0, all = 0;
@@ -924,13 +1059,14 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   // any status word), and the last one to arrive publishes, with every tile's verdict visible to it
   // (assume == 3: whether the generation ends the trace is in the previous trace's totals, still in its slot)
   const bool publish_here = assume && mirror != nullptr &&
-                            (assume == 2 || assume == 6 || batch_last ||
-                             (assume == 3 && (gen[g].n_live == 0 || gen[g].n_carry == 0)));
+                            (PLAN ? (carry_form == 2 || batch_last)
+                                  : (assume == 2 || assume == 6 || batch_last ||
+                                     (assume == 3 && (gen[g].n_live == 0 || gen[g].n_carry == 0))));
   if (assume) {
     if (threadIdx.x == 0) {
       const int64_t mine = (n - (int64_t)tile * PRT_BLOCK) < PRT_BLOCK ? (n - (int64_t)tile * PRT_BLOCK) : PRT_BLOCK;
-      bool holds = (int64_t)agg_live == mine && (int64_t)agg_carry == (assume == 1 ? mine : 0);
-      if (assume >= 5) {  // (thread 0 wrote s_excl itself, above)
+      bool holds = (int64_t)agg_live == (rec_none ? 0 : mine) && (int64_t)agg_carry == (carry_form == 1 ? mine : 0);
+      if (!PLAN && assume >= 5) {  // (thread 0 wrote s_excl itself, above)
         const unsigned before = s_excl[0];
         const int64_t alive = mine - (int64_t)s_excl[1];
         holds = (int64_t)agg_live == alive && (int64_t)agg_carry == (assume == 5 ? alive : 0);
@@ -939,12 +1075,12 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
       }
       // a tile of a launch that keeps its absorbed rays notes how many it kept (generation 0 has nobody to empty
       // its list for it: it keeps rays without noting them, and the generation behind it compacts by look-back)
-      if (agg_kept && g > 0) {
+      if (!PLAN && agg_kept && g > 0) {
         DeadList* dead = dead_list(gen, g);
         const unsigned at = atomicAdd(&dead->count, 1u);
         if (at < (unsigned)kDeadListCap) dead->entry[at] = ((unsigned)tile << 9) | agg_kept;
       }
-      if (assume == 3) {  // the previous trace's record of this tile
+      if (!PLAN && assume == 3) {  // the previous trace's record of this tile
         const TileHint h = tile_hints(gen, g)[tile];
         holds = agg_live == h.live && agg_carry == h.carry && n == *reinterpret_cast<const int64_t*>(gen[g].pad);
         s_excl[0] = h.excl_live;
@@ -990,13 +1126,13 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   STAMP(5);
   const int64_t last_tile = (n - 1) / PRT_BLOCK;
   int64_t excl_live, excl_carry;
-  if (assume == 3 || assume >= 5) {
+  if (!PLAN && (assume == 3 || assume >= 5)) {
     __syncthreads();
     excl_live = s_excl[0];
     excl_carry = s_excl[1];
   } else if (assume) {
-    excl_live = (int64_t)tile * PRT_BLOCK;
-    excl_carry = assume == 1 ? (int64_t)tile * PRT_BLOCK : 0;
+    excl_live = rec_none ? 0 : (int64_t)tile * PRT_BLOCK;
+    excl_carry = carry_form == 1 ? (int64_t)tile * PRT_BLOCK : 0;
   } else {
   if (wave == 0) {
     unsigned e_live, e_carry;
@@ -1006,7 +1142,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     (void)ok;
     if (lane == 0) {
       s_excl[0] = e_live; s_excl[1] = e_carry;
-      if (g < kTileHintGenerations) tile_hints(gen, g)[tile] = TileHint{e_live, e_carry, agg_live, agg_carry};
+      if (!PLAN && g < kTileHintGenerations) tile_hints(gen, g)[tile] = TileHint{e_live, e_carry, agg_live, agg_carry};
     }
   }
   __syncthreads();
@@ -1021,10 +1157,14 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     // (dense mode: the totals are the assumption itself; if it failed the error word says so)
     // (assume == 3: the totals of the previous trace's generation g are still in its slot)
     // (assume 5 / 6: every ray but the dead ones of the list)
-    const int64_t total_live = assume == 3 ? gen[g].n_live : assume >= 5 ? n - (int64_t)s_excl[2] : assume ? n : excl_live + agg_live;
-    const int64_t total_carry = assume == 3 ? gen[g].n_carry
+    const int64_t total_live = PLAN ? (assume ? (rec_none ? 0 : n) : excl_live + agg_live)
+                               : assume == 3 ? gen[g].n_live : assume >= 5 ? n - (int64_t)s_excl[2] : assume ? n : excl_live + agg_live;
+    const int64_t total_carry = PLAN ? (assume ? (carry_form == 1 ? n : 0) : excl_carry + agg_carry)
+                                : assume == 3 ? gen[g].n_carry
                                 : assume ? (assume == 1 ? n : assume == 5 ? n - (int64_t)s_excl[2] : 0) : excl_carry + agg_carry;
-    const int64_t next_in = (total_live == 0) ? 0 : total_carry;
+    // (the rays that go on are among those that were alive: no row recorded means no ray carried -- unless a plan
+    // stores no row for rays that live on)
+    const int64_t next_in = PLAN ? total_carry : ((total_live == 0) ? 0 : total_carry);
     gen[g].n_live = total_live;
     gen[g].n_carry = total_carry;
     gen[g + 1].n_in = next_in;
@@ -1081,9 +1221,12 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   }
   if (!interact_store_rows<COMPACT>(sh, r, carry, (unsigned)live_rank * 8u, (unsigned)carry_rank * 8u,
                                     next + uniform64(excl_carry), ld_next, rows + uniform64(row_base + excl_live),
-                                    ld_rows, next_generation, relaunch, ray_offset, lean_out, id0))
+                                    ld_rows, next_generation, relaunch, ray_offset, lean_out, id0, PLAN ? stored : true))
     atomicExch(&ctrl->error, PRT_ERR_FULL_ROWS);
   if (sh.err) raise_error(&ctrl->error, sh.err);
+  if (PLAN) {
+    if (plan->n_groups > 0) sink_accumulate(plan, g, sunk, sh, r.ox, r.oy, r.oz);  // (uniform)
+  }
   STAMP(7);
 }
 

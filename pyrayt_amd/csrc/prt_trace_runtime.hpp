@@ -191,6 +191,111 @@ extern "C" void prt_debug_host_profile(double* out9) { for (int k = 0; k < 8; ++
 #define HP(k)
 #endif
 
+// ---- record plans (include/prt.h prt_record_plan; the device side is PlanDev in prt_trace_kernels.hpp) -------------
+// the plan as the kernels read it, put into the ticket's device copy on the trace's stream
+__global__ void k_plan_set(PlanDev* dst, PlanDev value) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = value;
+}
+// out[e] = the sum over the slots of slotted[slot][e]; the slots are left zeroed for the ticket's next trace
+__global__ void __launch_bounds__(PRT_BLOCK)
+k_sink_fold(double* __restrict__ slotted, int slots, int n, double* __restrict__ out) {
+  const int e = blockIdx.x * PRT_BLOCK + threadIdx.x;
+  if (e >= n) return;
+  double v = 0.0;
+  for (int k = 0; k < slots; ++k) {
+    v += slotted[(size_t)k * n + e];
+    slotted[(size_t)k * n + e] = 0.0;
+  }
+  out[e] = v;
+}
+
+static unsigned long long plan_key_of(const PlanDev& p) {  // what the plan's dense-mode hints depend on
+  unsigned long long h = 1469598103934665603ull;
+  auto mix = [&](unsigned long long v) { h = (h ^ v) * 1099511628211ull; };
+  mix((unsigned long long)p.n_rec);
+  mix((unsigned long long)(p.store_rows != 0));
+  for (int k = 0; k < p.n_rec; ++k) mix((unsigned long long)(unsigned)p.rec_prims[k]);
+  return h | 1ull;
+}
+
+extern "C" int prt_trace_set_plan(prt_scene* s, int device, int ticket, const prt_record_plan* plan) {
+  DeviceCopy* c;
+  int rc = on_device(s, device, &c);
+  if (rc) return rc;
+  if (ticket < 0 || ticket >= PRT_TRACE_TICKETS) return fail(PRT_ERR_ARG, "ticket out of range");
+  TraceTicket* t = &c->ticket[ticket];
+  if (t->active) return fail(PRT_ERR_ARG, "this ticket has a trace in flight (prt_trace_end it first)");
+  if (!plan) {
+    t->plan_active = false;
+    return PRT_OK;
+  }
+  if (plan->struct_size != (int32_t)sizeof(prt_record_plan)) return fail(PRT_ERR_ARG, "prt_record_plan.struct_size does not match this library");
+  if (plan->n_surfaces < 0 || plan->n_surfaces > 8 || plan->n_groups < 0 || plan->generation_limit < 1 ||
+      plan->generation_limit > kMaxGenerationSlots)
+    return fail(PRT_ERR_ARG, "record plan: 0..8 surfaces, n_groups >= 0, 1 <= generation_limit <= 1024");
+  if (plan->n_groups > 0 && !plan->sums_out) return fail(PRT_ERR_ARG, "record plan: n_groups > 0 needs sums_out");
+  if (!(plan->rays_per_source > 0) && plan->n_groups > 1) return fail(PRT_ERR_ARG, "record plan: one group without rays_per_source");
+  if (plan->ms_quantity > PRT_FRAME_AXIS_INTERCEPT || plan->ms_transform < 0 || plan->ms_transform > 1)
+    return fail(PRT_ERR_ARG, "record plan: ms_quantity is a frame column 0..14, 15 (axis intercept) or < 0; ms_transform 0 | 1");
+  if (!plan->store_rows && plan->n_groups == 0 && plan->n_surfaces == 0)
+    return fail(PRT_ERR_ARG, "record plan: neither rows nor sums are asked for");
+  PlanDev p;
+  memset(&p, 0, sizeof(p));
+  p.n_rec = plan->n_surfaces;
+  for (int k = 0; k < plan->n_surfaces; ++k) {
+    // (a surface id that is none of the scene's passes no row: a primitive index no ray can hit)
+    p.rec_prims[k] = -2;
+    for (size_t q = 0; q < s->dev_prims.size(); ++q)
+      if ((int64_t)s->dev_prims[q].surface_id == plan->surfaces[k]) p.rec_prims[k] = (int32_t)q;
+  }
+  p.store_rows = plan->store_rows ? 1 : 0;
+  p.n_groups = plan->n_groups;
+  p.rays_per_source = plan->rays_per_source;
+  p.pivots = plan->pivots;
+  p.ms_quantity = plan->ms_quantity < 0 ? -1 : plan->ms_quantity;
+  p.ms_transform = plan->ms_transform;
+  p.ms_about = plan->ms_about;
+  p.limit = plan->generation_limit;
+  // the slotted sums: as many copies as stay under 8 MiB, at most 64, a power of two
+  p.slots = 1;
+  size_t per_slot = (size_t)p.limit * (size_t)(p.n_groups > 0 ? p.n_groups : 0) * SINK_STATS * sizeof(double);
+  if (p.n_groups > 0) {
+    while (p.slots < 64 && per_slot * (size_t)p.slots * 2 <= ((size_t)8 << 20)) p.slots *= 2;
+    const size_t need = per_slot * (size_t)p.slots;
+    if (need > t->sink_slot_bytes) {
+      HIP_TRY(hipDeviceSynchronize());  // (nothing of an earlier plan's traces may still add to the block given back)
+      if (t->sink_slots) (void)hipFree(t->sink_slots);
+      t->sink_slots = nullptr;
+      t->sink_slot_bytes = 0;
+      HIP_TRY(hipMalloc((void**)&t->sink_slots, need));
+      t->sink_slot_bytes = need;
+    }
+    t->sink_unclean = true;  // (cleared on the stream of the first trace under the plan)
+  }
+  p.sums = t->sink_slots;
+  if (!t->plan_dev) HIP_TRY(hipMalloc((void**)&t->plan_dev, sizeof(PlanDev)));
+  if (!t->plan_host) t->plan_host = (PlanDev*)malloc(sizeof(PlanDev));
+  if (!t->plan_host) return fail(PRT_ERR_HIP, "out of host memory");
+  *t->plan_host = p;
+  t->sums_out = plan->sums_out;
+  t->plan_key = plan_key_of(p);
+  t->plan_dirty = true;
+  t->plan_active = true;
+  return PRT_OK;
+}
+
+// behind a trace under a plan that sums: fold the slots into the caller's block (and leave them zeroed)
+static int plan_fold(TraceTicket* t) {
+  const PlanDev& p = *t->plan_host;
+  if (p.n_groups <= 0) return PRT_OK;
+  const int n = p.limit * p.n_groups * SINK_STATS;
+  hipLaunchKernelGGL(k_sink_fold, dim3((n + PRT_BLOCK - 1) / PRT_BLOCK), dim3(PRT_BLOCK), 0, t->st, t->sink_slots,
+                     p.slots, n, t->sums_out);
+  HIP_TRY(hipGetLastError());
+  t->sink_unclean = false;
+  return PRT_OK;
+}
+
 // enqueue generations [t->g, t->g + t->batch) of the ticket's trace (one launch each, no host round trip
 // in between) and whatever has to run behind them; they publish t->epoch to the ticket's mirror
 static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
@@ -220,10 +325,32 @@ static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
   const bool culls = s->has_cull_steps;
   auto kernel = t->compact ? (culls ? k_generation<true, true> : k_generation<false, true>)
                            : (culls ? k_generation<true, false> : k_generation<false, false>);
+  if (t->plan_active)
+    kernel = t->compact ? (culls ? k_generation<true, true, true> : k_generation<false, true, true>)
+                        : (culls ? k_generation<true, false, true> : k_generation<false, false, true>);
   for (int b = 0; b < t->batch; ++b) {
     const int gg = t->g + b;
     const double* src = (gg == 0) ? t->rays : buf[(gg - 1) & 1];
     const int64_t src_ld = (gg == 0) ? t->ld : n;
+    if (t->plan_active) {
+      // A trace under a record plan: the dense forms it knows are "every ray goes on" / "none does", each with
+      // "every ray stores a row" / "none does" (k_generation<.., PLAN>); anything else compacts by look-back.  A plan
+      // that stores no rows keeps its absorbed rays (as upstream carries them, _pyrayt.py:415-428): nothing of theirs is
+      // stored or summed, and the generation that absorbed a few stays dense.
+      int assume = 0;
+      if (t->use_hints && gg < (int)s->plan_hint_mode.size()) assume = s->plan_hint_mode[gg];
+      t->launch_mode[gg] = (char)assume;
+      s->plan_launches += 1;
+      s->plan_dense_launches += assume ? 1 : 0;
+      const int keep = (keep_absorbed || !t->plan_host->store_rows) ? 1 : 0;
+      hipLaunchKernelGGL(kernel, dim3(blocks_for(n)), dim3(PRT_BLOCK), lds, st, sd, src, src_ld, buf[gg & 1], n,
+                         t->rows_out, t->rows_cap, ctrl, gen, gg, tiles[t->flip], tiles[t->flip ^ 1], (double)(gg + 1),
+                         t->limit, t->ray_offset, keep,
+                         t->publish_in_kernel ? t->mirror_dev : (HostMirror*)nullptr, epoch, b,
+                         b + 1 == t->batch ? 1 : 0, assume, (const PlanDev*)t->plan_dev);
+      t->flip ^= 1;
+      continue;
+    }
     // dense-mode hint of the previous trace for this generation (the kernel reads the generation's
     // ray count on the device and checks the assumption tile by tile)
     int assume = 0;
@@ -277,7 +404,7 @@ static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
                        t->rows_out, t->rows_cap, ctrl, gen, gg, tiles[t->flip], tiles[t->flip ^ 1], (double)(gg + 1),
                        t->limit, t->ray_offset, keep,
                        t->publish_in_kernel ? t->mirror_dev : (HostMirror*)nullptr, epoch, b,
-                       b + 1 == t->batch ? 1 : 0, assume);
+                       b + 1 == t->batch ? 1 : 0, assume, (const PlanDev*)nullptr);
     t->flip ^= 1;
     if (b == 0) HP(4);
   }
@@ -295,7 +422,12 @@ static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
                        t->limit, tiles[0], (int64_t)blocks_for(n), n, t->test_stall, t->mirror_dev, epoch,
                        t->g, t->batch + 1);
   }
-  if (t->busy1) HIP_TRY(hipEventRecord(t->busy1, st));
+  if (t->busy1) {
+    HIP_TRY(hipEventRecord(t->busy1, st));
+    // (both events of the pair are on the stream now -- busy0 was recorded by this attempt's first batch: only such a
+    // job enters the merged intervals, whatever path a job that launches nothing took)
+    if (t->busy_recorded && t->busy0) *t->busy_recorded = 1;
+  }
   HIP_TRY(hipGetLastError());
   HP(5);
   t->launched = true;
@@ -340,13 +472,33 @@ static int fused_start(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
   // tile checks them on its own rays, so they serve a ray set of another SIZE as well: a design loop that
   // changes its ray count from call to call keeps them)
   t->use_hints = allow_hints && s->hint_n >= 0 && s->hint_keep_absorbed == keep_absorbed && !t->test_stall;
+  if (t->plan_active) {
+    // the plan as the kernels read it (once per change), clean sums (after an attempt that was not folded), and the
+    // plan's own hints: those of the last trace of this scene under a plan that stores the same rows
+    if (t->plan_dirty) {
+      hipLaunchKernelGGL(k_plan_set, dim3(1), dim3(1), 0, t->st, t->plan_dev, *t->plan_host);
+      t->plan_dirty = false;
+    }
+    if (t->plan_host->n_groups > 0) {
+      if (t->sink_unclean) HIP_TRY(hipMemsetAsync(t->sink_slots, 0, t->sink_slot_bytes, t->st));
+      t->sink_unclean = true;  // (until plan_fold has run behind this attempt)
+    }
+    bool plan_hints = t->allow_hints && s->plan_hint_key == t->plan_key && !t->test_stall;
+    if (plan_hints && s->plan_hint_rest > 0) {
+      s->plan_hint_rest -= 1;
+      plan_hints = false;
+    }
+    t->use_hints = plan_hints;
+    allow_hints = false;  // (no per-tile records, no dead lists under a plan)
+  }
   // The per-tile records of this ticket's last trace (TileHint) serve the generations that compact: offered with
   // the other hints, to a trace that publishes from its kernels (the slots the records lean on are then never
   // cleared between traces), and rested after a miss like them.
   // ... and only to a trace of the very buffer the records were taken from: another ray set loses its rays in other
   // tiles, every offer would be a miss and a repeat (a caller that refills one buffer with new rays is still offered
   // them -- and every tile checks)
-  bool allow_tiles = t->allow_tile_hints && t->use_hints && t->publish_in_kernel && t->record_rays == t->rays;
+  bool allow_tiles = t->allow_tile_hints && t->use_hints && t->publish_in_kernel && t->record_rays == t->rays &&
+                     !t->plan_active;
   if (allow_tiles && s->tile_hint_holdoff > 0) {
     s->tile_hint_holdoff -= 1;
     allow_tiles = false;
@@ -403,6 +555,13 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
       if ((host_gen[b].n_in - host_gen[b].n_live) * 32 > host_gen[b].n_in) t->seen_sparse[t->n_seen] |= 8;
       if ((host_gen[b].n_in - host_gen[b].n_live) * 16 > host_gen[b].n_in) t->seen_sparse[t->n_seen] |= 16;
       t->seen_mode[t->n_seen++] = all_live && lost == 0 ? 1 : all_live && host_gen[b].n_carry == 0 ? 2 : 0;
+      if (t->plan_active) {
+        // under a record plan (n_live counts the rows STORED): a generation is dense when its rays all go on or none
+        // does, and all of them store a row or none does (k_generation<.., PLAN>: bits 0..3 | bit 4)
+        const int carry_form = lost == 0 ? 1 : host_gen[b].n_carry == 0 ? 2 : 0;
+        const bool rec_all = all_live, rec_none = host_gen[b].n_live == 0;
+        t->seen_mode[t->n_seen - 1] = (char)(carry_form && (rec_all || rec_none) ? (carry_form | (rec_none ? 16 : 0)) : 0);
+      }
     }
     if (!done && host_gen[t->batch].n_in == 0) done = true;
     t->g += t->batch;
@@ -412,6 +571,25 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
     if (rc) return rc;
   }
   t->launched = false;
+  if (t->plan_active) {
+    // a trace under a record plan keeps its own hints and touches none of the scene's others
+    for (bool& kept : t->tile_record) kept = false;  // (the plan's launches leave no per-tile records, and reuse the slots)
+    if (error == PRT_ERR_SPECULATION || error == PRT_ERR_FULL_ROWS) return error;
+    if (error == PRT_ERR_ROWS_CAP && t->use_hints) return PRT_ERR_SPECULATION;  // (too small for the hint, perhaps not for the rows)
+    if (error == PRT_ERR_STALL) return PRT_ERR_STALL;
+    if (error) return trace_error(error);
+    if (!t->publish_in_kernel) t->flip = 0;
+    s->last_generations = (int)t->stats[0];
+    s->plan_hint_mode.assign(t->seen_mode, t->seen_mode + t->n_seen);
+    s->plan_hint_key = t->plan_key;
+    if (t->use_hints) s->plan_hint_misses_in_a_row = 0;
+    t->ready_workspace = t->w;
+    t->ready_n = t->n;
+    t->ready_slots = t->limit + 1;
+    t->ready_stall = t->test_stall;
+    t->record_rays = nullptr;
+    return t->total_rows;
+  }
   if (error) for (bool& kept : t->tile_record) kept = false;  // (whatever the attempt overwrote before it failed)
   if (!error) {
     // Which generations keep their absorbed rays next time (mode 4, see the launch loop).  It moves the compaction to
@@ -551,6 +729,17 @@ extern "C" int prt_trace_begin(prt_scene* s, int device, int ticket, const doubl
   t->compact = !s->full_rows && !(flags & PRT_TRACE_FULL_ROWS);
   t->active = true;
   if (n == 0 || generation_limit == 0) { reset_stats(s, t, PRT_VARIANT_FUSED); return PRT_OK; }
+  if (t->plan_active) {
+    if (flags & (PRT_TRACE_UNFUSED | PRT_TRACE_COUNT_PATHS)) {
+      t->active = false;
+      return fail(PRT_ERR_ARG, "a trace under a record plan runs on the fused path only (PRT_TRACE_UNFUSED / COUNT_PATHS)");
+    }
+    if (generation_limit > t->plan_host->limit) {
+      t->active = false;
+      return fail(PRT_ERR_ARG, "generation_limit exceeds the record plan's");
+    }
+    if (t->plan_host->store_rows && rows_cap > 0 && !rows_out) { t->active = false; return fail(PRT_ERR_ARG, "bad buffers"); }
+  }
   if (flags & PRT_TRACE_COUNT_PATHS) t->flags |= PRT_TRACE_UNFUSED;  // the counting nearest-hit kernel lives on that path
   if (t->flags & PRT_TRACE_UNFUSED) {  // host round trip per generation: everything happens in prt_trace_end
     reset_stats(s, t, s->options.hit_lanes > 1 ? PRT_VARIANT_KLANES : PRT_VARIANT_UNFUSED);
@@ -574,7 +763,11 @@ extern "C" int64_t prt_trace_end(prt_scene* s, int device, int ticket, int64_t* 
   s->stats_device = device;
   s->stats_ticket = ticket;
   for (int g = 0; g < t->limit; ++g) rows_per_generation[g] = 0;
-  if (t->n == 0 || t->limit == 0) return 0;
+  if (t->n == 0 || t->limit == 0) {
+    if (t->plan_active && t->plan_host->n_groups > 0)  // (no ray, no row: the sums of this trace are zeros)
+      HIP_TRY(hipMemsetAsync(t->sums_out, 0, (size_t)t->plan_host->limit * t->plan_host->n_groups * SINK_STATS * sizeof(double), t->st));
+    return 0;
+  }
   int64_t rc64 = 0;
   if (t->flags & PRT_TRACE_UNFUSED) {
     rc64 = trace_unfused(s, c, t, rows_per_generation);
@@ -589,6 +782,13 @@ extern "C" int64_t prt_trace_end(prt_scene* s, int device, int ticket, int64_t* 
         s->tile_hint_misses_in_a_row = std::min(s->tile_hint_misses_in_a_row + 1, 6);
         s->tile_hint_holdoff = 1 << s->tile_hint_misses_in_a_row;
         t->allow_tile_hints = false;
+      } else if (rc64 == PRT_ERR_SPECULATION && t->plan_active) {
+        // (the plan's own hints: forgotten, learnt again from the repeat, rested 2, 4 .. 64 traces after misses in a row)
+        s->plan_misses += 1;
+        s->plan_hint_misses_in_a_row = std::min(s->plan_hint_misses_in_a_row + 1, 6);
+        s->plan_hint_rest = 1 << s->plan_hint_misses_in_a_row;
+        s->plan_hint_key = 0;
+        t->allow_hints = false;
       } else if (rc64 == PRT_ERR_SPECULATION) {
         // a generation assumed dense was not (the rays or the scene changed since the hints were taken):
         // nothing of this attempt is kept; run again without assumptions, which also renews the hints
@@ -614,6 +814,8 @@ extern "C" int64_t prt_trace_end(prt_scene* s, int device, int ticket, int64_t* 
     }
     if (rc64 == PRT_ERR_SPECULATION || rc64 == PRT_ERR_FULL_ROWS || rc64 == PRT_ERR_TILE_HINT)
       rc64 = fail(PRT_ERR_HIP, "trace kept failing its own assumptions");
+    if (rc64 == PRT_ERR_STALL && t->plan_active)
+      rc64 = fail(PRT_ERR_HIP, "the look-back of a trace under a record plan gave up (no three-kernel path under a plan)");
     if (rc64 == PRT_ERR_STALL) {  // never observed outside the test hook; see lookback()
       for (int g = 0; g < t->limit; ++g) rows_per_generation[g] = 0;
       rc = settle_timing(t);
@@ -622,6 +824,10 @@ extern "C" int64_t prt_trace_end(prt_scene* s, int device, int ticket, int64_t* 
       reset_stats(s, t, PRT_VARIANT_UNFUSED);
       rc64 = trace_unfused(s, c, t, rows_per_generation);
     }
+  }
+  if (rc64 >= 0 && t->plan_active && !(t->flags & PRT_TRACE_UNFUSED)) {
+    rc = plan_fold(t);  // (the sums of this trace, on its stream, behind its last kernel)
+    if (rc) return rc;
   }
   if (rc64 >= 0 && (t->flags & PRT_TRACE_SYNC)) HIP_TRY(hipStreamSynchronize(t->st));
 #ifdef PRT_HOST_PROFILE
@@ -672,6 +878,7 @@ extern "C" int64_t prt_trace_batch(prt_scene* s, int device, prt_trace_job* jobs
       c->busy_events.push_back(e);
     }
     for (double& v : c->busy) v = 0;
+    c->busy_recorded.assign((size_t)count, 0);
   }
   int64_t sum = 0, first_error = 0;
   std::string message;
@@ -687,19 +894,20 @@ extern "C" int64_t prt_trace_batch(prt_scene* s, int device, prt_trace_job* jobs
       const prt_trace_job& job = jobs[k];
       c->ticket[lane].busy0 = busy ? c->busy_events[2 * k] : nullptr;
       c->ticket[lane].busy1 = busy ? c->busy_events[2 * k + 1] : nullptr;
+      c->ticket[lane].busy_recorded = busy ? &c->busy_recorded[(size_t)k] : nullptr;
       rc = prt_trace_begin(s, device, lane, job.rays, job.n, job.ld, generation_limit, ray_offset, job.rows_out,
                            job.rows_cap, workspaces[lane], flags, streams ? streams[lane] : nullptr);
       if (rc) { jobs[k].total = rc; first_error = rc; message = g_error; }
     }
   }
-  for (int k = 0; k < depth; ++k) c->ticket[k].busy0 = c->ticket[k].busy1 = nullptr;
+  for (int k = 0; k < depth; ++k) { c->ticket[k].busy0 = c->ticket[k].busy1 = nullptr; c->ticket[k].busy_recorded = nullptr; }
   if (first_error) return fail((int)first_error, message.c_str());
   if (busy) {
     // intervals relative to the first job's start (a float of milliseconds resolves ~2 ns over a 30 ms region)
     std::vector<std::pair<double, double>> spans;
     int64_t base = -1;  // the first job that launched anything: every interval is measured from its start
     for (int64_t k = 0; k < count; ++k) {
-      if (jobs[k].n == 0 || generation_limit == 0 || (flags & (PRT_TRACE_UNFUSED | PRT_TRACE_COUNT_PATHS))) continue;  // (no launch bracketed)
+      if (!c->busy_recorded[(size_t)k]) continue;  // (no launch of this job was bracketed: an empty job, the three-kernel path)
       if (base < 0) base = k;
       HIP_TRY(hipEventSynchronize(c->busy_events[2 * k + 1]));
       float t0 = 0, t1 = 0;
@@ -744,7 +952,7 @@ extern "C" int prt_trace_telemetry(const prt_scene* s, int64_t* out12) {
   out12[8] = s->tile_hint_launches;
   out12[9] = s->tile_hint_misses;
   out12[10] = s->sparse_keep_launches;
-  out12[11] = 0;
+  out12[11] = s->plan_dense_launches;  // generation launches under a record plan that ran dense
   out8[0] = s->lookback_fallbacks;
   out8[1] = s->speculation_misses;
   out8[2] = s->dense_launches;

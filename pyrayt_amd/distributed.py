@@ -85,6 +85,7 @@ class LibraryComm:
         self.device = torch.device("cuda", device) if isinstance(device, int) else device
         self._handle = ctypes.c_void_p()
         self._work = None
+        self._work_streams = set()
         limit = self.INIT_TIMEOUT_S if timeout is None else float(timeout)
         handle, outcome = ctypes.c_void_p(), {}
 
@@ -93,6 +94,9 @@ class LibraryComm:
                 outcome["rc"] = self._lib.prt_comm_create(self.device.index or 0, self.world, self.rank,
                                                           ctypes.c_char_p(bytes(unique_id)), ctypes.byref(handle))
                 outcome["message"] = self._lib.prt_last_error().decode("utf-8", "replace")
+                if outcome.get("abandoned") and outcome["rc"] >= 0 and handle:
+                    # the caller gave up waiting and is gone: a communicator completed this late belongs to nobody
+                    self._lib.prt_comm_destroy(handle)
             except BaseException as exc:  # noqa: BLE001
                 outcome["exc"] = exc
 
@@ -100,6 +104,7 @@ class LibraryComm:
         worker.start()
         worker.join(limit)
         if worker.is_alive():
+            outcome["abandoned"] = True
             raise TimeoutError(f"rank {self.rank} of {self.world}: ncclCommInitRank did not return within {limit:.0f} s -- not "
                                "every rank of the communicator called it (a rank that failed earlier, fewer processes than "
                                "WORLD_SIZE, ranks holding different unique ids, or no path between the GPUs: check "
@@ -181,6 +186,14 @@ class LibraryComm:
         need = int(self._lib.prt_allgather_workspace_bytes(self.world, limit, widest))
         if self._work is None or self._work.numel() < need:
             self._work = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._work_streams = set()
+        # (the staging block is kept across calls, and a communicator may be used from several streams -- the caller's,
+        # trace_and_gather's communication stream: the allocator must not hand the block's memory out again while a
+        # stream other than the one it was allocated under still works in it)
+        stream_now = torch.cuda.current_stream(self.device)
+        if stream_now.cuda_stream not in self._work_streams:
+            self._work_streams.add(stream_now.cuda_stream)
+            self._work.record_stream(stream_now)
         if out is None and reuse:
             kept = getattr(self, "_out", None)
             if kept is None or kept.shape != (rows.shape[0], total) or kept.dtype != rows.dtype:
@@ -296,7 +309,11 @@ def trace_and_gather(scene, ray_sets, generation_limit, comm, depth=2, flags=0, 
     """Trace a sequence of (this rank's shards of) ray sets and re-assemble every frame on every rank, with the
     re-assembly of frame k running behind trace k + 1: traces go out on the scene's ticket streams (``depth`` in
     flight), the RCCL all-gathers and the placement kernel of ``prt_allgather_rows`` on a communication stream of their
-    own.  At N = 8 the gather of the north-star job moves 315 MB into every GPU and takes several times as long as the
+    own.  The communication stream waits for the consumer only where it must: the gather of frame k waits for an event
+    the generator records on the current stream when it is resumed after handing out frame k - 1 (by then the consumer
+    is done with frame k - 2, whose block frame k is assembled into), not for everything enqueued on that stream.
+    A consumer that stops early -- or an error on the way -- leaves nothing behind: the traces in flight are collected
+    and the current stream waits for the ticket streams and the communication stream before the blocks are released.  At N = 8 the gather of the north-star job moves 315 MB into every GPU and takes several times as long as the
     trace; pipelined, a loop that wants whole frames pays max(trace, gather) per step instead of their sum.
 
     Yields ``(frame, rows_per_generation)`` per ray set, in order: ``frame`` is the whole (15, total) frame in reference
@@ -341,27 +358,53 @@ def trace_and_gather(scene, ray_sets, generation_limit, comm, depth=2, flags=0, 
         begun += 1
         return True
 
-    for _ in range(depth):
-        if not begin_next():
-            break
-    k = 0
-    while pending:
-        lane, slot = pending.pop(0)
-        rows, counts = scene.trace_end(lane)
-        begin_next()                                    # trace k + depth goes out before frame k is assembled
-        with torch_mod.cuda.stream(comm_stream):
-            comm_stream.wait_stream(streams[lane])      # the rows are ordered on the ticket's stream
-            comm_stream.wait_stream(current)            # ... and whoever still reads the frame block about to be reused
-            matrix = comm.gather_counts(counts, limit)  # (host sync of the communication stream only)
-            per_rank = matrix.sum(dim=1)
-            total = int(per_rank.sum())
+    consumer_done = [None, None]     # per frame block: the consumer on `current` has moved past the frame it held
+    try:
+        for _ in range(depth):
+            if not begin_next():
+                break
+        k = 0
+        while pending:
+            lane, slot = pending[0]
+            rows, counts = scene.trace_end(lane)
+            pending.pop(0)
+            begin_next()                                    # trace k + depth goes out before frame k is assembled
             which = k % 2
-            if frames[which] is None or frames[which].shape[1] < total:
-                frames[which] = torch_mod.empty((engine.RECORD_COLS, max(total, 1)), dtype=torch_mod.float64, device=device)
-            frame = comm.gather_rows(blocks[slot], matrix, limit, out=frames[which])
-            done = torch_mod.cuda.Event()
-            done.record(comm_stream)
-            gathered[slot] = done
-        current.wait_event(done)
-        yield frame, _merged_counts(matrix)
-        k += 1
+            with torch_mod.cuda.stream(comm_stream):
+                comm_stream.wait_stream(streams[lane])      # the rows are ordered on the ticket's stream
+                # (host sync of the communication stream only: the count matrix does not wait for what the consumer
+                # enqueued on the current stream for frame k - 1 -- only the frame block about to be reused does)
+                matrix = comm.gather_counts(counts, limit)
+                per_rank = matrix.sum(dim=1)
+                total = int(per_rank.sum())
+                if consumer_done[which] is not None:
+                    comm_stream.wait_event(consumer_done[which])   # whoever still read frame k - 2 out of this block
+                if frames[which] is None or frames[which].shape[1] < total:
+                    frames[which] = torch_mod.empty((engine.RECORD_COLS, max(total, 1)), dtype=torch_mod.float64,
+                                                    device=device)
+                    frames[which].record_stream(current)    # (allocated under comm_stream, read on the caller's stream)
+                frame = comm.gather_rows(blocks[slot], matrix, limit, out=frames[which])
+                done = torch_mod.cuda.Event()
+                done.record(comm_stream)
+                gathered[slot] = done
+            current.wait_event(done)
+            yield frame, _merged_counts(matrix)
+            # the generator resumes: the consumer is done with the frame BEFORE this one (it may hold frame k while it
+            # takes frame k + 1); what it enqueued on the current stream up to here covers its reads of that frame
+            mark = torch_mod.cuda.Event()
+            mark.record(current)
+            consumer_done[1 - which] = mark
+            k += 1
+    finally:
+        # A consumer that stops early, or an error in gather_counts / gather_rows / trace_end: the traces still in
+        # flight are collected -- their kernels may be writing into `blocks`, which go back to the allocator when this
+        # generator is closed, and their tickets stay `active` in the library otherwise (every later trace of the scene
+        # would be refused) -- and the caller's stream waits for everything that touched the blocks and frames.
+        for lane, _slot in pending:
+            try:
+                scene.trace_end(lane)
+            except Exception:  # noqa: BLE001
+                pass
+        for lane in range(depth):
+            current.wait_stream(streams[lane])
+        current.wait_stream(comm_stream)

@@ -64,10 +64,19 @@ def options_record(options=None):
         rec[key] = int(value)
     return rec
 
+# prt_record_plan (include/prt.h): what a trace records when the caller does not want every row
+PLAN_DTYPE = np.dtype(
+    [("struct_size", "<i4"), ("n_surfaces", "<i4"), ("store_rows", "<i4"), ("n_groups", "<i4"), ("surfaces", "<i8", (8,)),
+     ("rays_per_source", "<f8"), ("sums_out", "<u8"), ("pivots", "<u8"), ("ms_quantity", "<i4"), ("ms_transform", "<i4"),
+     ("ms_about", "<f8"), ("generation_limit", "<i4"), ("reserved", "<i4")])
+assert PLAN_DTYPE.itemsize == 128
+SINK_STATS = 12
+AXIS_INTERCEPT = 15  # PRT_FRAME_AXIS_INTERCEPT
+
 ERR_ROWS_CAP = -4
 ERR_UNTRACABLE = -5
 ERR_WAVELENGTH = -6
-PRT_VERSION = 210  # include/prt.h: the ABI this binding was written for
+PRT_VERSION = 220  # include/prt.h: the ABI this binding was written for
 TABLE_KEEP_FACTOR, TABLE_KEEP_MIN = 4, 64  # index tables keep earlier wavelengths up to this multiple of a ray set's own
 UNIQUE_CAP = 4096  # distinct wavelengths looked for on the device before the host sorts the whole row
 
@@ -112,6 +121,7 @@ def _declare(lib):
         "prt_trace_end": (c_i64, [c_p, c_int, c_int, c_p]),
         "prt_trace_batch": (c_i64, [c_p, c_int, c_p, c_i64, c_int, c_d, c_int, c_p, c_p, c_int]),
         "prt_trace_batch_busy": (c_int, [c_p, c_int, c_p]),
+        "prt_trace_set_plan": (c_int, [c_p, c_int, c_int, c_p]),
         "prt_trace_stats": (c_int, [c_p, c_p]),
         "prt_trace_telemetry": (c_int, [c_p, c_p]),
         "prt_generate_rays": (c_int, [c_int, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p]),
@@ -159,7 +169,7 @@ EXPORTED_SYMBOLS = (
     "prt_scene_component_rows", "prt_scene_info", "prt_intersect", "prt_propagate", "prt_world_normals",
     "prt_material_trace", "prt_interact_workspace_bytes", "prt_interact", "prt_scene_set_index_tables",
     "prt_gather_hits", "prt_scatter_shaded", "prt_unique_workspace_bytes", "prt_unique_values",
-    "prt_trace_workspace_bytes", "prt_trace", "prt_trace_begin", "prt_trace_end", "prt_trace_batch", "prt_trace_batch_busy", "prt_trace_stats", "prt_trace_telemetry", "prt_generate_rays",
+    "prt_trace_workspace_bytes", "prt_trace", "prt_trace_begin", "prt_trace_end", "prt_trace_batch", "prt_trace_batch_busy", "prt_trace_set_plan", "prt_trace_stats", "prt_trace_telemetry", "prt_generate_rays",
     "prt_camera_rays", "prt_render_hits", "prt_gooch_shade", "prt_gooch_mix", "prt_render",
     "prt_edge_workspace_bytes", "prt_edge_canvas", "prt_reflect", "prt_refract", "prt_binomial_root",
     "prt_smallest_positive_root", "prt_dot", "prt_array_csg", "prt_primitive_intersect",
@@ -243,6 +253,75 @@ def to_host(tensor):
 
 def _stream_ptr(torch, device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class RecordPlan:
+    """What a trace records when the caller does not want every row (``prt_record_plan``, include/prt.h).
+
+    The reference appends one row per live ray and generation (``pyrayt/_pyrayt.py:168-186``) and its users throw
+    most of them away on the next line -- ``results.loc[results['surface'] == imager.get_id()]``
+    (``examples/lens_design.ipynb`` cells 11, 19, 38), the rows of the last generation (cells 12, 15, 20) -- to look at
+    a spot, a focus, a merit function.  A plan tells the generation kernel while the row is still in registers:
+
+    surfaces   ids (``surface.get_id()``) whose rows pass; None / empty: the rows of every surface
+    rows       store the rows that pass (the frame is then ``frame.loc[frame.surface.isin(surfaces)]`` of the
+               unfiltered trace, row for row); False: store nothing, only sum
+    stats      sum the rows that pass, per generation and per group (``id // rays_per_source``), into ``plan.sums``
+               -- a device (generation_limit, n_groups, 12) tensor: what ``DeviceFrame.group_stats`` and
+               ``mean_square`` would read back out of the stored frame (``pyrayt_amd.frame.SinkStats`` turns it into
+               the same tables)
+    pivots     device (n_groups, 3) tensor subtracted from (y1, z1, axis intercept) before summing (a design loop
+               passes the previous iteration's means), or None
+    mean_square  (quantity, about, transform): quantity a frame column name or "axis_intercept", transform None | "sin"
+    """
+
+    def __init__(self, surfaces=None, rows=True, stats=False, rays_per_source=None, n_groups=None, pivots=None,
+                 mean_square=None, generation_limit=10):
+        from .frame import COLUMNS
+
+        self.surfaces = tuple(int(s) for s in (surfaces or ()))
+        if len(self.surfaces) > 8:
+            raise ValueError("a record plan lists at most 8 surfaces")
+        self.rows = bool(rows)
+        self.stats = bool(stats)
+        self.rays_per_source = float(rays_per_source) if rays_per_source else 0.0
+        self.n_groups = int(n_groups) if n_groups else 1
+        if not self.rays_per_source and self.n_groups != 1:
+            raise ValueError("one group without rays_per_source")
+        self.pivots = pivots
+        self.generation_limit = int(generation_limit)
+        self.ms = None
+        if mean_square is not None:
+            quantity, about, transform = (tuple(mean_square) + (None, None))[:3]
+            column = AXIS_INTERCEPT if quantity == "axis_intercept" else COLUMNS.index(quantity)
+            self.ms = (column, float(about or 0.0), {None: 0, "sin": 1}[transform])
+        self.sums = None  # device (generation_limit, n_groups, SINK_STATS), made when the plan is put on a ticket
+
+    def key(self):
+        return (self.surfaces, self.rows, self.stats, self.rays_per_source, self.n_groups, self.ms, self.generation_limit,
+                None if self.pivots is None else self.pivots.data_ptr())
+
+    def record(self, torch, device):
+        rec = np.zeros(1, dtype=PLAN_DTYPE)
+        rec["struct_size"] = PLAN_DTYPE.itemsize
+        rec["n_surfaces"] = len(self.surfaces)
+        rec["surfaces"][0, :len(self.surfaces)] = self.surfaces
+        rec["store_rows"] = int(self.rows)
+        rec["generation_limit"] = self.generation_limit
+        rec["ms_quantity"] = -1
+        if self.stats:
+            if self.sums is None or self.sums.device != device:
+                self.sums = torch.zeros((self.generation_limit, self.n_groups, SINK_STATS), dtype=torch.float64, device=device)
+            rec["n_groups"] = self.n_groups
+            rec["rays_per_source"] = self.rays_per_source
+            rec["sums_out"] = self.sums.data_ptr()
+            if self.pivots is not None:
+                assert self.pivots.is_cuda and self.pivots.dtype == torch.float64 and self.pivots.is_contiguous()
+                assert tuple(self.pivots.shape) == (self.n_groups, 3)
+                rec["pivots"] = self.pivots.data_ptr()
+            if self.ms is not None:
+                rec["ms_quantity"], rec["ms_about"], rec["ms_transform"] = self.ms[0], self.ms[1], self.ms[2]
+        return rec
 
 
 class DeviceScene:
@@ -393,6 +472,7 @@ class DeviceScene:
 
     def close(self):
         self._view_of = self._view = None
+        self._plans = None
         self._pending = [None] * TRACE_TICKETS
         self._begin_cache = [None] * TRACE_TICKETS
         self._end_views = [None] * TRACE_TICKETS
@@ -407,14 +487,38 @@ class DeviceScene:
         except Exception:
             pass
 
+    # --- record plans -------------------------------------------------------------------------
+    def set_plan(self, ticket, plan, device=None):
+        """Put a ``RecordPlan`` (or None: record everything, as the reference does) on one of the scene's tickets
+        (``prt_trace_set_plan``; ``trace()`` runs on ticket 0).  It stays in force until replaced."""
+        plans = getattr(self, "_plans", None)
+        if plans is None:
+            plans = self._plans = [None] * TRACE_TICKETS
+        held = plans[ticket]
+        if plan is None:
+            if held is not None:
+                _check(library().prt_trace_set_plan(self.handle, held[2], int(ticket), None))
+                plans[ticket] = None
+            return
+        torch = _torch()
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        index = dev.index or 0
+        if held is not None and held[0] is plan and held[1] == plan.key() and held[2] == index:
+            return
+        rec = plan.record(torch, dev)
+        _check(library().prt_trace_set_plan(self.handle, index, int(ticket), rec.ctypes.data))
+        plans[ticket] = (plan, plan.key(), index)
+
     # --- the hot loop -------------------------------------------------------------------------
-    def trace(self, rays, generation_limit, ray_offset=DEFAULT_RAY_OFFSET, flags=0, rows_cap=None, out=None):
+    def trace(self, rays, generation_limit, ray_offset=DEFAULT_RAY_OFFSET, flags=0, rows_cap=None, out=None, plan=False):
         """Run all generations on the device.
 
         rays: CUDA float64 tensor (13, n), row-major.  Returns (rows, counts): rows is a CUDA
         (15, total) tensor view, generation-major; counts the rows recorded per generation.
         out: optional (15, cap) CUDA float64 block to record into (a design loop that is done with
-        the previous frame passes it back instead of having a new block allocated per call)."""
+        the previous frame passes it back instead of having a new block allocated per call).
+        plan: a ``RecordPlan`` (what to record: rows of some surfaces only, and / or sums instead of rows), None to
+        record everything again, or False (default): whatever plan ticket 0 holds stays."""
         torch = _torch()
         lib = library()
         assert rays.is_cuda and rays.dtype == torch.float64 and rays.dim() == 2
@@ -422,8 +526,16 @@ class DeviceScene:
         n = rays.shape[1]
         dev = rays.device
         limit = int(generation_limit)
+        if plan is not False:
+            self.set_plan(0, plan, dev)
+        held = getattr(self, "_plans", None)
+        held = held[0][0] if held is not None and held[0] is not None else None
         if n == 0 or limit <= 0:
+            if held is not None and held.sums is not None:
+                held.sums.zero_()
             return torch.empty((RECORD_COLS, 0), dtype=torch.float64, device=dev), []
+        if held is not None and not held.rows and out is None and rows_cap is None:
+            rows_cap = 0  # (a plan that stores no rows needs no record block)
         if out is not None:
             assert out.is_cuda and out.dtype == torch.float64 and out.dim() == 2 and out.device == dev
             assert out.shape[0] == RECORD_COLS and out.is_contiguous()
@@ -445,7 +557,7 @@ class DeviceScene:
                 _stream_ptr(torch, dev),
             )
             if total == ERR_ROWS_CAP and cap < n * limit and out is None:
-                cap = min(n * limit, cap * 4)  # only when HBM was too tight for the full block
+                cap = min(n * limit, max(cap * 4, n))  # only when HBM was too tight for the full block
                 continue
             if total == ERR_WAVELENGTH and not rescanned:
                 # rays with wavelengths the tables were not built for (another ray set than last time): the
@@ -455,7 +567,8 @@ class DeviceScene:
                 continue
             _check(total)
             break
-        self._cap_hint = (n, limit, cap)
+        if held is None:
+            self._cap_hint = (n, limit, cap)
         per_generation = counts[:]
         while per_generation and per_generation[-1] == 0:
             per_generation.pop()
@@ -676,7 +789,7 @@ class DeviceScene:
         _check(library().prt_trace_telemetry(self.handle, out))
         keys = ("lookback_fallbacks", "speculation_misses", "dense_launches", "full_rows_fallbacks",
                 "counted_traces", "rays_not_well_formed", "implied_box_nodes", "exact_box_tests",
-                "tile_record_launches", "tile_record_misses", "sparse_keep_launches")
+                "tile_record_launches", "tile_record_misses", "sparse_keep_launches", "plan_dense_launches")
         return dict(zip(keys, (int(v) for v in out)))
 
     # --- per-state entry points -----------------------------------------------------------------

@@ -295,6 +295,71 @@ class DeviceFrame:
         return pd.DataFrame(values, columns=COLUMNS, copy=False)
 
 
+class SinkStats:
+    """The sums a trace under a ``RecordPlan(stats=True)`` accumulated in its generation kernels -- per generation and
+    per group what ``prt_frame_reduce`` / ``prt_frame_mean_square`` would have read back out of the stored frame --
+    turned into the tables ``DeviceFrame.group_stats`` / ``mean_square`` return.  One small device-to-host copy (96
+    bytes per generation and group); the frame itself was never written."""
+
+    def __init__(self, sums, pivots=None, about=0.0):
+        """sums: (generations, n_groups, 12) tensor or array; pivots: (n_groups, 3) the sums were taken about."""
+        host = sums.detach().cpu().numpy() if hasattr(sums, "detach") else np.asarray(sums)
+        self.sums = np.array(host, dtype=float)
+        piv = None if pivots is None else (pivots.detach().cpu().numpy() if hasattr(pivots, "detach") else np.asarray(pivots))
+        self.pivots = np.zeros((self.sums.shape[1], 3)) if piv is None else np.array(piv, dtype=float)
+
+    def last_generation_number(self):
+        """The highest generation that counted a row (None: no row passed)."""
+        working = np.nonzero(self.sums[:, :, 0].sum(axis=1) > 0)[0]
+        return int(working[-1]) if len(working) else None
+
+    def _block(self, generation):
+        if generation is None:
+            return self.sums.sum(axis=0)   # (additive over generations: one set of pivots)
+        if generation == "last":
+            generation = self.last_generation_number()
+            if generation is None:
+                return np.zeros(self.sums.shape[1:])
+        if not 0 <= int(generation) < self.sums.shape[0]:
+            return np.zeros(self.sums.shape[1:])
+        return self.sums[int(generation)]
+
+    def group_stats(self, generation=None):
+        """The table of ``DeviceFrame.group_stats`` (count, y, z, rms_radius, focus, focus_std, wavelength, intensity per
+        source) for the rows the plan let pass, of one generation (a number, or "last": the highest that counted a
+        row) or of all of them (None).  Same arithmetic as ``k_frame_finish`` (csrc/prt_frame.hpp)."""
+        s = self._block(generation)
+        count, with_focus = s[:, 0], s[:, 8]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            safe, safe_f = np.where(count > 0, count, 1.0), np.where(with_focus > 0, with_focus, 1.0)
+            dy, dz, df = s[:, 1] / safe, s[:, 2] / safe, s[:, 4] / safe_f
+            var_r = np.maximum(s[:, 3] / safe - dy * dy - dz * dz, 0.0)
+            var_f = np.maximum(s[:, 5] / safe_f - df * df, 0.0)
+            nan = np.nan
+            frame = pd.DataFrame({
+                "count": count.astype(np.int64),
+                "y": np.where(count > 0, self.pivots[:, 0] + dy, nan), "z": np.where(count > 0, self.pivots[:, 1] + dz, nan),
+                "rms_radius": np.where(count > 0, np.sqrt(var_r), nan),
+                "focus": np.where(with_focus > 0, self.pivots[:, 2] + df, nan),
+                "focus_std": np.where(with_focus > 0, np.sqrt(var_f), nan),
+                "wavelength": np.where(count > 0, s[:, 6] / safe, nan), "intensity": np.where(count > 0, s[:, 7] / safe, nan),
+            })
+        frame.index.name = "source_id"
+        return frame
+
+    def mean_square(self, generation=None, per_source=False):
+        """``np.mean(np.square(f(rows) - about))`` of the plan's ``mean_square`` quantity (``DeviceFrame.mean_square``):
+        a float, or per source a DataFrame (count, mean, mean_square)."""
+        s = self._block(generation)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            mean, mean_square = s[:, 10] / s[:, 9], s[:, 11] / s[:, 9]
+        if not per_source:
+            return float(mean_square[0])
+        frame = pd.DataFrame({"count": s[:, 9].astype(np.int64), "mean": mean, "mean_square": mean_square})
+        frame.index.name = "source_id"
+        return frame
+
+
 def _all_reduce_sum(tensor, group):
     """Sum of a small device tensor over the ranks of a torch.distributed group (through the host for a backend
     that does not take device tensors)."""

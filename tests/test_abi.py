@@ -191,7 +191,7 @@ def test_generation_kernel_keeps_its_register_allocation(lib_path):
     if not os.path.exists(mod.READELF):
         pytest.skip("llvm-readelf not available")
     kernels = {name: res for name, res in mod.kernel_resources(lib_path).items() if "k_generation" in name}
-    assert len(kernels) == 4, sorted(kernels)
+    assert len(kernels) == 8, sorted(kernels)  # CULL x COMPACT x PLAN (round 6: the record-plan instantiations, held to the same)
     for name, res in kernels.items():
         assert res["private_segment_fixed_size"] == 0, (name, res)
         assert res["vgpr_spill_count"] == 0 and res["vgpr_count"] <= 96, (name, res)

@@ -168,6 +168,58 @@ def test_gather_pipelined_behind_the_next_trace_gives_the_same_frames():
         comm.close()
 
 
+def test_gather_pipelined_abandoned_midway_frees_its_tickets():
+    """A consumer that stops iterating trace_and_gather (or an error inside it) must not leave traces in flight: the
+    generator's finally collects them, so the tickets are free for the next trace of the scene and the record blocks
+    are not released under running kernels (mirrors test_trace_many_abandoned_midway_frees_its_tickets)."""
+    from pyrayt_amd import distributed as pdist
+    from pyrayt_amd import engine
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    CountedObject.reset_ids()
+    parts, rays = scenes.config2(scenes.product_api(), 30_000, seed=77)
+    rays = torch.from_numpy(rays).to("cuda:0")
+    scene = engine.DeviceScene(SceneSnapshot(parts))
+    want_rows, want_counts = scene.trace(rays, LIMIT)
+    want = want_rows.cpu().numpy().copy()
+    comm = pdist.LibraryComm(0, 1, 0, pdist.LibraryComm.unique_id())
+    try:
+        for depth in (2, 3):
+            stream = pdist.trace_and_gather(scene, (rays for _ in range(8)), LIMIT, comm, depth=depth)
+            frame, counts = next(stream)
+            assert counts == want_counts and np.array_equal(frame.cpu().numpy(), want)
+            stream.close()                               # depth traces were in flight: collected by the generator
+            for ticket in range(depth):                  # every ticket is free again ...
+                out = torch.empty((15, rays.shape[1] * LIMIT), dtype=torch.float64, device="cuda:0")
+                scene.trace_begin(ticket, rays, LIMIT, out)
+                rows, counts = scene.trace_end(ticket)
+                torch.cuda.synchronize()
+                assert counts == want_counts and np.array_equal(rows.cpu().numpy(), want)
+            rows, counts = scene.trace(rays, LIMIT)      # ... and so is the blocking call
+
+        # an error raised inside the loop (the gather of frame 1 fails) also leaves no ticket behind
+        calls = {"n": 0}
+        real = comm.gather_rows
+
+        def failing(*args, **kwargs):
+            calls["n"] += 1
+            if calls["n"] == 2:
+                raise RuntimeError("injected")
+            return real(*args, **kwargs)
+
+        comm.gather_rows = failing
+        with pytest.raises(RuntimeError, match="injected"):
+            for _ in pdist.trace_and_gather(scene, (rays for _ in range(6)), LIMIT, comm, depth=2):
+                pass
+        comm.gather_rows = real
+        rows, counts = scene.trace(rays, LIMIT)
+        assert counts == want_counts and np.array_equal(rows.cpu().numpy(), want)
+    finally:
+        comm.close()
+    scene.close()
+
+
 def test_placement_kernel_against_the_indexed_copy():
     """prt_place_rows == the torch placement on a ragged count matrix with empty segments."""
     from pyrayt_amd import distributed as pdist

@@ -1104,13 +1104,14 @@ def test_four_traces_in_flight_get_their_queues_whichever_import_came_first():
     done = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300)
     assert done.returncode == 0, done.stderr[-1500:]
     assert done.stdout.split()[-2:] == ["user", "warned"], done.stdout
-    # ... and one that made a HIP call before the package could ask is checked by running something: whatever the
-    # answer, it is the measured one (on this runtime four streams do get four queues as long as the null stream idles)
+    # ... and one that made a HIP call before the package could ask is found out by running something: the runtime
+    # stays at its default of four queues, the four ticket streams plus the caller's own make five, two of them share
+    # a queue and the probe measures twice the single-stream time: the warning fires
     code = code.replace("import torch;", "os.environ.pop('GPU_MAX_HW_QUEUES', None); import torch; torch.cuda.is_available();")
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
     done = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300)
     assert done.returncode == 0, done.stderr[-1500:]
-    assert done.stdout.split()[-2] == "set-late" and done.stdout.split()[-1] in ("quiet", "warned"), done.stdout
+    assert done.stdout.split()[-2:] == ["set-late", "warned"], done.stdout
 
 
 @pytest.mark.parametrize("lens", ["biconvex", "thick_moved", "thick_tilted_scaled"])

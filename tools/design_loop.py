@@ -16,25 +16,29 @@ for _ in range(3):
     tracer.trace_device()
 
 
-def iteration(move):
+def iteration(move, fused):
     if move:
         det.move_x(1e-4)
+    if fused:  # the sums are accumulated by the generation kernels: no row is stored, none is read back
+        return tracer.trace_stats(surface=det).group_stats()["rms_radius"].iloc[0]
     frame = tracer.trace_device()
     return frame.group_stats(surface=det.get_id())["rms_radius"].iloc[0]
 
 
-for move in (False, True):
-    for _ in range(3):
-        iteration(move)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(30):
-        rms = iteration(move)
-    dt = (time.perf_counter() - t0) / 30
-    print(f"{'moving the detector' if move else 'unchanged system'}: {dt * 1e3:.3f} ms per iteration (rms spot {rms:.3e})")
+for fused in (False, True):
+    for move in (False, True):
+        for _ in range(5):
+            iteration(move, fused)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            rms = iteration(move, fused)
+        dt = (time.perf_counter() - t0) / 50
+        print(f"{'fused sink (trace_stats)' if fused else 'frame + group_stats   '} | {'moving the detector' if move else 'unchanged system   '}: "
+              f"{dt * 1e3:.3f} ms per iteration (rms spot {rms:.6e})")
 if "--profile" in sys.argv:
     pr = cProfile.Profile(); pr.enable()
     for _ in range(30):
-        iteration(True)
+        iteration(True, True)
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
