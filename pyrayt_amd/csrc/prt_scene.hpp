@@ -84,6 +84,9 @@ struct TraceTicket {
   bool allow_tile_hints = true, use_tile_records = false, used_tile_hints = false;
   bool records_off = false;  // this attempt: the records of the generations still to come were taken on other rays (see launch_mode 4)
   unsigned long long user = 0;  // identity of this ticket in the workspace registry (0: not drawn yet)
+  unsigned long long update_seen = 0;   // the scene update this ticket's stream has waited for ...
+  hipStream_t update_seen_stream = nullptr;  // ... and which stream that was
+  bool traced = false;                  // launched something since the scene's last update
   // record plan of this ticket (prt_trace_set_plan; prt_trace_kernels.hpp PlanDev): what the PLAN kernels are told
   bool plan_active = false;
   bool plan_dirty = false;            // the device copy is older than plan_host
@@ -97,6 +100,16 @@ struct TraceTicket {
 };
 
 struct DeviceCopy {
+  // the scene tables of this device: one allocation (`block`), the pointers below point into it.  prt_scene_update
+  // overwrites the whole image with ONE stream-ordered copy out of pinned staging memory (see there).
+  char* block = nullptr;
+  size_t block_bytes = 0;
+  char* staging = nullptr;                      // pinned host image of `block`
+  hipStream_t update_stream = nullptr;          // the copies of prt_scene_update run here ...
+  hipEvent_t update_event = nullptr, tail_event = nullptr;  // ... behind everything the tickets enqueued; consumers wait for update_event
+  unsigned long long update_serial = 0;         // updates so far (a ticket's stream waits once per update)
+  bool update_unsettled = false;                // an update's copy may still be in flight (entry points other than the tickets' wait on the host)
+  bool untracked_use = false;                   // something other than a ticket's trace used the tables since the last update
   DevPrim* prims = nullptr;
   double* tables = nullptr;                     // index tables of the PRT_MAT_TABLE materials: wavelengths | indices
   DevInstr* trace_code = nullptr;               // all components, each reduced to its candidate hit
@@ -979,14 +992,34 @@ extern "C" int prt_scene_create(const prt_prim* prims, int n_prims, const prt_no
   return PRT_OK;
 }
 
+// The scene tables of one device as ONE image: [prims | trace code | component step ranges | render code | one program
+// per component], each part at a 256-byte boundary.  `write` == nullptr: sizes only.  Returns the image's size; the
+// offsets of the parts go to `at` (5 + components entries).
+static size_t scene_image(const prt_scene* s, char* write, std::vector<size_t>* at) {
+  size_t pos = 0;
+  auto part = [&](const void* src, size_t bytes) {
+    const size_t here = pos;
+    if (write && bytes) std::memcpy(write + here, src, bytes);
+    pos += (std::max<size_t>(bytes, 1) + 255) / 256 * 256;
+    if (at) at->push_back(here);
+  };
+  if (at) at->clear();
+  part(s->dev_prims.data(), s->dev_prims.size() * sizeof(DevPrim));
+  part(s->trace_program.code.data(), s->trace_program.code.size() * sizeof(DevInstr));
+  part(s->trace_program.component_first.data(), s->trace_program.component_first.size() * sizeof(int32_t));
+  part(s->render_program.code.data(), s->render_program.code.size() * sizeof(DevInstr));
+  for (const Program& p : s->component_programs) part(p.code.data(), p.code.size() * sizeof(DevInstr));
+  return pos;
+}
+
 // give back whatever a device copy holds (the device is current)
 static void release_device_copy(DeviceCopy& c) {
-  (void)hipFree(c.prims);
+  (void)hipFree(c.block);  // (prims, trace_code, trace_component_first, render_code, component_code[] point into it)
   (void)hipFree(c.tables);
-  (void)hipFree(c.trace_code);
-  (void)hipFree(c.trace_component_first);
-  (void)hipFree(c.render_code);
-  for (DevInstr* p : c.component_code) (void)hipFree(p);
+  if (c.staging) (void)hipHostFree(c.staging);
+  if (c.update_stream) (void)hipStreamDestroy(c.update_stream);
+  if (c.update_event) (void)hipEventDestroy(c.update_event);
+  if (c.tail_event) (void)hipEventDestroy(c.tail_event);
   for (TraceTicket& t : c.ticket) {
     if (t.host_pinned) (void)hipHostFree(t.host_pinned);
     if (t.mirror) (void)hipHostFree(t.mirror);
@@ -1005,7 +1038,7 @@ extern "C" void prt_scene_destroy(prt_scene* s) {
   if (!s) return;
   for (size_t d = 0; d < s->per_device.size(); ++d) {
     DeviceCopy& c = s->per_device[d];
-    if (!c.prims && !c.trace_code) continue;
+    if (!c.block) continue;
     (void)hipSetDevice((int)d);
     // a trace that was begun and never ended, or one whose counts are out while its last stores are not,
     // still reads the tables and writes the host mirror freed below
@@ -1111,22 +1144,52 @@ extern "C" int prt_scene_update(prt_scene* s, const prt_prim* prims, int n_prims
     prt_scene_destroy(t);
     return 1;
   }
+  bool has_tables = false;
+  for (const DevPrim& d : t->dev_prims) has_tables = has_tables || d.mat_kind == MAT_TABLE;
+  for (const DevPrim& d : s->dev_prims) has_tables = has_tables || d.mat_kind == MAT_TABLE;
   for (size_t d = 0; d < s->per_device.size(); ++d) {
     DeviceCopy& c = s->per_device[d];
     if (!c.ready) continue;
     HIP_TRY(hipSetDevice((int)d));
-    HIP_TRY(hipDeviceSynchronize());  // the last trace may still be draining: it reads these tables
-    auto put = [](void* dst, const void* src, size_t bytes) {
-      return bytes ? hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
-    };
-    HIP_TRY(put(c.prims, t->dev_prims.data(), t->dev_prims.size() * sizeof(DevPrim)));
-    HIP_TRY(put(c.trace_code, t->trace_program.code.data(), t->trace_program.code.size() * sizeof(DevInstr)));
-    HIP_TRY(put(c.trace_component_first, t->trace_program.component_first.data(),
-                t->trace_program.component_first.size() * sizeof(int32_t)));
-    HIP_TRY(put(c.render_code, t->render_program.code.data(), t->render_program.code.size() * sizeof(DevInstr)));
-    for (size_t k = 0; k < t->component_programs.size(); ++k)
-      HIP_TRY(put(c.component_code[k], t->component_programs[k].code.data(),
-                  t->component_programs[k].code.size() * sizeof(DevInstr)));
+    if (scene_image(t, nullptr, nullptr) != c.block_bytes) { prt_scene_destroy(t); return fail(PRT_ERR_SCENE, "scene image changed its size"); }
+    // The new image goes over the old one with ONE copy out of pinned memory on a stream of the copy's own, ordered
+    // BEHIND whatever the tickets have enqueued (the last kernel of a trace whose counts are out may still be reading
+    // the tables) and IN FRONT of whatever they enqueue next (prt_trace_begin makes its stream wait for update_event):
+    // no device-wide synchronisation, nothing the host waits for -- a design loop moves a part before every trace.
+    // Entry points outside the ticket runtime (prt_propagate, the renderers ...) are not tracked stream by stream: if
+    // one of them used the tables since the last update, or the scene has index tables to re-apply, the device is
+    // synchronised first, as it always was.
+    if (c.update_unsettled) {  // (the previous update's copy reads the staging memory written below: long done as a rule)
+      if (hipEventQuery(c.update_event) != hipSuccess) {
+        (void)hipGetLastError();
+        HIP_TRY(hipEventSynchronize(c.update_event));
+      }
+      c.update_unsettled = false;
+    }
+    bool ordered = !c.untracked_use && !has_tables;
+    if (ordered) {
+      for (TraceTicket& tk : c.ticket) {
+        if (!tk.traced) continue;
+        if (hipEventRecord(c.tail_event, tk.st) != hipSuccess || hipStreamWaitEvent(c.update_stream, c.tail_event, 0) != hipSuccess) {
+          (void)hipGetLastError();
+          ordered = false;  // (e.g. a stream the caller has destroyed since)
+          break;
+        }
+      }
+    }
+    if (!ordered) HIP_TRY(hipDeviceSynchronize());
+    for (TraceTicket& tk : c.ticket) tk.traced = false;
+    c.untracked_use = false;
+    scene_image(t, c.staging, nullptr);
+    if (ordered) {
+      HIP_TRY(hipMemcpyAsync(c.block, c.staging, c.block_bytes, hipMemcpyHostToDevice, c.update_stream));
+      HIP_TRY(hipEventRecord(c.update_event, c.update_stream));
+      c.update_serial += 1;
+      c.update_unsettled = true;
+    } else {
+      HIP_TRY(hipMemcpy(c.block, c.staging, c.block_bytes, hipMemcpyHostToDevice));
+      c.update_unsettled = false;
+    }
   }
   s->prims.swap(t->prims);
   s->nodes.swap(t->nodes);
@@ -1179,19 +1242,12 @@ extern "C" int prt_scene_component_rows(const prt_scene* s, int root) {
   return 2 * leaves_under(s, s->roots[root]);
 }
 
-template <typename T>
-static int upload(T** dst, const std::vector<T>& src) {
-  *dst = nullptr;
-  const size_t bytes = std::max<size_t>(1, src.size()) * sizeof(T);
-  HIP_TRY(hipMalloc((void**)dst, bytes));
-  if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
-  return PRT_OK;
-}
-
 static int raise_lds_limits();  // defined after the kernels
 
 // make sure the scene tables exist on `device` and make it current
-static int on_device(prt_scene* s, int device, DeviceCopy** out) {
+// tracked: the caller is the ticket runtime, whose launches prt_scene_update orders its copy behind (and which makes
+// its streams wait for that copy); any other entry point is noted, and waits on the host for an update in flight
+static int on_device(prt_scene* s, int device, DeviceCopy** out, bool tracked = false) {
   if (!s) return fail(PRT_ERR_ARG, "scene is null");
   int count = 0;
   HIP_TRY(hipGetDeviceCount(&count));
@@ -1201,20 +1257,22 @@ static int on_device(prt_scene* s, int device, DeviceCopy** out) {
   DeviceCopy& c = s->per_device[device];
   if (!c.ready) {
     release_device_copy(c);  // (what an earlier attempt that failed half way left behind)
-    int rc = upload(&c.prims, s->dev_prims);
-    if (rc) return rc;
-    rc = upload(&c.trace_code, s->trace_program.code);
-    if (rc) return rc;
-    rc = upload(&c.trace_component_first, s->trace_program.component_first);
-    if (rc) return rc;
-    rc = upload(&c.render_code, s->render_program.code);
-    if (rc) return rc;
-    for (const Program& p : s->component_programs) {
-      DevInstr* code = nullptr;
-      rc = upload(&code, p.code);
-      if (rc) return rc;
-      c.component_code.push_back(code);
-    }
+    int rc = PRT_OK;
+    std::vector<size_t> at;
+    c.block_bytes = scene_image(s, nullptr, &at);
+    HIP_TRY(hipMalloc((void**)&c.block, c.block_bytes));
+    HIP_TRY(hipHostMalloc((void**)&c.staging, c.block_bytes, hipHostMallocDefault));
+    std::memset(c.staging, 0, c.block_bytes);
+    scene_image(s, c.staging, nullptr);
+    HIP_TRY(hipMemcpy(c.block, c.staging, c.block_bytes, hipMemcpyHostToDevice));
+    c.prims = (DevPrim*)(c.block + at[0]);
+    c.trace_code = (DevInstr*)(c.block + at[1]);
+    c.trace_component_first = (int32_t*)(c.block + at[2]);
+    c.render_code = (DevInstr*)(c.block + at[3]);
+    for (size_t k = 0; k < s->component_programs.size(); ++k) c.component_code.push_back((DevInstr*)(c.block + at[4 + k]));
+    HIP_TRY(hipStreamCreateWithFlags(&c.update_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c.update_event, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c.tail_event, hipEventDisableTiming));
     for (TraceTicket& t : c.ticket) {
       HIP_TRY(hipHostMalloc((void**)&t.host_pinned, 16 * sizeof(int64_t), hipHostMallocDefault));
       HIP_TRY(hipHostMalloc((void**)&t.mirror, 64 + (kMaxBatch + 4) * 64, hipHostMallocMapped | hipHostMallocCoherent));  // header + GenCtrl slots of 64 B
@@ -1228,6 +1286,13 @@ static int on_device(prt_scene* s, int device, DeviceCopy** out) {
     rc = apply_tables(s, c);
     if (rc) return rc;
     c.ready = true;
+  }
+  if (!tracked) {
+    c.untracked_use = true;
+    if (c.update_unsettled) {  // (an update's copy may still be on its way: this caller's stream is not known here)
+      HIP_TRY(hipEventSynchronize(c.update_event));
+      c.update_unsettled = false;
+    }
   }
   *out = &c;
   return PRT_OK;

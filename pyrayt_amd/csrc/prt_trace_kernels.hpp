@@ -799,8 +799,11 @@ __device__ __forceinline__ double sink_quantity(int quantity, const Shaded& s, d
     default: return ox - s.tx * oy / s.ty;  // the axis intercept (k_frame_mean_square's FRAME_AXIS_INTERCEPT)
   }
 }
-__device__ __forceinline__ void sink_accumulate(ConstPlan plan, int g, bool sunk, const Shaded& s, double ox, double oy,
-                                                double oz) {
+// (called by EVERY lane of the wave -- the xor shuffles need their partners -- with the operands of the lanes that
+// have a row to add: its end point y1, z1, its axis intercept, the mean-square quantity already transformed and
+// shifted, and the three metadata values)
+__device__ __forceinline__ void sink_accumulate(ConstPlan plan, int g, bool sunk, double py, double pz, double focus,
+                                                double w, double wavelength, double intensity, double id) {
   if (__ballot(sunk) == 0ull) return;  // (uniform)
   const int n_groups = plan->n_groups, lane = threadIdx.x & 63;
   const double rays_per_source = plan->rays_per_source;
@@ -808,7 +811,7 @@ __device__ __forceinline__ void sink_accumulate(ConstPlan plan, int g, bool sunk
   if (sunk) {
     group = 0;
     if (rays_per_source > 0) {
-      const double q = floor(s.id / rays_per_source);  // _pyrayt.py:352
+      const double q = floor(id / rays_per_source);  // _pyrayt.py:352
       group = (q >= 0 && q < (double)n_groups) ? (int)q : -1;
     }
   }
@@ -819,19 +822,14 @@ __device__ __forceinline__ void sink_accumulate(ConstPlan plan, int g, bool sunk
     double pivot_y = 0.0, pivot_z = 0.0, pivot_focus = 0.0;
     const double* __restrict__ pivots = plan->pivots;
     if (pivots) { pivot_y = pivots[3 * group]; pivot_z = pivots[3 * group + 1]; pivot_focus = pivots[3 * group + 2]; }
-    const double y = s.py - pivot_y, z = s.pz - pivot_z;
-    const double focus = ox - s.tx * oy / s.ty;
+    const double y = py - pivot_y, z = pz - pivot_z;
     const double f = focus - pivot_focus;
     const bool f_ok = f == f && fabs(f) < PRT_INF;  // a ray parallel to the axis has no intercept
     v[0] = 1.0; v[1] = y; v[2] = z; v[3] = y * y + z * z;
     v[4] = f_ok ? f : 0.0; v[5] = f_ok ? f * f : 0.0;
-    v[6] = s.wavelength; v[7] = s.intensity;
+    v[6] = wavelength; v[7] = intensity;
     v[8] = f_ok ? 1.0 : 0.0;
-    const int quantity = plan->ms_quantity;
-    if (quantity >= 0) {  // (uniform)
-      double q = sink_quantity(quantity, s, ox, oy, oz);
-      if (plan->ms_transform == 1) q = sin(q);
-      const double w = q - plan->ms_about;
+    if (plan->ms_quantity >= 0) {  // (uniform)
       const bool w_ok = w == w && fabs(w) < PRT_INF;
       v[9] = w_ok ? 1.0 : 0.0; v[10] = w_ok ? w : 0.0; v[11] = w_ok ? w * w : 0.0;
     }
@@ -1196,7 +1194,8 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     if (threadIdx.x == 0 && !failed) raise_error(&ctrl->error, PRT_ERR_ROWS_CAP);
     return;
   }
-  if (!live) return;
+  if (!PLAN && !live) return;
+  if (live) {  // (PLAN: the lanes without a live ray stay for the wave reductions of the sink below)
   // un-park the early columns
   sh.generation = PARK(0); sh.intensity = PARK(1); sh.wavelength = PARK(2);
   sh.index_in = PARK(3); sh.id = PARK(4);
@@ -1225,7 +1224,23 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     atomicExch(&ctrl->error, PRT_ERR_FULL_ROWS);
   if (sh.err) raise_error(&ctrl->error, sh.err);
   if (PLAN) {
-    if (plan->n_groups > 0) sink_accumulate(plan, g, sunk, sh, r.ox, r.oy, r.oz);  // (uniform)
+    // the sink's operands wait in the lane's parking slots (free again: the record columns are stored) for the
+    // wave to come together below -- held in registers across the join they cost the kernel 24-32 B of scratch
+    if (plan->n_groups > 0 && sunk) {  // (first clause uniform)
+      PARK(0) = sh.py; PARK(3) = sh.pz;
+      PARK(5) = r.ox - sh.tx * r.oy / sh.ty;  // the axis intercept, as k_frame_reduce computes it from the stored columns
+      const int quantity = plan->ms_quantity;
+      if (quantity >= 0) {
+        double q = sink_quantity(quantity, sh, r.ox, r.oy, r.oz);
+        if (plan->ms_transform == 1) q = sin(q);
+        PARK(6) = q - plan->ms_about;
+      }
+    }
+  }
+  }
+  if (PLAN) {
+    if (plan->n_groups > 0)  // (uniform; every lane of the wave: the reductions need their partners)
+      sink_accumulate(plan, g, sunk, PARK(0), PARK(3), PARK(5), PARK(6), PARK(2), PARK(1), PARK(4));
   }
   STAMP(7);
 }

@@ -220,7 +220,7 @@ static unsigned long long plan_key_of(const PlanDev& p) {  // what the plan's de
 
 extern "C" int prt_trace_set_plan(prt_scene* s, int device, int ticket, const prt_record_plan* plan) {
   DeviceCopy* c;
-  int rc = on_device(s, device, &c);
+  int rc = on_device(s, device, &c, true);
   if (rc) return rc;
   if (ticket < 0 || ticket >= PRT_TRACE_TICKETS) return fail(PRT_ERR_ARG, "ticket out of range");
   TraceTicket* t = &c->ticket[ticket];
@@ -705,7 +705,7 @@ extern "C" int prt_trace_begin(prt_scene* s, int device, int ticket, const doubl
                                void* workspace, int flags, void* stream) {
   HP(0);
   DeviceCopy* c;
-  int rc = on_device(s, device, &c);
+  int rc = on_device(s, device, &c, true);
   if (rc) return rc;
   if (ticket < 0 || ticket >= PRT_TRACE_TICKETS) return fail(PRT_ERR_ARG, "ticket out of range");
   TraceTicket* t = &c->ticket[ticket];
@@ -723,6 +723,13 @@ extern "C" int prt_trace_begin(prt_scene* s, int device, int ticket, const doubl
   t->rays = rays; t->n = n; t->ld = ld; t->limit = generation_limit; t->ray_offset = ray_offset;
   t->rows_out = rows_out; t->rows_cap = rows_cap; t->w = (char*)workspace; t->flags = flags;
   t->st = (hipStream_t)stream;
+  // a scene update whose copy may still be on its way (prt_scene_update): this stream waits for it, once
+  if (c->update_serial != 0 && (t->update_seen != c->update_serial || t->update_seen_stream != t->st)) {
+    HIP_TRY(hipStreamWaitEvent(t->st, c->update_event, 0));
+    t->update_seen = c->update_serial;
+    t->update_seen_stream = t->st;
+  }
+  t->traced = true;
   t->launched = false;
   t->allow_hints = !(flags & PRT_TRACE_NO_HINTS);
   t->allow_tile_hints = t->allow_hints && !(flags & PRT_TRACE_NO_TILE_RECORDS);
@@ -753,7 +760,7 @@ extern "C" int prt_trace_begin(prt_scene* s, int device, int ticket, const doubl
 
 extern "C" int64_t prt_trace_end(prt_scene* s, int device, int ticket, int64_t* rows_per_generation) {
   DeviceCopy* c;
-  int rc = on_device(s, device, &c);
+  int rc = on_device(s, device, &c, true);
   if (rc) return rc;
   if (ticket < 0 || ticket >= PRT_TRACE_TICKETS || !rows_per_generation)
     return fail(PRT_ERR_ARG, "bad ticket / null rows_per_generation");
@@ -858,7 +865,7 @@ extern "C" int64_t prt_trace_batch(prt_scene* s, int device, prt_trace_job* jobs
                                    double ray_offset, int depth, void* const* workspaces, void* const* streams,
                                    int flags) {
   DeviceCopy* c;
-  int rc = on_device(s, device, &c);
+  int rc = on_device(s, device, &c, true);
   if (rc) return rc;
   if (count < 0 || (count && !jobs) || depth < 1 || depth > PRT_TRACE_TICKETS || !workspaces)
     return fail(PRT_ERR_ARG, "bad job list / depth out of range (1..PRT_TRACE_TICKETS) / null workspaces");

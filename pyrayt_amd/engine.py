@@ -1262,7 +1262,7 @@ def sources_on_device(sources):
                for src in sources)
 
 
-def generate_rays(sources, rays_per_source, device, lo=0, hi=None):
+def generate_rays(sources, rays_per_source, device, lo=0, hi=None, specs=None):
     """The concatenated initial ray set of ``sources`` (pyrayt/_pyrayt.py:356-365), columns
     [lo, hi) of it, built directly in HBM: a CUDA (13, hi-lo) float64 tensor with consecutive
     ids.  Nothing crosses PCIe but the ~200-byte source descriptions."""
@@ -1276,7 +1276,8 @@ def generate_rays(sources, rays_per_source, device, lo=0, hi=None):
         a, b = max(lo, k * n), min(hi, (k + 1) * n)
         if b <= a:
             continue
-        kind, params, seed = src.device_spec()
+        # (specs: what RayTracer already asked the sources for -- a Lamp draws a new seed every time it is asked)
+        kind, params, seed = src.device_spec() if specs is None else specs[k][:3]
         rec = np.zeros(1, dtype=SOURCE_DTYPE)
         rec["kind"], rec["wavelength"], rec["seed"] = kind, src.wavelength, seed
         rec["params"][0, : len(params)] = params

@@ -328,6 +328,13 @@ class SinkStats:
         """The table of ``DeviceFrame.group_stats`` (count, y, z, rms_radius, focus, focus_std, wavelength, intensity per
         source) for the rows the plan let pass, of one generation (a number, or "last": the highest that counted a
         row) or of all of them (None).  Same arithmetic as ``k_frame_finish`` (csrc/prt_frame.hpp)."""
+        frame = pd.DataFrame(self.values(generation))
+        frame.index.name = "source_id"
+        return frame
+
+    def values(self, generation=None):
+        """``group_stats`` as a dict of numpy arrays (one entry per source): what a merit function reads in a loop,
+        without the 0.2 ms a DataFrame takes to build."""
         s = self._block(generation)
         count, with_focus = s[:, 0], s[:, 8]
         with np.errstate(invalid="ignore", divide="ignore"):
@@ -336,16 +343,14 @@ class SinkStats:
             var_r = np.maximum(s[:, 3] / safe - dy * dy - dz * dz, 0.0)
             var_f = np.maximum(s[:, 5] / safe_f - df * df, 0.0)
             nan = np.nan
-            frame = pd.DataFrame({
+            return {
                 "count": count.astype(np.int64),
                 "y": np.where(count > 0, self.pivots[:, 0] + dy, nan), "z": np.where(count > 0, self.pivots[:, 1] + dz, nan),
                 "rms_radius": np.where(count > 0, np.sqrt(var_r), nan),
                 "focus": np.where(with_focus > 0, self.pivots[:, 2] + df, nan),
                 "focus_std": np.where(with_focus > 0, np.sqrt(var_f), nan),
                 "wavelength": np.where(count > 0, s[:, 6] / safe, nan), "intensity": np.where(count > 0, s[:, 7] / safe, nan),
-            })
-        frame.index.name = "source_id"
-        return frame
+            }
 
     def mean_square(self, generation=None, per_source=False):
         """``np.mean(np.square(f(rows) - about))`` of the plan's ``mean_square`` quantity (``DeviceFrame.mean_square``):

@@ -40,6 +40,19 @@ class CountedObject:
         CountedObject._ids = count(start)
 
 
+class SceneEpoch:
+    """A process-wide counter that moves whenever an attribute of any scene object is assigned -- a transform applied
+    (``_append_world_transform`` assigns the matrices), a material or a normal sign changed, a wavelength set.  What
+    holds a compiled copy of a scene (``RayTracer``: the device scene of its components, the ray set of its sources)
+    remembers the value it was compiled at and looks at the objects again only when it has moved: a design loop that
+    calls ``trace()`` on an unchanged system pays nothing for it, one that moved a part re-snapshots as ever.  Not
+    seen: arrays edited in place (``part._world[0, 3] += 1`` -- upstream's own caches, the inverse matrix and the CSG
+    cull boxes, would be stale as well) and the insides of a user's material object (such systems are looked at
+    again on every trace); ``RayTracer.invalidate()`` is the way out for anything of that kind."""
+
+    value = 0
+
+
 class WorldObject(CountedObject):
     """An object with a 4x4 homogeneous object->world transform.
 
@@ -47,6 +60,10 @@ class WorldObject(CountedObject):
     re-derived with ``np.linalg.inv`` after every change, exactly as the reference does
     (``world_objects.py:122-129``) so the matrices handed to the device are the same floats.
     """
+
+    def __setattr__(self, name, value):
+        object.__setattr__(self, name, value)
+        SceneEpoch.value += 1
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)

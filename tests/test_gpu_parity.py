@@ -627,6 +627,112 @@ def test_raytracer_keeps_its_scene_when_a_part_moves():
     assert spots[0] != spots[1] != spots[2]                       # the detector really moved
 
 
+def test_raytracer_looks_at_its_system_again_only_when_something_was_assigned():
+    """RayTracer keeps the compiled scene and the generated ray set while the change counter of the scene objects
+    (g3d.objects.SceneEpoch) stands still, and picks up every kind of edit the moment it is made: a part moved, a
+    source moved, a material replaced, normals flipped, the ray count or the component list changed -- each time
+    the frame is that of a tracer built from scratch on the edited system."""
+    import pyrayt_amd as pyrayt
+    from pyrayt_amd import scene as scene_module
+
+    pyrayt.g3d.objects.CountedObject.reset_ids()
+    lens = pyrayt.components.biconvex_lens(2, 2, 0.25, aperture=1)
+    src = pyrayt.components.ConeOfRays(cone_angle=6).move_x(-1.9)
+    det = pyrayt.components.baffle((1, 1)).move_x(1)
+    tracer = pyrayt.RayTracer(src, [lens, det], rays_per_source=5_000)
+
+    def fresh():
+        return pyrayt.RayTracer(src, tracer.get_system(), rays_per_source=tracer.get_rays_per_source()).trace()
+
+    def same(a, b):
+        return a.shape == b.shape and np.array_equal(a.to_numpy(), b.to_numpy(), equal_nan=True)
+
+    first = tracer.trace()
+    snapshots = []
+    original = scene_module.SceneSnapshot.__init__
+
+    def counting(self, *args, **kwargs):
+        snapshots.append(1)
+        original(self, *args, **kwargs)
+
+    scene_module.SceneSnapshot.__init__ = counting
+    try:
+        rays_before = tracer._ray_cache[1]
+        for _ in range(3):
+            assert same(tracer.trace(), first)
+        assert not snapshots and tracer._ray_cache[1] is rays_before   # nothing was looked at, nothing regenerated
+        det.move_x(0.03)
+        assert same(tracer.trace(), fresh()) and len(snapshots) >= 1
+        src.move_x(-0.02)
+        moved = tracer.trace()
+        assert tracer._ray_cache[1] is not rays_before and same(moved, fresh()) and not same(moved, first)
+        det.material = pyrayt.materials.mirror               # an attribute assigned: seen
+        assert same(tracer.trace(), fresh())
+        det.material = pyrayt.materials.absorber
+        tracer.set_rays_per_source(7_000)
+        assert len(tracer.trace()) == len(fresh())
+        tracer.set_rays_per_source(5_000)
+        extra = pyrayt.components.baffle((1, 1)).move_x(0.6)
+        tracer.load_components([lens, extra, det])
+        assert same(tracer.trace(), fresh())
+        # an array edited in place is not an assignment: upstream's own cached inverse would be stale too
+        before = tracer.trace()
+        det._world[0, 3] += 0.05
+        det._object = np.linalg.inv(det._world)
+        count = len(snapshots)
+        assert same(tracer.trace(), before) and len(snapshots) == count
+        tracer.invalidate()
+        assert same(tracer.trace(), fresh()) and not same(tracer.get_results(), before)
+    finally:
+        scene_module.SceneSnapshot.__init__ = original
+
+
+def test_scene_updates_are_ordered_between_the_traces_around_them():
+    """prt_scene_update overwrites the scene tables with one stream-ordered copy -- behind the kernels of the traces
+    before it, in front of those after it, with no device-wide synchronisation.  Moving a part before every trace,
+    with the traces on different tickets and streams and the previous trace's rows not waited for, every frame must
+    be the one a scene compiled from scratch at that position gives."""
+    from pyrayt_amd.engine import DeviceScene
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    CountedObject.reset_ids()
+    parts, rays = scenes.config2(scenes.product_api(), 200_000, seed=5)
+    device_rays = dev(rays)
+    ds = DeviceScene(SceneSnapshot(parts))
+    streams = ds.ticket_streams(device_rays.device, 3)
+    blocks = [torch.empty((15, rays.shape[1] * 10), dtype=torch.float64, device="cuda:0") for _ in range(3)]
+    got, positions = [], []
+    for step in range(9):
+        parts[1].move_x(0.01 * (1 + step % 3))
+        positions.append(parts[1].get_world_transform())
+        assert ds.update(SceneSnapshot(parts))
+        ticket = step % 3
+        streams[ticket].wait_stream(torch.cuda.current_stream())
+        ds.trace_begin(ticket, device_rays, 10, blocks[ticket], stream=streams[ticket])
+        rows, counts = ds.trace_end(ticket)           # (counts are out; the last kernel may still be storing rows)
+        torch.cuda.current_stream().wait_stream(streams[ticket])
+        got.append((rows.clone(), counts))            # (the clone is ordered behind the trace; the next update is not waited for)
+    torch.cuda.synchronize()
+    for step, (rows, counts) in enumerate(got):
+        parts[1]._world = positions[step]
+        parts[1]._object = np.linalg.inv(positions[step])
+        reference = DeviceScene(SceneSnapshot(parts))
+        want, want_counts = reference.trace(device_rays, 10)
+        assert counts == want_counts and torch.equal(rows, want), step
+        reference.close()
+    # an entry point outside the ticket runtime between two updates: the update falls back to synchronising
+    ds.propagate(device_rays)
+    parts[1].move_x(0.02)
+    assert ds.update(SceneSnapshot(parts))
+    rows, counts = ds.trace(device_rays, 10)
+    reference = DeviceScene(SceneSnapshot(parts))
+    want, want_counts = reference.trace(device_rays, 10)
+    assert counts == want_counts and torch.equal(rows, want)
+    reference.close()
+    ds.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # compact state: rows 3, 7, 8 of the ray state are not carried between generations while they hold
 # what RaySet's defaults put there; a ray set that differs anywhere must get all 13 rows

@@ -20,7 +20,7 @@ def iteration(move, fused):
     if move:
         det.move_x(1e-4)
     if fused:  # the sums are accumulated by the generation kernels: no row is stored, none is read back
-        return tracer.trace_stats(surface=det).group_stats()["rms_radius"].iloc[0]
+        return tracer.trace_stats(surface=det).values()["rms_radius"][0]
     frame = tracer.trace_device()
     return frame.group_stats(surface=det.get_id())["rms_radius"].iloc[0]
 
