@@ -255,6 +255,9 @@ def _stream_ptr(torch, device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+_TICKET_STREAMS = {}  # device -> the process's ticket streams on it (DeviceScene.ticket_streams)
+
+
 class RecordPlan:
     """What a trace records when the caller does not want every row (``prt_record_plan``, include/prt.h).
 
@@ -723,12 +726,15 @@ class DeviceScene:
         runtime maps streams onto a handful of hardware queues -- four by default -- and two streams that
         land on one queue run their kernels one after the other, so a program should not keep making new ones)."""
         torch = _torch()
-        made = getattr(self, "_ticket_streams", None)
-        if made is None or made[0] != device:
-            made = self._ticket_streams = (device, [])
-        while len(made[1]) < depth:
-            made[1].append(torch.cuda.Stream(device))
-        streams = made[1][:depth]
+        # one pool per device for the whole process, not one set per scene: the runtime hands hardware queues to
+        # streams as they are created, and in a process that has made hundreds of streams (one set per scene, say)
+        # four particular ones may well sit on the same queue -- found by the queue probe of _runtime in the test
+        # suite's process.  Two scenes that trace on the same ticket number at the same time share a stream and
+        # take turns; tickets of one scene never do.
+        made = _TICKET_STREAMS.setdefault(str(device), [])
+        while len(made) < depth:
+            made.append(torch.cuda.Stream(device))
+        streams = made[:depth]
         # more streams than the runtime's default of four hardware queues covers (one is the null stream's): fine when
         # the queue setting was in place before the runtime initialised.  A user's own setting is taken at its word;
         # one made late (_runtime: torch was imported first, and possibly used) is checked once, by running something

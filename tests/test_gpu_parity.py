@@ -677,8 +677,8 @@ def test_raytracer_looks_at_its_system_again_only_when_something_was_assigned():
         assert same(tracer.trace(), fresh())
         # an array edited in place is not an assignment: upstream's own cached inverse would be stale too
         before = tracer.trace()
-        det._world[0, 3] += 0.05
-        det._object = np.linalg.inv(det._world)
+        extra._world[0, 3] += 0.05                               # (the part the rays end on)
+        extra._object[...] = np.linalg.inv(extra._world)
         count = len(snapshots)
         assert same(tracer.trace(), before) and len(snapshots) == count
         tracer.invalidate()
