@@ -84,6 +84,45 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 COPY_GBS = 6300.0               # what a bare copy with the kernel's row pattern reaches (tools/ubench/copy_f64: 5.7-6.4 TB/s)
 
 
+# What one rank does at the shard sizes of the 1/2/4/8 curve, measured on ONE MI355X (profiles/r5/shard_scaling.txt:
+# config 2, the library's own loop with 2-4 traces in flight, and one blocking prt_trace at a time) -- the stated
+# expectation a first multi-GPU record can be read against (no N > 1 run has happened on hardware yet).
+SHARD_MS_PER_STEP = {1_000_000: {"overlapped": 0.1353, "synchronous": 0.1795},
+                     500_000: {"overlapped": 0.0711, "synchronous": 0.1141},
+                     250_000: {"overlapped": 0.0385, "synchronous": 0.0802},
+                     125_000: {"overlapped": 0.0241, "synchronous": 0.0650}}
+XGMI_LINK_GBS, XGMI_LINKS = 153.0, 7  # 7 links x ~153 GB/s per GPU (~76 per direction if that figure is bidirectional)
+
+
+def scaling_model(n_job, world, rows_per_step):
+    """Expected step time and aggregate rate of `world` ranks on an `n_job`-ray job, from single-GPU measurements of a
+    rank's shard, and what re-assembling the frame on every GPU would add (bytes into each GPU; bound by one link for
+    a ring schedule, by all seven for a direct one)."""
+    shard = max(1, n_job // max(world, 1))
+    sizes = sorted(SHARD_MS_PER_STEP)
+    lo = max([k for k in sizes if k <= shard] or [sizes[0]])
+    hi = min([k for k in sizes if k >= shard] or [sizes[-1]])
+    model = {"shard_rays": shard, "from": "profiles/r5/shard_scaling.txt (one GPU tracing a rank's shard; config 2)"}
+    for mode in ("overlapped", "synchronous"):
+        a, b = SHARD_MS_PER_STEP[lo][mode], SHARD_MS_PER_STEP[hi][mode]
+        ms = a if hi == lo else a + (b - a) * (shard - lo) / (hi - lo)
+        model[mode] = {"ms_per_step": ms, "value": rows_per_step / (ms * 1e-3),
+                       "speedup_over_1_gpu": SHARD_MS_PER_STEP[1_000_000][mode] / ms * (n_job / 1_000_000)}
+    into_each = rows_per_step * 120.0 * (world - 1) / max(world, 1)
+    model["gather"] = {"bytes_into_each_gpu": into_each,
+                       "ring_ms_one_link": [into_each / (XGMI_LINK_GBS * 1e9) * 1e3, into_each / (XGMI_LINK_GBS / 2 * 1e9) * 1e3],
+                       "direct_ms_all_links": [into_each / (XGMI_LINK_GBS * XGMI_LINKS * 1e9) * 1e3,
+                                               into_each / (XGMI_LINK_GBS / 2 * XGMI_LINKS * 1e9) * 1e3],
+                       "what": "every rank receives the other ranks' rows (ncclAllGather per record column): link-bound if "
+                               "RCCL schedules a ring, seven links in parallel if it pushes directly; each pair = the "
+                               "153 GB/s figure taken per direction / as bidirectional.  `value` (no gather in the timed "
+                               "region) is what the model's `overlapped` line predicts; value_with_gather adds this"}
+    model["note"] = ("strong scaling of one 1M-ray job: at N = 8 a rank's shard is 125k rays, less than one round of workgroups "
+                     "(1280 x 256 rays resident), so a step is a chain of three launches each about as long as one wave lives; "
+                     "the expectation is ~5.6x at N = 8 with four chains in flight, ~2.7x on one stream")
+    return model
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,6 +184,16 @@ def summary_checks(frame, want):
         pairs, pair_counts = np.unique(np.stack((gens, surf)), axis=1, return_counts=True)
         checks["rows_per_generation_x_surface"] = bool(np.array_equal(pairs, want["gen_surface_pairs"]) and
                                                        np.array_equal(pair_counts, want["gen_surface_counts"]))
+    if not checks.get("rows_per_generation_x_surface", False):
+        # say WHICH generation x surface differs: the first thing anybody debugging a first multi-GPU run wants to know
+        pairs, pair_counts = np.unique(np.stack((gens, surf)), axis=1, return_counts=True)
+        got = {tuple(p): int(c) for p, c in zip(pairs.T.tolist(), pair_counts)}
+        ref = {tuple(p): int(c) for p, c in zip(np.asarray(want["gen_surface_pairs"]).T.tolist(), want["gen_surface_counts"])}
+        for key in sorted(set(got) | set(ref)):
+            if got.get(key, 0) != ref.get(key, 0):
+                print(f"bench.py: generation {key[0]} x surface {key[1]}: {got.get(key, 0)} rows, the reference has "
+                      f"{ref.get(key, 0)}", file=sys.stderr, flush=True)
+    if checks["rows"]:
         checks["q5_ids"] = bool(np.array_equal(frame[(gens == 1) & (surf == surf.max()), 4].astype(np.int64), want["q5_ids"]))
         checks["surface_checksum"] = int((surf * (gens + 1)).sum()) == int(want["surface_checksum"])
         checks["column_sums"] = bool(np.allclose(frame.sum(axis=0), want["column_sums"], rtol=1e-9, atol=1e-3))
@@ -518,6 +567,10 @@ def main():
             pre_verification = verdict[0]
             if pre_verification is not None and not pre_verification[0]:
                 if rank == 0:
+                    for seed_key, seed_checks in sorted((pre_verification[1].get("checks") or {}).items()):
+                        failed_checks = [name for name, ok in (seed_checks or {}).items() if not ok]
+                        if failed_checks:
+                            print(f"bench.py: seed {seed_key}: failed {failed_checks}", file=sys.stderr, flush=True)
                     print(json.dumps({"metric": "ray-surface intersections/sec, 1M-ray biconvex lens", "value": None, "n_gpus": world,
                                       "verified": False, "verification": pre_verification[1]}), flush=True)
                 dist.barrier()
@@ -673,6 +726,96 @@ def main():
         cold = {"ms": min(cold_times) * 1e3, "rows_per_s_this_gpu": cold_count / min(cold_times),
                 "what": "DeviceScene(snapshot) + its first trace (no hints, control words initialised), best of 3; "
                         "kernels already loaded by this process"}
+    # (g) record plans (round 6; include/prt.h prt_record_plan): the same steps when the caller wants only the rows of
+    #     the detector -- `results.loc[results['surface'] == imager.get_id()]`, examples/lens_design.ipynb cells 11, 19,
+    #     38 -- or no rows at all, only the sums its merit function is made of (cells 12, 15, 20): issued like the
+    #     timed region (`overlapped`) and as blocking prt_trace calls (`synchronous`).  Their rows per second count the
+    #     ray segments RESOLVED (what the metric counts), of which only the detector's are stored / summed.
+    record_plans = None
+    if args.side_steps > 0 and args.workload == "config2" and args.flags == 0:
+        try:
+            detector = int(snap.prims["surface_id"][-1])
+            resolved_per_step = float(sum(set_stats[k % len(set_stats)]["rows"] for k in range(args.side_steps))) / args.side_steps
+            record_plans = {}
+            for label, plan in (("detector_rows", engine.RecordPlan(surfaces=(detector,), rows=True, generation_limit=limit)),
+                                ("detector_sums", engine.RecordPlan(surfaces=(detector,), rows=False, stats=True,
+                                                                    generation_limit=limit))):
+                respin()
+                for k in range(8):
+                    got, got_counts = scene.trace(ray_set(k), limit, out=block, plan=plan)
+                torch.cuda.synchronize(device)
+                p0 = time.perf_counter()
+                for k in range(args.side_steps):
+                    got, got_counts = scene.trace(ray_set(k), limit, out=block)
+                torch.cuda.synchronize(device)
+                sync_s = (time.perf_counter() - p0) / args.side_steps
+                stored = int(sum(got_counts))
+                st = scene.trace_stats()
+                for ticket in range(depth):
+                    scene.set_plan(ticket, plan, device)
+                batch = engine.TraceBatch(scene, [ray_set(k) for k in range(args.side_steps)], limit, depth=depth,
+                                          outs=blocks[:max(depth, 2)], flags=engine.TRACE_NO_TIMING | engine.TRACE_BUSY)
+                batch.run()
+                torch.cuda.synchronize(device)
+                p0 = time.perf_counter()
+                batch.run()
+                torch.cuda.synchronize(device)
+                over_s = (time.perf_counter() - p0) / args.side_steps
+                union = batch.busy()
+                for ticket in range(depth):
+                    scene.set_plan(ticket, None, device)
+                # what such a step has to move: the caller's 13 rows in, lean state between the generations, 120 B per
+                # stored row (SURVEY 8d's per-unit figures with the rows that are not asked for left out)
+                carried = float(st["rays_carried"])
+                bytes_step = 104.0 * n + STATE_BYTES_LEAN * (st["ray_generations"] - n) + STATE_BYTES_LEAN * carried + ROW_BYTES * stored
+                record_plans[label] = {
+                    "rows_stored_per_step": stored, "segments_resolved_per_step": resolved_per_step,
+                    "synchronous_ms_per_step": sync_s * 1e3, "overlapped_ms_per_step": over_s * 1e3,
+                    "value_synchronous": resolved_per_step * world / sync_s, "value_overlapped": resolved_per_step * world / over_s,
+                    "launches_per_step": st["kernel_launches"],
+                    "roofline": {"bound": "hbm", "bytes_per_step": bytes_step,
+                                 "what": "13 state rows in + 56 B lean state each way between generations + 120 B per STORED row",
+                                 "kernel_ms_per_step": union["union_ms"] / args.side_steps if union["traces"] else None,
+                                 "achieved": bytes_step / (union["union_ms"] / args.side_steps * 1e-3) / 1e9 if union["traces"] else None,
+                                 "frac": bytes_step / (union["union_ms"] / args.side_steps * 1e-3) / 1e9 / HBM_PEAK_GBS if union["traces"] else None,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s"}}
+            scene.trace(rays_dev, limit, out=block, plan=None)
+            # ... and the loop those plans are for, through the front end (RayTracer on the same system: sources on the
+            # device, the detector's spot size read every iteration; every second figure with the detector moved first)
+            import pyrayt_amd as pyrayt
+
+            CountedObject.reset_ids()
+            loop_lens = pyrayt.components.biconvex_lens(2, 2, 0.25, aperture=1)
+            loop_src = pyrayt.components.ConeOfRays(cone_angle=6).move_x(-1.9)
+            loop_det = pyrayt.components.baffle((1, 1)).move_x(1)
+            tracer = pyrayt.RayTracer(loop_src, [loop_lens, loop_det], rays_per_source=n)
+
+            def iteration(move, fused):
+                if move:
+                    loop_det.move_x(1e-4)
+                if fused:
+                    return tracer.trace_stats(surface=loop_det).values()["rms_radius"][0]
+                return tracer.trace_device().group_stats(surface=loop_det.get_id())["rms_radius"].iloc[0]
+
+            loop = {}
+            for fused in (False, True):
+                for move in (False, True):
+                    for _ in range(5):
+                        iteration(move, fused)
+                    torch.cuda.synchronize(device)
+                    p0 = time.perf_counter()
+                    for _ in range(40):
+                        iteration(move, fused)
+                    torch.cuda.synchronize(device)
+                    loop[("trace_stats" if fused else "trace_device+group_stats") + ("_moving_part" if move else "_unchanged")] = \
+                        (time.perf_counter() - p0) / 40 * 1e3
+            record_plans["design_loop_ms_per_iteration"] = dict(loop, what=(
+                f"RayTracer on the bench's system, {n} rays from a device-side ConeOfRays, the detector's rms spot radius "
+                "read on the host every iteration (tools/design_loop.py): the frame stored and reduced (prt_frame_stats) "
+                "against the sums accumulated in the generation kernels (RayTracer.trace_stats)"))
+        except Exception as exc:  # noqa: BLE001
+            record_plans = dict(record_plans or {}, error=f"{type(exc).__name__}: {exc}"[:300])
+        respin()
     # --- in-run correctness tie: the rows of the timed workload against the reference's own summaries of it ---------
     # One GPU: the rows the last timed step of EACH ray set of the rotation left in its record block (brought to the
     # host right behind the timed region).  Several GPUs: checked before the timed region, see `pre_verification`.
@@ -844,7 +987,7 @@ def main():
     with open(engine.LIB_PATH, "rb") as fh:
         library_sha16 = hashlib.sha256(fh.read()).hexdigest()[:16]
     traffic, traffic_note = None, None
-    traffic_file = next((f for f in (os.path.join(ROOT, "profiles", r, "traffic.json") for r in ("r5", "r4", "r3", "r2"))
+    traffic_file = next((f for f in (os.path.join(ROOT, "profiles", r, "traffic.json") for r in ("r6", "r5", "r4", "r3", "r2"))
                          if os.path.exists(f)), None)
     if traffic_file and args.flags == 0 and n == RAYS_PER_GPU and args.workload == "config2":
         with open(traffic_file) as fh:
@@ -920,6 +1063,13 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
+            # (`frac` prices the timed region: with two traces in flight it is the throughput of two INTERLEAVED traces
+            # over the time the device had at least one of them in flight -- not one kernel's duration.  The generation
+            # kernel with the device to itself is `kernel_alone_frac` (= one_stream.frac, what rocprofv3 --stats of
+            # `bench.py --streams 1` averages))
+            "frac_means": ("algorithmic bytes of the region's launches / the union of the traces' busy intervals: two traces "
+                           "interleaved" if busy is not None else "algorithmic bytes of a launch / its HIP-event duration"),
+            "kernel_alone_frac": None,
             "frac_of_measured_copy": achieved / COPY_GBS,
             "traffic": traffic,
             "traffic_source": traffic_note,
@@ -971,6 +1121,7 @@ def main():
         bytes_alone = one_stream.pop("_bytes")
         gbs = bytes_alone / (one_stream["kernel_ms_per_step"] * args.steps * 1e-3) / 1e9 if one_stream["kernel_ms_per_step"] > 0 else 0.0
         one_stream["achieved"], one_stream["frac"] = gbs, gbs / HBM_PEAK_GBS
+        line["roofline"]["kernel_alone_frac"] = gbs / HBM_PEAK_GBS
         one_stream["what"] = ("the same steps on ONE stream right behind the timed region: the generation kernel with the device to "
                               "itself (HIP events per trace; compare rocprofv3 --stats of `bench.py --streams 1`)")
 
@@ -1020,6 +1171,13 @@ def main():
         line["changing_ray_count"] = side_resized
     if result_sink:
         line["result_sink"] = result_sink
+    line["scaling_model"] = scaling_model(n_job if strong else n_job * world, world, total_rows_per_step)
+    if record_plans:
+        line["record_plans"] = record_plans
+        if "detector_rows" in record_plans and "value_overlapped" in record_plans.get("detector_rows", {}):
+            line["value_filtered"] = record_plans["detector_rows"]["value_overlapped"]
+        if "detector_sums" in record_plans and "value_overlapped" in record_plans.get("detector_sums", {}):
+            line["value_sums_only"] = record_plans["detector_sums"]["value_overlapped"]
     if gather:
         line["gather"] = gather
         if "ms" in gather:  # a trace, then its re-assembly, one after the other

@@ -139,7 +139,7 @@ struct prt_scene {
   std::vector<char> plan_hint_mode;
   unsigned long long plan_hint_key = 0;
   int plan_hint_rest = 0, plan_hint_misses_in_a_row = 0;
-  long long plan_launches = 0, plan_dense_launches = 0, plan_misses = 0;
+  long long plan_launches = 0, plan_dense_launches = 0, plan_misses = 0, plan_traces = 0;
   int tile_hint_holdoff = 0, tile_hint_misses_in_a_row = 0;  // per-tile records rest after a miss like the dense hints do
   long long tile_hint_launches = 0, tile_hint_misses = 0;
   bool has_untracable = false;                  // a shading error can be raised at store time (a surface without a

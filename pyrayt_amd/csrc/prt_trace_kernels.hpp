@@ -836,19 +836,39 @@ __device__ __forceinline__ void sink_accumulate(ConstPlan plan, int g, bool sunk
   }
   const int64_t wave_id = (int64_t)blockIdx.x * (PRT_BLOCK / 64) + (threadIdx.x >> 6);
   double* const mine = plan->sums + ((size_t)(wave_id & (plan->slots - 1)) * plan->limit + g) * n_groups * SINK_STATS;
+  const bool with_ms = plan->ms_quantity >= 0;  // (uniform)
   unsigned long long pending = __ballot(group >= 0);
   while (pending) {  // one turn per group present in the wave: almost always exactly one
     const int leader = __ffsll((long long)pending) - 1;
     const int cur = __shfl(group, leader);
     const bool take = group == cur;
+    double* const out = mine + (size_t)cur * SINK_STATS;
+    // the three counts are popcounts of ballots (scalar unit); the sums that can be non-zero go through the shuffles
+    const unsigned long long m_take = __ballot(take);
+    const double n_rows = (double)__popcll(m_take), n_focus = (double)__popcll(__ballot(take && v[8] != 0.0));
+    if (lane == 0) {
+      atomicAdd(out + 0, n_rows);
+      if (n_focus != 0.0) atomicAdd(out + 8, n_focus);
+    }
 #pragma unroll
-    for (int k = 0; k < SINK_STATS; ++k) {
+    for (int k = 1; k < 8; ++k) {
       double t = take ? v[k] : 0.0;
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
-      if (lane == 0 && t != 0.0) atomicAdd(mine + (size_t)cur * SINK_STATS + k, t);
+      if (lane == 0 && t != 0.0) atomicAdd(out + k, t);
     }
-    pending &= ~__ballot(take);
+    if (with_ms) {
+      const double n_ms = (double)__popcll(__ballot(take && v[9] != 0.0));
+      if (lane == 0 && n_ms != 0.0) atomicAdd(out + 9, n_ms);
+#pragma unroll
+      for (int k = 10; k < 12; ++k) {
+        double t = take ? v[k] : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+        if (lane == 0 && t != 0.0) atomicAdd(out + k, t);
+      }
+    }
+    pending &= ~m_take;
   }
 }
 

@@ -334,15 +334,18 @@ static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
     const int64_t src_ld = (gg == 0) ? t->ld : n;
     if (t->plan_active) {
       // A trace under a record plan: the dense forms it knows are "every ray goes on" / "none does", each with
-      // "every ray stores a row" / "none does" (k_generation<.., PLAN>); anything else compacts by look-back.  A plan
-      // that stores no rows keeps its absorbed rays (as upstream carries them, _pyrayt.py:415-428): nothing of theirs is
-      // stored or summed, and the generation that absorbed a few stays dense.
+      // "every ray stores a row" / "none does" (k_generation<.., PLAN>); anything else compacts by look-back.  Bit 5 of a
+      // hint (plans that store no rows): the generation lost a few absorbed rays last time -- it is launched dense with
+      // its absorbed rays kept, as upstream carries them (_pyrayt.py:415-428): nothing of theirs is stored or summed by
+      // the generation behind, which finds them dead on arrival (the product path's sparse-loss form without its dead
+      // lists: with no rows to place, dead lanes cost the next generation nothing but their slots).
       int assume = 0;
       if (t->use_hints && gg < (int)s->plan_hint_mode.size()) assume = s->plan_hint_mode[gg];
       t->launch_mode[gg] = (char)assume;
       s->plan_launches += 1;
       s->plan_dense_launches += assume ? 1 : 0;
-      const int keep = (keep_absorbed || !t->plan_host->store_rows) ? 1 : 0;
+      const int keep = (keep_absorbed || (assume & 32)) ? 1 : 0;
+      assume &= 31;
       hipLaunchKernelGGL(kernel, dim3(blocks_for(n)), dim3(PRT_BLOCK), lds, st, sd, src, src_ld, buf[gg & 1], n,
                          t->rows_out, t->rows_cap, ctrl, gen, gg, tiles[t->flip], tiles[t->flip ^ 1], (double)(gg + 1),
                          t->limit, t->ray_offset, keep,
@@ -484,6 +487,9 @@ static int fused_start(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
       t->sink_unclean = true;  // (until plan_fold has run behind this attempt)
     }
     bool plan_hints = t->allow_hints && s->plan_hint_key == t->plan_key && !t->test_stall;
+    if (plan_hints && (++s->plan_traces & 31) == 0) {  // (every 32nd trace under the plan: the kept-rays bits are measured anew)
+      for (char& m : s->plan_hint_mode) if (m & 32) m = 0;
+    }
     if (plan_hints && s->plan_hint_rest > 0) {
       s->plan_hint_rest -= 1;
       plan_hints = false;
@@ -560,7 +566,16 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
         // does, and all of them store a row or none does (k_generation<.., PLAN>: bits 0..3 | bit 4)
         const int carry_form = lost == 0 ? 1 : host_gen[b].n_carry == 0 ? 2 : 0;
         const bool rec_all = all_live, rec_none = host_gen[b].n_live == 0;
-        t->seen_mode[t->n_seen - 1] = (char)(carry_form && (rec_all || rec_none) ? (carry_form | (rec_none ? 16 : 0)) : 0);
+        char mode = (char)(carry_form && (rec_all || rec_none) ? (carry_form | (rec_none ? 16 : 0)) : 0);
+        if (!t->plan_host->store_rows && !keep_absorbed) {
+          // (no rows to place: a generation that loses only a few absorbed rays keeps them next time and stays dense;
+          // one launched that way is seen to carry everything and stays that way -- every 64th trace of the scene under
+          // a plan is launched without the bit, so that a generation that has begun to absorb in numbers is found out)
+          const bool kept = (t->launch_mode[t->g + b] & 32) != 0;
+          const bool sparse = lost > 0 && host_gen[b].n_carry > 0 && lost * 64 <= host_gen[b].n_in;
+          if ((kept && carry_form == 1) || (!kept && sparse)) mode = (char)(1 | 16 | 32);
+        }
+        t->seen_mode[t->n_seen - 1] = mode;
       }
     }
     if (!done && host_gen[t->batch].n_in == 0) done = true;
