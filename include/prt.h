@@ -154,11 +154,7 @@ typedef struct prt_scene_options {
                                 the interval form (an intersection of the leaves' [enter, exit] intervals) */
   int32_t no_clearance;      /* 1: the cylinder that cuts a lens chain to its aperture is evaluated for every wave (0: not for a
                                 wave all of whose chords run inside it by a margin: a convexity argument) */
-  int32_t chunks;            /* how a repeated trace of 256k .. 2.5M rays whose generations all run dense is issued: 0 as two
-                                chunks -- the first and the second half of the rays, each a chain of launches of its own, the
-                                second on a stream of the library's, generation g of one overlapping generation g +- 1 of the
-                                other (see "chunked traces" at prt_trace) --, 1 never, 2 (tests) whenever it has two tiles */
-  int32_t reserved[3];
+  int32_t reserved[4];
 } prt_scene_options;
 
 /* Build a scene from a snapshot.  roots[] lists the node index of every top-level component
@@ -338,18 +334,6 @@ int prt_generate_rays(int device, const prt_source* source, int64_t n_total, int
                                      (see prt_trace_telemetry); A/B, tests */
 #define PRT_TRACE_COUNT_PATHS 128 /* count, in prt_trace_telemetry, the rays that are not well formed and
                                      the CSG node evaluations that took an exact path (see there) */
-#define PRT_TRACE_NO_CHUNKS 4096  /* do not run this trace as two chunks (see prt_scene_options.chunks); A/B, tests */
-/* Chunked traces.  A generation's workgroups leave the chip partly idle while they start up and drain, and kernels of
- * the SAME chain cannot fill that (generation g + 1 needs g); kernels of another chain can.  A caller with two
- * independent ray sets gets that from two tickets on two streams; a caller with ONE blocking prt_trace gets it from
- * the library: once the scene's previous trace has shown every generation to run dense (all rays recorded; all or none
- * carried on; a few absorbed ones kept), a trace of 256k .. 2.5M rays is issued as two chunks -- rays [0, n_a) on the
- * caller's stream, [n_a, n) on a stream of the library's, forked from and joined back into the caller's by events --
- * whose rows land where the one-chain trace puts them: generation-major, and inside a generation chunk A's rows in
- * front of chunk B's (a chunk skips the other's rows of a generation, known at launch for dense generations; the last
- * generation behind one that kept absorbed rays takes chunk A's dead-ray count from a two-thread kernel in between).
- * Every tile checks what it was launched on, as ever; a refuted assumption, in either chunk, makes the library repeat
- * the trace as one chain without assumptions.  The workspace of prt_trace_workspace_bytes(n) holds both chunks. */
 int64_t prt_trace_workspace_bytes(int64_t n);
 int64_t prt_trace(prt_scene* scene, int device, const double* rays, int64_t n, int64_t ld,
                   int generation_limit, double ray_offset, double* rows_out, int64_t rows_cap,
@@ -556,7 +540,6 @@ int prt_frame_mean_square(int device, const double* rows, int64_t ld, int64_t n_
 #define PRT_VARIANT_UNFUSED 2     /* propagate / scan / interact kernels per generation */
 #define PRT_VARIANT_KLANES 3      /* ... with the surface-parallel nearest-hit kernel (K lanes per ray,
                                      shuffle min-reduce; prt_scene_options.hit_lanes = 4 | 8 | 16) */
-#define PRT_VARIANT_CHUNKED 4     /* PRT_VARIANT_FUSED issued as two chunks on two streams (see "Chunked traces") */
 int prt_trace_stats(const prt_scene* scene, double* out8);
 /* counters of this scene since it was created: out12 = { traces re-run on the three-kernel path after a
  * look-back gave up, traces repeated because a dense-mode hint did not hold, generation launches made in

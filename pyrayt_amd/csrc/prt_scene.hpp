@@ -84,18 +84,6 @@ struct TraceTicket {
   bool allow_tile_hints = true, use_tile_records = false, used_tile_hints = false;
   bool records_off = false;  // this attempt: the records of the generations still to come were taken on other rays (see launch_mode 4)
   unsigned long long user = 0;  // identity of this ticket in the workspace registry (0: not drawn yet)
-  // a trace run as two chunks (prt_trace_runtime.hpp, "chunked traces"): chunk A is the ticket itself with the first
-  // n_a rays, chunk B a helper ticket of the device copy with the rest, on a stream of the library's own
-  bool chunked = false;                 // this attempt runs as two chunks
-  bool secondary = false;               // this IS a helper ticket (chunk B of `lead`)
-  struct TraceTicket* lead = nullptr;   // chunk B: the ticket whose launch decisions it follows
-  int64_t n_whole = 0;                  // rays of the whole trace (`n` is this chunk's while chunked)
-  char launch_assume[kMaxGenerationSlots] = {0}, launch_keep[kMaxGenerationSlots] = {0};  // what each generation of the attempt was launched with
-  int64_t slots_skip = 0;               // the chunk skip the generation slots of the ready workspace hold (0: an ordinary trace's)
-  int64_t slots_base0 = 0;              // ... and the row base of generation 0 there
-  hipEvent_t mark_event = nullptr;      // chunk A: recorded behind generation `mark_after` (its dead list is complete then)
-  int mark_after = -1;
-  int link_before = -1;                 // chunk B: the generation whose row base waits for chunk A's dead list
   unsigned long long update_seen = 0;   // the scene update this ticket's stream has waited for ...
   hipStream_t update_seen_stream = nullptr;  // ... and which stream that was
   bool traced = false;                  // launched something since the scene's last update
@@ -129,9 +117,6 @@ struct DeviceCopy {
   DevInstr* render_code = nullptr;              // same with the renderers' selection rule
   std::vector<DevInstr*> component_code;        // one program per component, no I_ROOT
   TraceTicket ticket[PRT_TRACE_TICKETS];
-  TraceTicket helper[PRT_TRACE_TICKETS];        // chunk B of a chunked trace of ticket k (resources made at first use)
-  hipStream_t chunk_stream[PRT_TRACE_TICKETS] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t chunk_fork[PRT_TRACE_TICKETS] = {nullptr, nullptr, nullptr, nullptr}, chunk_join[PRT_TRACE_TICKETS] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> busy_events;          // PRT_TRACE_BUSY: two per job of the largest batch so far (kept, reused)
   std::vector<char> busy_recorded;              // ... per job of the current batch: its pair was recorded by a launch
   double busy[4] = {0, 0, 0, 0};                // prt_trace_batch_busy: what the last such batch measured
@@ -155,7 +140,6 @@ struct prt_scene {
   unsigned long long plan_hint_key = 0;
   int plan_hint_rest = 0, plan_hint_misses_in_a_row = 0;
   long long plan_launches = 0, plan_dense_launches = 0, plan_misses = 0, plan_traces = 0;
-  long long chunked_traces = 0;                 // traces that ran, and held, as two chunks
   int tile_hint_holdoff = 0, tile_hint_misses_in_a_row = 0;  // per-tile records rest after a miss like the dense hints do
   long long tile_hint_launches = 0, tile_hint_misses = 0;
   bool has_untracable = false;                  // a shading error can be raised at store time (a surface without a
@@ -1045,17 +1029,6 @@ static void release_device_copy(DeviceCopy& c) {
     free((void*)t.plan_host);  // (malloc'ed by prt_trace_set_plan)
     if (t.plan_dev) (void)hipFree(t.plan_dev);
     if (t.sink_slots) (void)hipFree(t.sink_slots);
-    if (t.mark_event) (void)hipEventDestroy(t.mark_event);
-  }
-  for (int k = 0; k < PRT_TRACE_TICKETS; ++k) {
-    TraceTicket& h = c.helper[k];
-    if (h.host_pinned) (void)hipHostFree(h.host_pinned);
-    if (h.mirror) (void)hipHostFree(h.mirror);
-    if (h.ev0) (void)hipEventDestroy(h.ev0);
-    if (h.ev1) (void)hipEventDestroy(h.ev1);
-    if (c.chunk_stream[k]) (void)hipStreamDestroy(c.chunk_stream[k]);
-    if (c.chunk_fork[k]) (void)hipEventDestroy(c.chunk_fork[k]);
-    if (c.chunk_join[k]) (void)hipEventDestroy(c.chunk_join[k]);
   }
   for (hipEvent_t e : c.busy_events) (void)hipEventDestroy(e);
   c = DeviceCopy();

@@ -465,13 +465,6 @@ __device__ __forceinline__ DeadList* dead_list(GenCtrl* gen, int g) {
 __device__ __forceinline__ TileHint* tile_hints(GenCtrl* gen, int g) {
   return reinterpret_cast<TileHint*>(reinterpret_cast<char*>(gen) + kTileHintOffset) + (size_t)g * gridDim.x;
 }
-// A trace run as two chunks (prt_trace_runtime.hpp): the rows of generation g are [chunk A's | chunk B's], so behind its own
-// rows of generation g a chunk skips what the other one records -- known at launch for the dense forms a chunked trace is
-// made of (the other chunk's ray count) and kept in the generation slot's padding, behind the ray count the per-tile
-// records belong to.  Zero in every slot of an ordinary trace (k_fused_init clears the slots).
-__device__ __forceinline__ int64_t chunk_skip(const GenCtrl* gen, int g) {
-  return *reinterpret_cast<const int64_t*>(gen[g].pad + 2);
-}
 struct FusedCtrl {
   int32_t error;
   int32_t pad;
@@ -1193,9 +1186,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     gen[g].n_live = total_live;
     gen[g].n_carry = total_carry;
     gen[g + 1].n_in = next_in;
-    // (+ the rows another chunk of the same trace records between this chunk's generations: 0 unless the runtime runs
-    // the trace as two chunks, see chunk_skip)
-    gen[g + 1].row_base = row_base + total_live + chunk_skip(gen, g);
+    gen[g + 1].row_base = row_base + total_live;
     // (the end of the trace: launches queued blind behind it must find empty generations, whatever an
     // earlier trace left in their slots)
     if (next_in == 0)

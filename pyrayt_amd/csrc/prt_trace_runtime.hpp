@@ -39,22 +39,8 @@ static TraceLayout trace_layout(int64_t n) {
   return l;
 }
 
-// ---- chunked traces (include/prt.h, "Chunked traces") ---------------------------------------------------------------
-static const int64_t kChunkMinRays = 262144;   // a trace is issued as two chunks from here on (each at least 512 tiles) ...
-static const int64_t kChunkMaxRays = 2500000;  // ... up to where the states of both still share the Infinity Cache
-// rays of chunk A (a whole number of tiles: chunk B's tiles are then the one-chain trace's tiles nA / 256 onwards)
-static int64_t chunk_split(int64_t n) { return (int64_t)align_up((size_t)((n + 1) / 2), PRT_BLOCK); }
-// where chunk B's workspace starts inside the caller's block
-static size_t chunk_b_offset(int64_t n) { return align_up(trace_layout(chunk_split(n)).total, 256); }
-
 extern "C" int64_t prt_trace_workspace_bytes(int64_t n) {
-  if (n < 0) n = 0;
-  size_t total = trace_layout(n).total;
-  if (n >= 2 * PRT_BLOCK) {  // room for the control words of a second chunk
-    const size_t chunked = chunk_b_offset(n) + trace_layout(n - chunk_split(n)).total;
-    if (chunked > total) total = chunked;
-  }
-  return (int64_t)total;
+  return (int64_t)trace_layout(n < 0 ? 0 : n).total;
 }
 
 static int64_t trace_error(int error) {
@@ -204,22 +190,6 @@ extern "C" void prt_debug_host_profile(double* out9) { for (int k = 0; k < 8; ++
 #else
 #define HP(k)
 #endif
-
-// the generation slots of a chunk: where its generation 0 records and what it skips behind every generation
-// (chunk_skip() in prt_trace_kernels.hpp); base0 = skip = 0 puts an ordinary trace's values back
-__global__ void k_chunk_setup(GenCtrl* gen, int n_slots, int64_t base0, int64_t skip) {
-  for (int k = threadIdx.x; k < n_slots; k += blockDim.x) *reinterpret_cast<int64_t*>(gen[k].pad + 2) = skip;
-  if (threadIdx.x == 0) gen[0].row_base = base0;
-}
-// in front of chunk B's generation g when chunk A's generation g runs on the dead list of ITS generation g - 1 (the last
-// generation of the trace): chunk A records its rays less the dead ones, and chunk B's rows start behind them
-__global__ void k_chunk_link(GenCtrl* gen_b, int g, const DeadList* dead_a) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const unsigned entries = dead_a->count < (unsigned)kDeadListCap ? dead_a->count : (unsigned)kDeadListCap;
-  int64_t dead = 0;
-  for (unsigned k = 0; k < entries; ++k) dead += dead_a->entry[k] & 511u;
-  gen_b[g].row_base -= dead;
-}
 
 // ---- record plans (include/prt.h prt_record_plan; the device side is PlanDev in prt_trace_kernels.hpp) -------------
 // the plan as the kernels read it, put into the ticket's device copy on the trace's stream
@@ -386,25 +356,6 @@ static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
     }
     // dense-mode hint of the previous trace for this generation (the kernel reads the generation's
     // ray count on the device and checks the assumption tile by tile)
-    if (t->secondary) {
-      // chunk B of a chunked trace: launched exactly as chunk A's generation was (its decisions were taken first)
-      const int assume_b = t->lead->launch_assume[gg], keep_b = t->lead->launch_keep[gg];
-      t->launch_mode[gg] = t->lead->launch_mode[gg];
-      if (gg == t->link_before) {
-        const TraceLayout la = trace_layout(t->lead->n);
-        GenCtrl* gen_a = (GenCtrl*)(t->lead->w + la.gen);
-        HIP_TRY(hipStreamWaitEvent(st, t->lead->mark_event, 0));
-        hipLaunchKernelGGL(k_chunk_link, dim3(1), dim3(64), 0, st, gen, gg,
-                           (const DeadList*)(reinterpret_cast<char*>(gen_a) + kDeadListOffset) + ((gg - 1) % 3));
-      }
-      hipLaunchKernelGGL(kernel, dim3(blocks_for(n)), dim3(PRT_BLOCK), lds, st, sd, src, src_ld, buf[gg & 1], n,
-                         t->rows_out, t->rows_cap, ctrl, gen, gg, tiles[t->flip], tiles[t->flip ^ 1], (double)(gg + 1),
-                         t->limit, t->ray_offset, keep_b,
-                         t->publish_in_kernel ? t->mirror_dev : (HostMirror*)nullptr, epoch, b,
-                         b + 1 == t->batch ? 1 : 0, assume_b, (const PlanDev*)nullptr);
-      t->flip ^= 1;
-      continue;
-    }
     int assume = 0;
     if (t->use_hints && gg < (int)s->hint_mode.size()) assume = s->hint_mode[gg];
     // (a generation whose dense hint was refuted lately keeps compacting for a while: see hint_rest)
@@ -458,9 +409,6 @@ static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
                        t->publish_in_kernel ? t->mirror_dev : (HostMirror*)nullptr, epoch, b,
                        b + 1 == t->batch ? 1 : 0, assume, (const PlanDev*)nullptr);
     t->flip ^= 1;
-    t->launch_assume[gg] = (char)assume;
-    t->launch_keep[gg] = (char)keep;
-    if (t->chunked && gg == t->mark_after) HIP_TRY(hipEventRecord(t->mark_event, st));  // (chunk B's link waits for this generation's dead list)
     if (b == 0) HP(4);
   }
   if (timed) {
@@ -508,19 +456,6 @@ static int fused_start(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
                        n_slots, (unsigned long long*)(w + l.tiles_a), (int64_t)blocks_for(n), n, t->test_stall);
     t->flip = 0;
     for (bool& kept : t->tile_record) kept = false;  // (the slots the records are checked against are cleared)
-    t->slots_skip = t->slots_base0 = 0;
-  }
-  {
-    // the generation slots carry what this chunk skips behind each generation and where its generation 0 records
-    // (zeros for a trace that is one chain): put in place when the slots were cleared or last held other values
-    const bool chunk = t->chunked || t->secondary;
-    const int64_t other = !chunk ? 0 : (t->secondary ? t->lead->n : t->n_whole - t->n);
-    const int64_t base0 = t->secondary ? t->lead->n : 0;
-    if (t->slots_skip != other || t->slots_base0 != base0) {
-      hipLaunchKernelGGL(k_chunk_setup, dim3(1), dim3(256), 0, t->st, (GenCtrl*)(w + l.gen), n_slots, base0, other);
-      t->slots_skip = other;
-      t->slots_base0 = base0;
-    }
   }
   t->ready_workspace = nullptr;
   // the generation kernels tell the host themselves unless an error can still be raised after the
@@ -530,10 +465,9 @@ static int fused_start(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
   // Hints from the previous trace of this scene with this many rays (PRT_TRACE_NO_HINTS turns them off).
   // After a miss the hints rest for 2, 4, 8 ... 64 traces (a caller that alternates between ray sets of
   // different shapes must not pay a repeat every time).
-  if (!t->secondary)
-    for (int& rest : s->hint_rest) rest -= rest > 0 ? 1 : 0;  // (counted in traces of this scene)
+  for (int& rest : s->hint_rest) rest -= rest > 0 ? 1 : 0;  // (counted in traces of this scene)
   bool allow_hints = t->allow_hints;
-  if (!t->secondary && allow_hints && s->hint_holdoff > 0) {
+  if (allow_hints && s->hint_holdoff > 0) {
     s->hint_holdoff -= 1;
     allow_hints = false;
   }
@@ -570,8 +504,7 @@ static int fused_start(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
   // tiles, every offer would be a miss and a repeat (a caller that refills one buffer with new rays is still offered
   // them -- and every tile checks)
   bool allow_tiles = t->allow_tile_hints && t->use_hints && t->publish_in_kernel && t->record_rays == t->rays &&
-                     !t->plan_active && !t->chunked && !t->secondary;  // (a chunked trace runs on dense forms only)
-  if (t->secondary) t->use_hints = t->lead->use_hints;
+                     !t->plan_active;
   if (allow_tiles && s->tile_hint_holdoff > 0) {
     s->tile_hint_holdoff -= 1;
     allow_tiles = false;
@@ -588,7 +521,6 @@ static int fused_start(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
   int want = kGenerationBatch;
   if (s->last_generations > 0) want = std::min(s->last_generations, kMaxBatch);
   t->batch = std::min(want, t->limit);
-  if (t->secondary) t->batch = t->lead->batch;
   HP(1);
   return fused_launch_batch(s, c, t);
 }
@@ -599,8 +531,6 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
   const int keep_absorbed = (t->flags & PRT_TRACE_KEEP_ABSORBED) ? 1 : 0;
   int error = 0;
   bool done = false;
-  TraceTicket* h = t->chunked ? t->lead : nullptr;  // (chunk B's ticket while this attempt is chunked)
-  GenCtrl merged[kMaxBatch + 4];
   while (true) {
     int rc = await_epoch(t, t->epoch);
     if (rc) return rc;
@@ -608,22 +538,6 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
     const GenCtrl* host_gen = t->mirror->gen;
     t->stats[3] += t->batch;
     error = t->mirror->error;
-    if (h) {
-      // a chunked trace: what the generations did is what their two chunks did together
-      rc = await_epoch(h, h->epoch);
-      if (rc) return rc;
-      h->launched = false;
-      for (int b = 0; b <= t->batch; ++b) {
-        merged[b] = t->mirror->gen[b];
-        merged[b].n_in += h->mirror->gen[b].n_in;
-        merged[b].n_live += h->mirror->gen[b].n_live;
-        merged[b].n_carry += h->mirror->gen[b].n_carry;
-      }
-      host_gen = merged;
-      if (!error) error = h->mirror->error;
-      // (a record block a chunk found too small may only have been too small for where the assumptions put its rows)
-      if (error == PRT_ERR_ROWS_CAP || error == PRT_ERR_TILE_HINT || error == PRT_ERR_STALL) error = PRT_ERR_SPECULATION;
-    }
     if (error) break;
     for (int b = 0; b < t->batch; ++b) {
       if (host_gen[b].n_in == 0) { done = true; break; }
@@ -667,16 +581,11 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
     if (!done && host_gen[t->batch].n_in == 0) done = true;
     t->g += t->batch;
     if (done || t->g >= t->limit) break;
-    if (h) { error = PRT_ERR_SPECULATION; break; }  // (rays left behind the generations the hints knew of: as one chain, anew)
     t->batch = std::min(kGenerationBatch, t->limit - t->g);
     rc = fused_launch_batch(s, c, t);
     if (rc) return rc;
   }
   t->launched = false;
-  if (h) {
-    for (bool& kept : t->tile_record) kept = false;  // (a chunked trace leaves no per-tile records of the whole ray set)
-    for (bool& kept : h->tile_record) kept = false;
-  }
   if (t->plan_active) {
     // a trace under a record plan keeps its own hints and touches none of the scene's others
     for (bool& kept : t->tile_record) kept = false;  // (the plan's launches leave no per-tile records, and reuse the slots)
@@ -744,7 +653,7 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
   if (error) return trace_error(error);
   if (!t->publish_in_kernel) t->flip = 0;  // (k_fused_reinit cleared buffer 0; the next launch cleans buffer 1)
   s->last_generations = (int)t->stats[0];
-  s->hint_n = h ? t->n_whole : t->n;
+  s->hint_n = t->n;
   s->hint_keep_absorbed = keep_absorbed;
   if (!s->missed_mode.empty()) {
     // This trace is the repeat of an attempt whose dense hints did not hold: the generations that were offered a
@@ -797,16 +706,6 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
   t->ready_n = t->n;
   t->ready_slots = t->limit + 1;
   t->ready_stall = t->test_stall;
-  if (h) {
-    for (bool& kept : t->tile_record) kept = false;
-    t->record_rays = nullptr;
-    h->ready_workspace = h->w;
-    h->ready_n = h->n;
-    h->ready_slots = h->limit + 1;
-    h->ready_stall = h->test_stall;
-    s->chunked_traces += 1;
-    t->stats[7] = PRT_VARIANT_CHUNKED;
-  }
   return t->total_rows;
 }
 
@@ -814,107 +713,6 @@ static void reset_stats(prt_scene* s, TraceTicket* t, int variant) {
   for (double& v : t->stats) v = 0;
   t->stats[6] = (double)s->lookback_fallbacks;
   t->stats[7] = variant;
-}
-
-// May this trace run as two chunks?  Only on what the scene's previous trace has shown: every generation it will launch
-// runs in a form whose rows land at places known when it is launched -- dense (1, 2), dense with its absorbed rays kept
-// (4), or, as the LAST generation, on the dead list of the one before (6) -- and the launch loop below will decide
-// exactly that (the same conditions, in the same order, as fused_launch_batch; a chunked trace offers no per-tile
-// records).  Anything else runs as one chain.
-static bool chunk_eligible(const prt_scene* s, const DeviceCopy* c, const TraceTicket* t) {
-  const int how = s->options.chunks;
-  if (how == 1 || t->plan_active || s->has_untracable) return false;
-  // (a caller that keeps several traces in flight has its overlap already: two chains fill the chip, four evict each
-  // other's states from the Infinity Cache)
-  if (how != 2)
-    for (const TraceTicket& other : c->ticket)
-      if (&other != t && other.active && other.n) return false;
-  if (t->flags & (PRT_TRACE_NO_CHUNKS | PRT_TRACE_UNFUSED | PRT_TRACE_TEST_STALL | PRT_TRACE_PUBLISH_KERNEL | PRT_TRACE_NO_HINTS |
-                  PRT_TRACE_COUNT_PATHS))
-    return false;
-  if (how == 2 ? t->n < 2 * PRT_BLOCK : (t->n < kChunkMinRays || t->n > kChunkMaxRays)) return false;
-  const int keep_absorbed = (t->flags & PRT_TRACE_KEEP_ABSORBED) ? 1 : 0;
-  if (!t->allow_hints || s->hint_holdoff > 0 || s->hint_n < 0 || s->hint_keep_absorbed != keep_absorbed) return false;
-  const int generations = s->last_generations;
-  if (generations < 1 || generations > kMaxBatch || generations > t->limit || (int)s->hint_mode.size() < generations) return false;
-  for (int g = 0; g < generations; ++g) {
-    if (g < (int)s->hint_rest.size() && s->hint_rest[g] > 1) return false;  // (rests are counted down before they are looked at)
-    const int mode = s->hint_mode[g];
-    const bool last = g + 1 == generations;
-    if (mode == 1 || mode == 2) continue;
-    if (mode == 4 && !(t->flags & PRT_TRACE_NO_SPARSE_KEEP)) continue;
-    if (mode == 6 && last && g >= 2 && s->hint_mode[g - 1] == 4 && !(t->flags & PRT_TRACE_NO_SPARSE_KEEP)) continue;
-    return false;
-  }
-  // (a generation that carries everything on is followed by another one unless the limit ends the trace)
-  if (s->hint_mode[generations - 1] != 2 && s->hint_mode[generations - 1] != 6 && generations != t->limit) return false;
-  return true;
-}
-
-// chunk B's ticket, stream and events of ticket `k` (made at first use)
-static int chunk_resources(DeviceCopy* c, int k) {
-  TraceTicket& h = c->helper[k];
-  if (!h.mirror) {
-    HIP_TRY(hipHostMalloc((void**)&h.host_pinned, 16 * sizeof(int64_t), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void**)&h.mirror, 64 + (kMaxBatch + 4) * 64, hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset((void*)h.mirror, 0, 64 + (kMaxBatch + 4) * 64);
-    HIP_TRY(hipHostGetDevicePointer((void**)&h.mirror_dev, (void*)h.mirror, 0));
-    HIP_TRY(hipEventCreate(&h.ev0));
-    HIP_TRY(hipEventCreate(&h.ev1));
-  }
-  if (!c->chunk_stream[k]) HIP_TRY(hipStreamCreateWithFlags(&c->chunk_stream[k], hipStreamNonBlocking));
-  if (!c->chunk_fork[k]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_fork[k], hipEventDisableTiming));
-  if (!c->chunk_join[k]) HIP_TRY(hipEventCreateWithFlags(&c->chunk_join[k], hipEventDisableTiming));
-  if (!c->ticket[k].mark_event) HIP_TRY(hipEventCreateWithFlags(&c->ticket[k].mark_event, hipEventDisableTiming));
-  return PRT_OK;
-}
-
-// start the ticket's trace as two chunks (see include/prt.h "Chunked traces"): chunk A on the caller's stream, chunk B on
-// the library's, forked behind whatever the caller's stream holds and joined back into it behind B's last launch
-static int chunk_start(prt_scene* s, DeviceCopy* c, TraceTicket* t, int ticket) {
-  int rc = chunk_resources(c, ticket);
-  if (rc) return rc;
-  TraceTicket* h = &c->helper[ticket];
-  const int64_t n = t->n, n_a = chunk_split(n);
-  t->n_whole = n;
-  t->n = n_a;
-  t->chunked = true;
-  t->lead = h;  // (the ticket's partner: chunk B)
-  const int generations = s->last_generations;
-  t->mark_after = s->hint_mode[generations - 1] == 6 ? generations - 2 : -1;
-  h->secondary = true;
-  h->lead = t;
-  h->link_before = t->mark_after >= 0 ? generations - 1 : -1;
-  h->rays = t->rays + n_a; h->n = n - n_a; h->ld = t->ld; h->limit = t->limit; h->ray_offset = t->ray_offset;
-  h->rows_out = t->rows_out; h->rows_cap = t->rows_cap; h->w = t->w + chunk_b_offset(n);
-  h->flags = t->flags | PRT_TRACE_NO_TIMING;
-  h->st = c->chunk_stream[ticket];
-  h->launched = false;
-  h->allow_hints = t->allow_hints; h->allow_tile_hints = false; h->compact = t->compact;
-  h->busy0 = h->busy1 = nullptr;
-  h->plan_active = false;
-  reset_stats(s, h, PRT_VARIANT_FUSED);
-  HIP_TRY(hipEventRecord(c->chunk_fork[ticket], t->st));
-  HIP_TRY(hipStreamWaitEvent(h->st, c->chunk_fork[ticket], 0));
-  rc = fused_start(s, c, t);
-  if (rc) return rc;
-  rc = fused_start(s, c, h);
-  if (rc) return rc;
-  HIP_TRY(hipEventRecord(c->chunk_join[ticket], h->st));
-  HIP_TRY(hipStreamWaitEvent(t->st, c->chunk_join[ticket], 0));
-  // (the trace's own event pairs end behind the join: both chunks are inside)
-  if (!(t->flags & PRT_TRACE_NO_TIMING)) HIP_TRY(hipEventRecord(t->ev1, t->st));
-  if (t->busy1) HIP_TRY(hipEventRecord(t->busy1, t->st));
-  return PRT_OK;
-}
-
-// back to one chain (a chunked attempt is over, or is about to be repeated)
-static void chunk_end(TraceTicket* t) {
-  if (!t->chunked) return;
-  t->n = t->n_whole;
-  t->chunked = false;
-  t->lead = nullptr;
-  t->mark_after = -1;
 }
 
 extern "C" int prt_trace_begin(prt_scene* s, int device, int ticket, const double* rays, int64_t n, int64_t ld,
@@ -970,9 +768,8 @@ extern "C" int prt_trace_begin(prt_scene* s, int device, int ticket, const doubl
     return PRT_OK;
   }
   reset_stats(s, t, PRT_VARIANT_FUSED);
-  t->chunked = false;
-  rc = chunk_eligible(s, c, t) ? chunk_start(s, c, t, ticket) : fused_start(s, c, t);
-  if (rc) { chunk_end(t); t->active = false; }
+  rc = fused_start(s, c, t);
+  if (rc) t->active = false;
   return rc;
 }
 
@@ -999,7 +796,6 @@ extern "C" int64_t prt_trace_end(prt_scene* s, int device, int ticket, int64_t* 
   } else {
     for (int attempt = 0;; ++attempt) {
       rc64 = fused_finish(s, c, t, rows_per_generation);
-      chunk_end(t);  // (whatever follows -- a repeat, the rows' consumers -- sees the whole trace; the caller's stream is joined)
       if ((rc64 != PRT_ERR_SPECULATION && rc64 != PRT_ERR_FULL_ROWS && rc64 != PRT_ERR_TILE_HINT) || attempt == 4) break;
       if (rc64 == PRT_ERR_TILE_HINT) {
         // a generation found other counts in a tile than its last run left on record (other rays, or a scene

@@ -36,7 +36,6 @@ TRACE_NO_TIMING = 256
 TRACE_NO_TILE_RECORDS = 512
 TRACE_NO_SPARSE_KEEP = 1024
 TRACE_BUSY = 2048
-TRACE_NO_CHUNKS = 4096
 TRACE_TICKETS = 4
 
 # prt_scene_options (include/prt.h): how a scene is compiled / which nearest-hit kernel serves
@@ -46,7 +45,7 @@ TRACE_TICKETS = 4
 OPTIONS_DTYPE = np.dtype(
     [("struct_size", "<i4"), ("no_chain", "<i4"), ("no_cull", "<i4"), ("cull_min", "<i4"), ("no_groups", "<i4"),
      ("no_implied", "<i4"), ("hit_lanes", "<i4"), ("hit_staged", "<i4"), ("list_order_groups", "<i4"),
-     ("one_direction", "<i4"), ("no_intervals", "<i4"), ("no_clearance", "<i4"), ("chunks", "<i4"), ("reserved", "<i4", (3,))])
+     ("one_direction", "<i4"), ("no_intervals", "<i4"), ("no_clearance", "<i4"), ("reserved", "<i4", (4,))])
 assert OPTIONS_DTYPE.itemsize == 64
 OPTION_NAMES = tuple(name for name in OPTIONS_DTYPE.names if name not in ("struct_size", "reserved"))
 DEFAULT_OPTIONS = {}
