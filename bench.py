@@ -697,17 +697,11 @@ def main():
                                                                   how="sync" if mode == "sync" else "one_stream"),
                          args.side_steps)
     side_resized = side("changing ray count", resized_steps, args.side_steps)
-    # (d) with the dense-mode hints but without the per-tile records of the previous trace (PRT_TRACE_NO_TILE_RECORDS):
-    #     what a trace sees whose rays are lost in other places than last time's -- after the one repeat that finds out
-    side_no_records = side("no tile records", lambda c, t=None: run_steps(
-        c, t, flags=args.flags | engine.TRACE_NO_TILE_RECORDS, how="sync" if mode == "sync" else "one_stream"), args.side_steps)
-    side_no_records_overlap = side("no tile records, overlapped", lambda c, t=None: run_steps(
-        c, t, flags=args.flags | engine.TRACE_NO_TILE_RECORDS), args.side_steps) if mode == "overlap" else None
     # ... and (b) once more issued like the timed region, so that there is a figure to put next to `value`
     side_no_hints_overlap = side("no hints, overlapped", lambda c, t=None: run_steps(
         c, t, flags=args.flags | engine.TRACE_NO_HINTS), args.side_steps) if mode == "overlap" else None
     # (e) the round-3 headline form: the SAME ray set traced again and again, issued like the timed region -- dense
-    #     hints and per-tile records of the previous trace active, the input possibly still in the Infinity Cache
+    #     hints of the previous trace active, the input possibly still in the Infinity Cache
     side_replay = side("replay", lambda c, t=None: run_steps(c, t, rotate=False), args.side_steps) \
         if len(ray_sets) > 1 else None
     # (f) a fresh scene's first trace: scene compilation, table upload, control-word initialisation, no hints
@@ -1023,10 +1017,9 @@ def main():
                         f", generation_limit {limit}, rays resident in HBM; " +
                         (f"the timed steps rotate through {len(ray_sets)} distinct seeded ray sets (seeds {base_seed + seed_shift} ... "
                          f"{base_seed + seed_shift + len(ray_sets) - 1}): no step re-traces its predecessor's rays; the dense-mode hints "
-                         "of the scene's previous trace apply (they are checked per tile), its per-tile compaction records do not"
+                         "of the scene's previous trace apply (they are checked per tile)"
                          if len(ray_sets) > 1 else
-                         "the timed step is a REPEATED IDENTICAL trace: dense-mode hints and per-tile records of the previous "
-                         "trace active, first batch sized by it") +
+                         "the timed step is a REPEATED IDENTICAL trace: dense-mode hints of the previous trace active, first batch sized by it") +
                         {"overlap": f", {depth} traces in flight on {depth} HIP streams (prt_trace_batch = prt_trace_begin / prt_trace_end per trace): the "
                                     "host enqueues ahead and the kernels of different traces overlap on the device",
                          "one_stream": ", one trace kept in flight on the same stream while the previous one's counts are "
@@ -1052,8 +1045,8 @@ def main():
             "trace_flags": args.flags,
             "scene_options": scene_options,
             "spinup_steps_untimed": spinup_steps,
-            # repeats the library made on its own since the scene was created (a missed dense hint, a per-tile record
-            # that did not hold, the look-back fallback): each is a trace run twice
+            # repeats the library made on its own since the scene was created (a dense hint that did not hold, the
+            # look-back fallback): each is a trace run twice
             "telemetry": scene.telemetry(),
             "parallelism": f"ray data-parallel x{world} (contiguous id shards), no collective in the timed region",
         },
@@ -1135,14 +1128,6 @@ def main():
         return kind
 
     side_sync, side_no_hints, side_resized = publish(side_sync), publish(side_no_hints), publish(side_resized)
-    side_no_records = publish(side_no_records)
-    if side_no_records:
-        line["value_no_tile_records_one_stream"] = side_no_records["rows_per_s_this_gpu"] * world
-        line["roofline"]["no_tile_records"] = {k: side_no_records[k] for k in ("avg_launch_ms", "frac", "kernel_ms_per_step",
-                                                                               "launches_per_step", "ms_per_step")}
-    if side_no_records_overlap:
-        side_no_records_overlap.pop("_bytes"), side_no_records_overlap.pop("_kernel_ms")
-        line["value_no_tile_records"] = side_no_records_overlap["rows_per_s_this_gpu"] * world  # issued like `value`
     line["verified"] = verified
     line["verification"] = verify_note
     if side_replay:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PRT_VERSION 220 /* 0.2.2: record plans (prt_record_plan, prt_trace_set_plan, prt_sink_bytes). 0.2.1: prt_frame_mean_square, PRT_TRACE_BUSY / prt_trace_batch_busy, prt_comm_info.  0.2.0: prt_interact takes the caller-shaded state, PRT_MAT_TABLE / PRT_MAT_HOST,
+#define PRT_VERSION 220 /* 0.2.2: record plans (prt_record_plan, prt_trace_set_plan); per-tile records retired (PRT_TRACE_NO_TILE_RECORDS ignored, telemetry slots 8 / 9 count plan launches / misses). 0.2.1: prt_frame_mean_square, PRT_TRACE_BUSY / prt_trace_batch_busy, prt_comm_info.  0.2.0: prt_interact takes the caller-shaded state, PRT_MAT_TABLE / PRT_MAT_HOST,
                            prt_scene_set_index_tables, prt_gather_hits / prt_scatter_shaded, prt_unique_values,
                            prt_frame_stats_sharded / prt_frame_pivots / prt_frame_finish, prt_trace_telemetry fills 12 slots.  A caller built against another version must not load this library:
                            prt_version() is there to be compared with this constant (pyrayt_amd.engine.library does). */
@@ -327,8 +327,8 @@ int prt_generate_rays(int device, const prt_source* source, int64_t n_total, int
 #define PRT_TRACE_NO_TIMING 256   /* do not bracket the generation launches with HIP events (prt_trace_stats then
                                      reports 0 ms of kernel time): two event records and one event query less per
                                      trace, which is most of what a 125k-ray trace costs the host */
-#define PRT_TRACE_NO_TILE_RECORDS 512 /* do not run compacting generations on the per-tile records of the ticket's
-                                     previous trace (they then run their look-back, as in a first trace); A/B, tests */
+/* (512 was PRT_TRACE_NO_TILE_RECORDS: the per-tile records were retired in 0.2.2 -- worth under 2 % wherever they applied
+ * once the sparse-loss forms existed, profiles/r6/ab_round6.txt; the bit is ignored) */
 #define PRT_TRACE_BUSY 2048         /* prt_trace_batch only: bracket every job's launches with a pair of HIP events of its own (on the job's stream) and merge the intervals behind the batch: prt_trace_batch_busy */
 #define PRT_TRACE_NO_SPARSE_KEEP 1024 /* do not launch sparse-loss generations dense with their absorbed rays kept
                                      (see prt_trace_telemetry); A/B, tests */
@@ -547,8 +547,9 @@ int prt_trace_stats(const prt_scene* scene, double* out8);
  * and from the traces run with PRT_TRACE_COUNT_PATHS: how many such traces, ray-generations whose ray was
  * not well formed (see "shortcuts" in DESIGN.md: such a ray takes none), CSG node evaluations with
  * survivors under an implied cull box, ... of which evaluated upstream's box test exactly;
- * generation launches made on per-tile records, traces repeated because a record did not hold,
- * dense-mode launches that kept their absorbed rays (sparse loss, below), 0 }.
+ * generation launches made under a record plan, traces under a plan repeated because one of the plan's own dense
+ * hints did not hold (slots 8 and 9 counted the per-tile records of 0.2.0-0.2.1, retired in 0.2.2),
+ * dense-mode launches that kept their absorbed rays (sparse loss, below), launches under a plan that ran dense }.
  * Dense mode: a generation in which the previous trace of the same scene (whatever its ray count)
  * recorded every ray and carried all or none of them on is launched on the assumption that it will
  * again -- every tile then knows its output position without the look-back; each tile checks the
@@ -559,17 +560,9 @@ int prt_trace_stats(const prt_scene* scene, double* out8);
  * direction zeroed, the way upstream carries them (_pyrayt.py:415-428), and the next generation -- which
  * compacts -- finds them dead, records nothing for them and drops them.  The rows are the same; what is saved is
  * the look-back of a generation whose few odd rays make their tiles the slowest ones, so that every tile waited
- * for a straggler (PRT_TRACE_NO_SPARSE_KEEP turns it off for a call; a trace of the same ray buffer as the
- * ticket's last prefers the per-tile record).  Such a launch notes, per tile, how many rays it kept (a dead list
+ * for a straggler (PRT_TRACE_NO_SPARSE_KEEP turns it off for a call).  Such a launch notes, per tile, how many rays it kept (a dead list
  * in the workspace), and the generation behind it -- if it loses no ray of its own -- is launched on that list:
  * its tiles' positions are "tile index x tile size minus the dead rays in front", again without a look-back.
- * Per-tile records: a generation that does lose rays leaves, for every tile, where the tile's rows and carried
- * rays went and how many it had, in the workspace.  The next trace of the same ticket with the same workspace
- * and ray count runs that generation on the record instead of a look-back; every tile checks its own counts
- * against it, and a tile that finds other counts makes the library repeat the trace without the records
- * (exact either way; they rest after a miss like the dense hints; PRT_TRACE_NO_TILE_RECORDS / NO_HINTS turn
- * them off for a call).  They pay for traces whose rays are lost in the same places as last time -- a repeated
- * trace, a design loop that moves a part the vignetted rays do not depend on.
  * Compact state: between the generations of a trace the ray state goes without its rows 3, 7 and 8
  * (origin w, direction w, generation): in a ray set that starts like RaySet's defaults
  * (pyrayt/_pyrayt.py:29-36: w = 1 / 0, generation 0) they hold 1, +0 and the generation's number in every

@@ -77,12 +77,6 @@ struct TraceTicket {
   int64_t ready_n = -1;
   int ready_slots = 0, ready_stall = 0;
   int flip = 0;  // which of the two tile-status buffers the next generation launch works on
-  // generations whose per-tile record (TileHint, prt_kernels.hip) in this ticket's workspace is that of the
-  // ticket's last successful trace -- with ready_workspace / ready_n they say when `assume == 3` may be offered
-  bool tile_record[16] = {false};
-  const double* record_rays = nullptr;  // the ray buffer of the trace those records are from
-  bool allow_tile_hints = true, use_tile_records = false, used_tile_hints = false;
-  bool records_off = false;  // this attempt: the records of the generations still to come were taken on other rays (see launch_mode 4)
   unsigned long long user = 0;  // identity of this ticket in the workspace registry (0: not drawn yet)
   unsigned long long update_seen = 0;   // the scene update this ticket's stream has waited for ...
   hipStream_t update_seen_stream = nullptr;  // ... and which stream that was
@@ -140,8 +134,6 @@ struct prt_scene {
   unsigned long long plan_hint_key = 0;
   int plan_hint_rest = 0, plan_hint_misses_in_a_row = 0;
   long long plan_launches = 0, plan_dense_launches = 0, plan_misses = 0, plan_traces = 0;
-  int tile_hint_holdoff = 0, tile_hint_misses_in_a_row = 0;  // per-tile records rest after a miss like the dense hints do
-  long long tile_hint_launches = 0, tile_hint_misses = 0;
   bool has_untracable = false;                  // a shading error can be raised at store time (a surface without a
                                                 // traceable material, a caller-shaded one, a table glass that may miss
                                                 // a wavelength): such traces publish behind the batch (k_fused_reinit)

@@ -442,13 +442,6 @@ struct GenCtrl {
   uint32_t pad[8];
 };
 static_assert(sizeof(GenCtrl) == 64, "host_gen sizing");
-// Per-tile record of a generation that compacted (look-back): where the tile's rows and carried rays went and how
-// many it had.  The next trace of this ticket with this workspace may run that generation on the record instead
-// of a look-back (assume == 3): every tile checks its own counts against it, exactly as dense mode checks "all".
-// The records of the first kTileHintGenerations generations sit at a fixed distance behind the generation slots
-// (no kernel argument of their own: the generation kernel has no register to spare for one).
-struct TileHint { unsigned excl_live, excl_carry, live, carry; };
-static const int kTileHintGenerations = 16;
 // Dead lists: a generation launched dense with its absorbed rays kept (hint mode 4) notes, per tile that kept any,
 // (tile << 9 | how many); the generation behind it, launched on that list (assume 5 / 6), takes its tiles' offsets
 // from "tile index x tile size minus the dead rays in front" -- no look-back for a handful of dead rays.  Three
@@ -458,12 +451,8 @@ struct DeadList { unsigned count, pad[3], entry[kDeadListCap]; };
 static_assert(sizeof(DeadList) == 4096, "dead list sizing");
 static const size_t kDeadListOffset =
     ((size_t)(kMaxGenerationSlots + 2) * sizeof(GenCtrl) + 255) / 256 * 256 - sizeof(GenCtrl);  // from gen[0], see trace_layout
-static const size_t kTileHintOffset = kDeadListOffset + 3 * sizeof(DeadList);
 __device__ __forceinline__ DeadList* dead_list(GenCtrl* gen, int g) {
   return reinterpret_cast<DeadList*>(reinterpret_cast<char*>(gen) + kDeadListOffset) + (g % 3);
-}
-__device__ __forceinline__ TileHint* tile_hints(GenCtrl* gen, int g) {
-  return reinterpret_cast<TileHint*>(reinterpret_cast<char*>(gen) + kTileHintOffset) + (size_t)g * gridDim.x;
 }
 struct FusedCtrl {
   int32_t error;
@@ -511,7 +500,6 @@ typedef const __attribute__((address_space(4))) PlanDev* ConstPlan;
 
 #define PRT_ERR_SPECULATION (-101) /* internal: a generation launched in dense mode was not dense -> host re-runs without hints */
 #define PRT_ERR_STALL (-100) /* internal: look-back gave up -> host falls back to the unfused path */
-#define PRT_ERR_TILE_HINT (-103) /* internal: a generation launched on the per-tile record of its last run found other counts -> host re-runs without the records */
 #define PRT_ERR_FULL_ROWS (-102) /* internal: a ray set needs the rows the compact form leaves out -> host re-runs with all 13 */
 
 // Raising an error on the device.  The verdicts that make the host repeat the trace (SPECULATION, STALL,
@@ -1075,11 +1063,9 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   // the generation that ends the batch (known at launch in this mode) also tells the host: its tiles
   // check in on counters kept in the otherwise unused status buffer (cleared by the next generation like
   // any status word), and the last one to arrive publishes, with every tile's verdict visible to it
-  // (assume == 3: whether the generation ends the trace is in the previous trace's totals, still in its slot)
   const bool publish_here = assume && mirror != nullptr &&
                             (PLAN ? (carry_form == 2 || batch_last)
-                                  : (assume == 2 || assume == 6 || batch_last ||
-                                     (assume == 3 && (gen[g].n_live == 0 || gen[g].n_carry == 0))));
+                                  : (assume == 2 || assume == 6 || batch_last));
   if (assume) {
     if (threadIdx.x == 0) {
       const int64_t mine = (n - (int64_t)tile * PRT_BLOCK) < PRT_BLOCK ? (n - (int64_t)tile * PRT_BLOCK) : PRT_BLOCK;
@@ -1098,14 +1084,8 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
         const unsigned at = atomicAdd(&dead->count, 1u);
         if (at < (unsigned)kDeadListCap) dead->entry[at] = ((unsigned)tile << 9) | agg_kept;
       }
-      if (!PLAN && assume == 3) {  // the previous trace's record of this tile
-        const TileHint h = tile_hints(gen, g)[tile];
-        holds = agg_live == h.live && agg_carry == h.carry && n == *reinterpret_cast<const int64_t*>(gen[g].pad);
-        s_excl[0] = h.excl_live;
-        s_excl[1] = h.excl_carry;
-      }
       if (!holds && !failed)  // in place before this tile checks in below
-        raise_verdict(&ctrl->error, assume == 3 ? PRT_ERR_TILE_HINT : PRT_ERR_SPECULATION);
+        raise_verdict(&ctrl->error, PRT_ERR_SPECULATION);
       finisher = tile == 0;
       if (publish_here) {
         // Two levels (64 tiles to a counter, the last of each on to the root): thousands of increments of
@@ -1144,7 +1124,7 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   STAMP(5);
   const int64_t last_tile = (n - 1) / PRT_BLOCK;
   int64_t excl_live, excl_carry;
-  if (!PLAN && (assume == 3 || assume >= 5)) {
+  if (!PLAN && assume >= 5) {
     __syncthreads();
     excl_live = s_excl[0];
     excl_carry = s_excl[1];
@@ -1158,27 +1138,21 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
     // test hook: pretend the spin expired (such traces publish through k_fused_reinit behind the batch)
     if (ctrl->pad == 1 && tile == 3 && lane == 0) raise_verdict(&ctrl->error, PRT_ERR_STALL);
     (void)ok;
-    if (lane == 0) {
-      s_excl[0] = e_live; s_excl[1] = e_carry;
-      if (!PLAN && g < kTileHintGenerations) tile_hints(gen, g)[tile] = TileHint{e_live, e_carry, agg_live, agg_carry};
-    }
+    if (lane == 0) { s_excl[0] = e_live; s_excl[1] = e_carry; }
   }
   __syncthreads();
   excl_live = s_excl[0];
   excl_carry = s_excl[1];
   finisher = tile == last_tile;
-  if (finisher && threadIdx.x == 0) *reinterpret_cast<int64_t*>(gen[g].pad) = n;  // the ray count the tile records belong to
   }
   STAMP(6);
 
   if (finisher && threadIdx.x == 0) {  // totals are known here: hand over to g + 1
     // (dense mode: the totals are the assumption itself; if it failed the error word says so)
-    // (assume == 3: the totals of the previous trace's generation g are still in its slot)
     // (assume 5 / 6: every ray but the dead ones of the list)
     const int64_t total_live = PLAN ? (assume ? (rec_none ? 0 : n) : excl_live + agg_live)
-                               : assume == 3 ? gen[g].n_live : assume >= 5 ? n - (int64_t)s_excl[2] : assume ? n : excl_live + agg_live;
+                               : assume >= 5 ? n - (int64_t)s_excl[2] : assume ? n : excl_live + agg_live;
     const int64_t total_carry = PLAN ? (assume ? (carry_form == 1 ? n : 0) : excl_carry + agg_carry)
-                                : assume == 3 ? gen[g].n_carry
                                 : assume ? (assume == 1 ? n : assume == 5 ? n - (int64_t)s_excl[2] : 0) : excl_carry + agg_carry;
     // (the rays that go on are among those that were alive: no row recorded means no ray carried -- unless a plan
     // stores no row for rays that live on)

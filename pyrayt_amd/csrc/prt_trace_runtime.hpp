@@ -9,7 +9,7 @@
 //   | block counts | block offsets | hit_t (n f64) | hit_prim (n i32)      [unfused path only]
 //   | ray buffer A (13 n) | ray buffer B (13 n)
 struct TraceLayout {
-  size_t ctrl, fctrl, gen, dead_lists, tile_hints, gen_rows, tiles_a, tiles_b, counts, offsets, hit_t, hit_prim, rays_a,
+  size_t ctrl, fctrl, gen, dead_lists, gen_rows, tiles_a, tiles_b, counts, offsets, hit_t, hit_prim, rays_a,
       rays_b, total;
 };
 static TraceLayout trace_layout(int64_t n) {
@@ -24,7 +24,6 @@ static TraceLayout trace_layout(int64_t n) {
   l.fctrl = take(sizeof(GenCtrl) + (kMaxGenerationSlots + 1) * sizeof(GenCtrl));
   l.gen = l.fctrl + sizeof(GenCtrl);
   l.dead_lists = take(3 * sizeof(DeadList));                                   // (at kDeadListOffset from gen[0]: dead_list())
-  l.tile_hints = take((size_t)kTileHintGenerations * nb * sizeof(TileHint));  // (at kTileHintOffset from gen[0]: tile_hints())
   l.gen_rows = take(kMaxGenerationSlots * sizeof(int64_t));
   l.tiles_a = take(nb * sizeof(unsigned long long));
   l.tiles_b = take(nb * sizeof(unsigned long long));
@@ -35,7 +34,7 @@ static TraceLayout trace_layout(int64_t n) {
   l.rays_a = take(nn * PRT_RAY_ROWS * sizeof(double));
   l.rays_b = take(nn * PRT_RAY_ROWS * sizeof(double));
   l.total = at;
-  if (l.tile_hints - l.gen != kTileHintOffset || l.dead_lists - l.gen != kDeadListOffset) abort();  // (the kernel finds them by these constants)
+  if (l.dead_lists - l.gen != kDeadListOffset) abort();  // (the kernel finds them by this constant)
   return l;
 }
 
@@ -360,11 +359,6 @@ static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
     if (t->use_hints && gg < (int)s->hint_mode.size()) assume = s->hint_mode[gg];
     // (a generation whose dense hint was refuted lately keeps compacting for a while: see hint_rest)
     if (assume && gg < (int)s->hint_rest.size() && s->hint_rest[gg] > 0) assume = 0;
-    // a generation that compacts on the per-tile record its last run left in this workspace (exact, and it leaves
-    // nothing behind: preferred to mode 4 below when the trace is of the same ray buffer again)
-    const bool on_record = (assume == 0 || assume == 4) && t->use_tile_records && !t->records_off &&
-                           gg < kTileHintGenerations && t->tile_record[gg];
-    const bool kept_then = t->launch_mode[gg] == 4;  // in the ticket's last trace (meaningful where it left records)
     // Mode 4 (sparse loss): last time every ray of this generation was recorded and all but a few of them -- absorbed
     // ones -- were carried on.  Compacting those few away costs every tile a look-back, and the tiles that hold such a
     // ray are as a rule the slow ones (a ray that misses the part it was expected to hit visits the parts behind it):
@@ -374,10 +368,7 @@ static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
     // the next generation finds them dead on arrival, records nothing for them and drops them when it compacts.
     int keep = keep_absorbed;
     if (assume == 4) {
-      // (a trace of the ticket's last ray buffer without a record of this generation -- it ran dense last time --
-      // compacts once to leave one: from then on such traces run on records, which leave the next generation alone)
-      const bool wants_record = t->use_tile_records && gg < kTileHintGenerations;
-      if (on_record || wants_record || (t->flags & PRT_TRACE_NO_SPARSE_KEEP)) assume = 0;
+      if (t->flags & PRT_TRACE_NO_SPARSE_KEEP) assume = 0;
       else { assume = 1; keep = 1; }
     }
     // Modes 5 / 6: the generation behind one that keeps its absorbed rays and loses none of its own (5: carries the
@@ -390,17 +381,8 @@ static int fused_launch_batch(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
       else if (gg == 1) assume = 0;
     }
     t->launch_mode[gg] = (char)(keep && !keep_absorbed ? 4 : assume);
-    // (a generation that keeps its absorbed rays this time and did not last time, or the other way round, hands the
-    // generations behind it other rays than their records were taken on)
-    if ((t->launch_mode[gg] == 4) != kept_then) t->records_off = true;
     s->dense_launches += assume ? 1 : 0;
     s->sparse_keep_launches += keep && !keep_absorbed ? 1 : 0;
-    if (on_record && assume == 0) {
-      assume = 3;
-      t->launch_mode[gg] = 3;
-      t->used_tile_hints = true;
-      s->tile_hint_launches += 1;
-    }
     // launches, not generations, alternate between the two status buffers, across traces too: every
     // launch works on the one the launch before it left clean and cleans the other (k_generation)
     hipLaunchKernelGGL(kernel, dim3(blocks_for(n)), dim3(PRT_BLOCK), lds, st, sd, src, src_ld, buf[gg & 1], n,
@@ -455,7 +437,6 @@ static int fused_start(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
     hipLaunchKernelGGL(k_fused_init, dim3(64), dim3(256), 0, t->st, (FusedCtrl*)(w + l.fctrl), (GenCtrl*)(w + l.gen),
                        n_slots, (unsigned long long*)(w + l.tiles_a), (int64_t)blocks_for(n), n, t->test_stall);
     t->flip = 0;
-    for (bool& kept : t->tile_record) kept = false;  // (the slots the records are checked against are cleared)
   }
   t->ready_workspace = nullptr;
   // the generation kernels tell the host themselves unless an error can still be raised after the
@@ -497,21 +478,6 @@ static int fused_start(prt_scene* s, DeviceCopy* c, TraceTicket* t) {
     t->use_hints = plan_hints;
     allow_hints = false;  // (no per-tile records, no dead lists under a plan)
   }
-  // The per-tile records of this ticket's last trace (TileHint) serve the generations that compact: offered with
-  // the other hints, to a trace that publishes from its kernels (the slots the records lean on are then never
-  // cleared between traces), and rested after a miss like them.
-  // ... and only to a trace of the very buffer the records were taken from: another ray set loses its rays in other
-  // tiles, every offer would be a miss and a repeat (a caller that refills one buffer with new rays is still offered
-  // them -- and every tile checks)
-  bool allow_tiles = t->allow_tile_hints && t->use_hints && t->publish_in_kernel && t->record_rays == t->rays &&
-                     !t->plan_active;
-  if (allow_tiles && s->tile_hint_holdoff > 0) {
-    s->tile_hint_holdoff -= 1;
-    allow_tiles = false;
-  }
-  t->use_tile_records = allow_tiles;
-  t->records_off = false;
-  t->used_tile_hints = false;
   t->g = 0;
   t->n_seen = 0;
   t->total_rows = 0;
@@ -588,7 +554,6 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
   t->launched = false;
   if (t->plan_active) {
     // a trace under a record plan keeps its own hints and touches none of the scene's others
-    for (bool& kept : t->tile_record) kept = false;  // (the plan's launches leave no per-tile records, and reuse the slots)
     if (error == PRT_ERR_SPECULATION || error == PRT_ERR_FULL_ROWS) return error;
     if (error == PRT_ERR_ROWS_CAP && t->use_hints) return PRT_ERR_SPECULATION;  // (too small for the hint, perhaps not for the rows)
     if (error == PRT_ERR_STALL) return PRT_ERR_STALL;
@@ -602,10 +567,8 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
     t->ready_n = t->n;
     t->ready_slots = t->limit + 1;
     t->ready_stall = t->test_stall;
-    t->record_rays = nullptr;
     return t->total_rows;
   }
-  if (error) for (bool& kept : t->tile_record) kept = false;  // (whatever the attempt overwrote before it failed)
   if (!error) {
     // Which generations keep their absorbed rays next time (mode 4, see the launch loop).  It moves the compaction to
     // the generation behind: free when that one compacts anyway, worth it when the loss is dense enough for its
@@ -644,10 +607,9 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
       t->seen_mode[g] = mode;
     }
   }
-  if (error == PRT_ERR_SPECULATION || error == PRT_ERR_FULL_ROWS || error == PRT_ERR_TILE_HINT) return error;
+  if (error == PRT_ERR_SPECULATION || error == PRT_ERR_FULL_ROWS) return error;
   // a record block that looked too small to a generation launched on a hint may only have been too small
   // for the hint: the caller repeats without hints before it reports it
-  if (error == PRT_ERR_ROWS_CAP && t->used_tile_hints) return PRT_ERR_TILE_HINT;
   if (error == PRT_ERR_ROWS_CAP && t->use_hints) return PRT_ERR_SPECULATION;
   if (error == PRT_ERR_STALL) return PRT_ERR_STALL;
   if (error) return trace_error(error);
@@ -693,14 +655,6 @@ static int64_t fused_finish(prt_scene* s, DeviceCopy* c, TraceTicket* t, int64_t
   }
   s->hint_mode.assign(t->seen_mode, t->seen_mode + t->n_seen);
   if (t->use_hints) s->hint_misses_in_a_row = 0;
-  if (t->used_tile_hints) s->tile_hint_misses_in_a_row = 0;
-  // which generations left (or confirmed) a per-tile record in this workspace: those that compacted
-  // (a trace that published through k_fused_reinit had its generation slots -- the ray count and totals the records
-  // are checked against -- cleared behind it: its records are not offered)
-  for (int g = 0; g < kTileHintGenerations; ++g)
-    t->tile_record[g] = t->publish_in_kernel && g < t->n_seen && (t->launch_mode[g] == 0 || t->launch_mode[g] == 3) &&
-                        (t->seen_mode[g] == 0 || t->seen_mode[g] == 4);
-  t->record_rays = t->rays;
   // the control words are as a next trace of this shape needs them (see the launch loop)
   t->ready_workspace = t->w;
   t->ready_n = t->n;
@@ -747,7 +701,6 @@ extern "C" int prt_trace_begin(prt_scene* s, int device, int ticket, const doubl
   t->traced = true;
   t->launched = false;
   t->allow_hints = !(flags & PRT_TRACE_NO_HINTS);
-  t->allow_tile_hints = t->allow_hints && !(flags & PRT_TRACE_NO_TILE_RECORDS);
   t->compact = !s->full_rows && !(flags & PRT_TRACE_FULL_ROWS);
   t->active = true;
   if (n == 0 || generation_limit == 0) { reset_stats(s, t, PRT_VARIANT_FUSED); return PRT_OK; }
@@ -796,15 +749,8 @@ extern "C" int64_t prt_trace_end(prt_scene* s, int device, int ticket, int64_t* 
   } else {
     for (int attempt = 0;; ++attempt) {
       rc64 = fused_finish(s, c, t, rows_per_generation);
-      if ((rc64 != PRT_ERR_SPECULATION && rc64 != PRT_ERR_FULL_ROWS && rc64 != PRT_ERR_TILE_HINT) || attempt == 4) break;
-      if (rc64 == PRT_ERR_TILE_HINT) {
-        // a generation found other counts in a tile than its last run left on record (other rays, or a scene
-        // that treats them differently): again without the records -- the dense hints stay, they were not refuted
-        s->tile_hint_misses += 1;
-        s->tile_hint_misses_in_a_row = std::min(s->tile_hint_misses_in_a_row + 1, 6);
-        s->tile_hint_holdoff = 1 << s->tile_hint_misses_in_a_row;
-        t->allow_tile_hints = false;
-      } else if (rc64 == PRT_ERR_SPECULATION && t->plan_active) {
+      if ((rc64 != PRT_ERR_SPECULATION && rc64 != PRT_ERR_FULL_ROWS) || attempt == 4) break;
+      if (rc64 == PRT_ERR_SPECULATION && t->plan_active) {
         // (the plan's own hints: forgotten, learnt again from the repeat, rested 2, 4 .. 64 traces after misses in a row)
         s->plan_misses += 1;
         s->plan_hint_misses_in_a_row = std::min(s->plan_hint_misses_in_a_row + 1, 6);
@@ -834,7 +780,7 @@ extern "C" int64_t prt_trace_end(prt_scene* s, int device, int ticket, int64_t* 
       rc = fused_start(s, c, t);
       if (rc) return rc;
     }
-    if (rc64 == PRT_ERR_SPECULATION || rc64 == PRT_ERR_FULL_ROWS || rc64 == PRT_ERR_TILE_HINT)
+    if (rc64 == PRT_ERR_SPECULATION || rc64 == PRT_ERR_FULL_ROWS)
       rc64 = fail(PRT_ERR_HIP, "trace kept failing its own assumptions");
     if (rc64 == PRT_ERR_STALL && t->plan_active)
       rc64 = fail(PRT_ERR_HIP, "the look-back of a trace under a record plan gave up (no three-kernel path under a plan)");
@@ -971,8 +917,8 @@ extern "C" int prt_trace_batch_busy(const prt_scene* s, int device, double* out4
 extern "C" int prt_trace_telemetry(const prt_scene* s, int64_t* out12) {
   int64_t* out8 = out12;
   if (!s || !out8) return fail(PRT_ERR_ARG, "null argument");
-  out12[8] = s->tile_hint_launches;
-  out12[9] = s->tile_hint_misses;
+  out12[8] = s->plan_launches;  // generation launches under a record plan (slots 8 / 9 counted the per-tile records retired in round 6)
+  out12[9] = s->plan_misses;    // traces under a plan repeated because one of the plan's dense hints did not hold
   out12[10] = s->sparse_keep_launches;
   out12[11] = s->plan_dense_launches;  // generation launches under a record plan that ran dense
   out8[0] = s->lookback_fallbacks;

@@ -33,7 +33,6 @@ TRACE_TEST_STALL = 32
 TRACE_SYNC = 64
 TRACE_COUNT_PATHS = 128
 TRACE_NO_TIMING = 256
-TRACE_NO_TILE_RECORDS = 512
 TRACE_NO_SPARSE_KEEP = 1024
 TRACE_BUSY = 2048
 TRACE_TICKETS = 4
@@ -795,7 +794,7 @@ class DeviceScene:
         _check(library().prt_trace_telemetry(self.handle, out))
         keys = ("lookback_fallbacks", "speculation_misses", "dense_launches", "full_rows_fallbacks",
                 "counted_traces", "rays_not_well_formed", "implied_box_nodes", "exact_box_tests",
-                "tile_record_launches", "tile_record_misses", "sparse_keep_launches", "plan_dense_launches")
+                "plan_launches", "plan_misses", "sparse_keep_launches", "plan_dense_launches")
         return dict(zip(keys, (int(v) for v in out)))
 
     # --- per-state entry points -----------------------------------------------------------------

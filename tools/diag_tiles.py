@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Which launches of a repeated trace run dense / on tile records / with a look-back, and what each trace costs:
+"""Which launches of a repeated trace run dense / with their absorbed rays kept / with a look-back, and what each trace costs:
     python tools/diag_tiles.py [workload] [rays] [traces] [fresh|same] [flags]"""
 import os
 import sys
@@ -16,12 +16,12 @@ from pyrayt_amd.scene import SceneSnapshot
 workload = sys.argv[1] if len(sys.argv) > 1 else "config3"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4_000_000
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-fresh = len(sys.argv) > 4 and sys.argv[4] == "fresh"  # every trace from another buffer (same rays): no per-tile records
+fresh = len(sys.argv) > 4 and sys.argv[4] == "fresh"  # every trace from another buffer (same rays)
 flags = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 parts, rays = getattr(scenes, workload)(scenes.product_api(), n)
 ds = engine.DeviceScene(SceneSnapshot(parts))
 dev = torch.from_numpy(rays).cuda()
-keys = ("dense_launches", "sparse_keep_launches", "tile_record_launches", "tile_record_misses", "speculation_misses")
+keys = ("dense_launches", "sparse_keep_launches", "speculation_misses")
 before = ds.telemetry()
 for k in range(reps):
     torch.cuda.synchronize()

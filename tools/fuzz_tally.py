@@ -1,5 +1,5 @@
-"""How often the random benches of tests/test_gpu_fuzz.py run a generation dense with its absorbed rays kept (hint mode 4),
-on a per-tile record, or dense:  python tools/fuzz_tally.py [first] [count]"""
+"""How often the random benches of tests/test_gpu_fuzz.py run a generation dense with its absorbed rays kept (hint mode 4)
+or dense:  python tools/fuzz_tally.py [first] [count]"""
 import sys, collections
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +13,6 @@ def closing(self):
     tally["scenes"] += 1
     tally["scenes_with_keep"] += told["sparse_keep_launches"] > 0
     tally["keep_launches"] += told["sparse_keep_launches"]
-    tally["record_launches"] += told["tile_record_launches"]
     tally["dense_launches"] += told["dense_launches"]
     close(self)
 engine.DeviceScene.close = closing
