@@ -212,3 +212,82 @@ def test_random_scene_traced_again_from_the_same_buffers(seed):
         assert counts == want_counts, (seed, "changed", k)
         helpers.assert_frames_match(rows.cpu().numpy().T, want, what=f"seed {seed} changed pass {k}")
     ds.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# record plans (round 6): the PLAN instantiations of the generation kernel on the fuzz scenes -- a filtered trace
+# must be the full trace's frame filtered, BIT FOR BIT (same arithmetic, other stores), the fused sums those of the
+# frame oracle on it; repeated, so that the plan's own dense-mode hints (and their kept-absorbed-rays form) run too
+# ---------------------------------------------------------------------------------------------
+def _check_plans(ds, device_rays, limit, rng, seed):
+    from oracle import frame_oracle
+    from pyrayt_amd import engine
+
+    if engine.DEFAULT_TRACE_FLAGS & (engine.TRACE_UNFUSED | engine.TRACE_COUNT_PATHS):
+        pytest.skip("record plans need the fused path")
+
+    full, full_counts = ds.trace(device_rays, limit, plan=None)
+    full = full.clone()
+    frame = full.cpu().numpy()
+    ids = np.unique(frame[5]).astype(np.int64) if frame.shape[1] else np.array([7], dtype=np.int64)
+    picks = [tuple(int(v) for v in rng.choice(ids, size=min(len(ids), int(rng.integers(1, 4))), replace=False)), ()]
+    n = device_rays.shape[1]
+    for surfaces in picks:
+        keep = np.isin(frame[5].astype(np.int64), surfaces) if surfaces else np.ones(frame.shape[1], dtype=bool)
+        want = frame[:, keep]
+        rps, groups = (max(n // 3, 1), 4) if seed % 2 else (None, 1)
+        for rows_on in (True, False):
+            if not rows_on and not surfaces and seed % 4:
+                continue
+            plan = engine.RecordPlan(surfaces=surfaces, rows=rows_on, stats=True, rays_per_source=rps, n_groups=groups,
+                                     mean_square=("y1", 0.125, None), generation_limit=limit)
+            for turn in range(3):
+                rows, counts = ds.trace(device_rays, limit, plan=plan)
+                torch.cuda.synchronize()
+                if rows_on:
+                    assert np.array_equal(rows.cpu().numpy(), want, equal_nan=True), (seed, surfaces, turn)
+                    assert sum(counts) == want.shape[1]
+                else:
+                    assert rows.shape[1] == 0
+                got = plan.sums.cpu().numpy()
+                # (rows with a NaN in a summed column poison that sum, in the oracle as in the kernel: compared as such)
+                for g in range(limit):
+                    ref = frame_oracle.reduce_sums(want, None, float(g), rps, groups)
+                    ok = np.isclose(got[g, :, :9], ref, rtol=1e-10, atol=1e-9, equal_nan=True) | ~np.isfinite(ref)
+                    assert ok.all(), (seed, surfaces, rows_on, turn, g, got[g, :, :9], ref)
+    rows, counts = ds.trace(device_rays, limit, plan=None)
+    assert counts == full_counts and np.array_equal(rows.cpu().numpy(), frame, equal_nan=True), seed
+
+
+@pytest.mark.parametrize("seed", list(_seeds())[::4])
+def test_random_scene_under_record_plans(seed):
+    from pyrayt_amd.engine import DeviceScene
+    from pyrayt_amd.scene import SceneSnapshot
+
+    parts, rays, rng, short, odd = build_random_scene(seed)
+    rays = np.ascontiguousarray(rays[:, : int(rng.choice([700, 4096, 20_000]))])
+    ds = DeviceScene(SceneSnapshot(parts))
+    _check_plans(ds, torch.from_numpy(rays).to("cuda:0"), 6, rng, seed)
+    ds.close()
+
+
+@pytest.mark.parametrize("seed", list(_seeds())[::4])
+def test_random_bench_under_record_plans(seed):
+    from pyrayt_amd.engine import DeviceScene
+    from pyrayt_amd.g3d.objects import CountedObject
+    from pyrayt_amd.scene import SceneSnapshot
+
+    api = scenes.product_api()
+    rng = np.random.default_rng(99_000 + seed)
+    CountedObject.reset_ids()
+    parts, x = [], 0.0
+    for _ in range(int(rng.integers(1, 6))):
+        parts.append(random_part(rng, api.components, api.materials).move_x(x))
+        x += float(rng.uniform(0.5, 1.8))
+    parts.append(api.components.baffle((3.0, 3.0)).move_x(x + 0.5))
+    n = int(rng.choice([3_000, 20_000]))
+    rays = scenes.cone_rays(n, (-1.5, 0.0, 0.0), float(rng.uniform(2.0, 12.0)), 8000 + seed,
+                            wavelength=float(rng.uniform(0.45, 0.7)))
+    ds = DeviceScene(SceneSnapshot(parts))
+    _check_plans(ds, torch.from_numpy(rays).to("cuda:0"), int(rng.integers(3, 10)), rng, seed)
+    ds.close()

@@ -18,7 +18,9 @@ from oracle import frame_oracle
 from pyrayt_amd import engine
 from pyrayt_amd.frame import DeviceFrame, SinkStats
 
-pytestmark = pytest.mark.gpu
+# (tools/run_matrix.sh runs the suites under every trace flag: a plan's traces run on the fused path only)
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(bool(engine.DEFAULT_TRACE_FLAGS & (engine.TRACE_UNFUSED | engine.TRACE_COUNT_PATHS)),
+                                                  reason="record plans need the fused path")]
 
 torch = pytest.importorskip("torch")
 
