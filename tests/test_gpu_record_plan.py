@@ -230,7 +230,8 @@ def test_sums_only_plan_at_the_north_star_size_runs_dense_and_matches_the_refere
         assert np.allclose(got[column].to_numpy(), want[column].to_numpy(), rtol=1e-9, atol=1e-12, equal_nan=True), column
     after = ds.telemetry()
     # 10 traces x 3 generations under the plan, of which only the very first trace's ran without hints
-    assert after["plan_dense_launches"] - before["plan_dense_launches"] >= 27
+    if not engine.DEFAULT_TRACE_FLAGS & engine.TRACE_NO_HINTS:   # (tools/run_matrix.sh also runs this suite without hints)
+        assert after["plan_dense_launches"] - before["plan_dense_launches"] >= 27
     ds.close()
 
 

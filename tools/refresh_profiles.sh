@@ -41,6 +41,9 @@ cp gpurun_out/traffic/bench_FETCH_SIZE_counter_collection.csv $out/k_generation_
 cp gpurun_out/traffic/bench_WRITE_SIZE_counter_collection.csv $out/k_generation_pmc_WRITE_SIZE.csv
 cp gpurun_out/traffic/cal_FETCH_SIZE_counter_collection.csv $out/calibration_pmc_FETCH_SIZE.csv
 cp gpurun_out/traffic/cal_WRITE_SIZE_counter_collection.csv $out/calibration_pmc_WRITE_SIZE.csv
+# round 6: what a record plan buys (rows of the detector only / sums only) and the design loop it is for
+python3 tools/plan_bench.py 2>&1 | grep -v amdgpu.ids > $out/plan_bench.txt
+python3 tools/design_loop.py 2>&1 | grep -v amdgpu.ids > $out/design_loop.txt
 python3 tools/shard_scaling.py > $out/shard_scaling.txt 2>&1
 { echo; python3 tools/c_host_bench.py 2>&1 | grep -v amdgpu.ids; } >> $out/shard_scaling.txt
 python3 tools/slow_paths.py 2>&1 | grep -v amdgpu.ids > $out/slow_paths.txt
