@@ -232,3 +232,59 @@ def test_binding_constants_are_the_headers():
     errors = {name: int(value) for name, value in re.findall(r"#define PRT_ERR_([A-Z_]+) \((-\d+)\)", header)}
     for name in ("ROWS_CAP", "UNTRACABLE", "WAVELENGTH"):
         assert getattr(engine, "ERR_" + name) == errors[name], name
+
+
+def test_binding_structs_have_the_layout_of_the_header(tmp_path):
+    """The numpy record types the binding hands to the library (scene options, trace jobs, record plans, sources, cameras)
+    against the C structs of include/prt.h: size and the offset of every field, read off a program gcc compiles from the
+    header itself."""
+    import shutil
+    import subprocess
+
+    from pyrayt_amd import engine
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    structs = {
+        "prt_scene_options": (engine.OPTIONS_DTYPE, ["struct_size", "no_chain", "hit_lanes", "no_clearance", "reserved"]),
+        "prt_trace_job": (engine.JOB_DTYPE, None),
+        "prt_record_plan": (engine.PLAN_DTYPE, ["struct_size", "n_surfaces", "store_rows", "n_groups", "surfaces", "rays_per_source",
+                                                "sums_out", "pivots", "ms_quantity", "ms_transform", "ms_about",
+                                                "generation_limit", "reserved"]),
+        "prt_camera": (engine.CAMERA_DTYPE, ["world", "h_pixels", "v_pixels", "h_width", "v_width"]),
+    }
+    lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{os.path.join(ROOT, "include", "prt.h")}"', "int main(void) {"]
+    for name, (dtype, fields) in structs.items():
+        lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
+        for field in fields or ():
+            lines.append(f'  printf("{name}.{field} %zu\\n", offsetof({name}, {field}));')
+    lines += ["  return 0;", "}"]
+    source = tmp_path / "layout.c"
+    source.write_text("\n".join(lines))
+    binary = tmp_path / "layout"
+    subprocess.run(["gcc", "-o", str(binary), str(source)], check=True, capture_output=True)
+    got = dict(line.split() for line in subprocess.run([str(binary)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, (dtype, fields) in structs.items():
+        assert int(got[name]) == dtype.itemsize, (name, got[name], dtype.itemsize)
+        for field in fields or ():
+            assert int(got[f"{name}.{field}"]) == dtype.fields[field][1], (name, field)
+
+
+def test_scene_objects_count_their_changes():
+    """g3d.objects.SceneEpoch moves on every attribute assignment of a scene object -- a transform, a material, a normal
+    flip, a source's wavelength -- and stands still otherwise: what RayTracer keys its compiled scene and its generated
+    rays on (the GPU side of that is tests/test_gpu_parity.py::test_raytracer_looks_at_its_system_again_...)."""
+    import pyrayt_amd as pyrayt
+    from pyrayt_amd.g3d.objects import SceneEpoch
+
+    lens = pyrayt.components.biconvex_lens(2, 2, 0.25, aperture=1)
+    source = pyrayt.components.ConeOfRays(cone_angle=6)
+    plate = pyrayt.components.baffle((1, 1))
+    seen = SceneEpoch.value
+    lens.get_world_transform(); plate.bounding_box; source.wavelength; lens.surface_ids    # reads do not count
+    assert SceneEpoch.value == seen
+    for change in (lambda: lens.move_x(0.1), lambda: plate.rotate_z(3), lambda: setattr(plate, "material", pyrayt.materials.mirror),
+                   plate.invert_normals, lambda: setattr(source, "wavelength", 0.5), lambda: source.move_x(-1)):
+        change()
+        assert SceneEpoch.value > seen
+        seen = SceneEpoch.value
