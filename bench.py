@@ -84,13 +84,13 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 COPY_GBS = 6300.0               # what a bare copy with the kernel's row pattern reaches (tools/ubench/copy_f64: 5.7-6.4 TB/s)
 
 
-# What one rank does at the shard sizes of the 1/2/4/8 curve, measured on ONE MI355X (profiles/r5/shard_scaling.txt:
+# What one rank does at the shard sizes of the 1/2/4/8 curve, measured on ONE MI355X (profiles/r6/shard_scaling.txt:
 # config 2, the library's own loop with 2-4 traces in flight, and one blocking prt_trace at a time) -- the stated
 # expectation a first multi-GPU record can be read against (no N > 1 run has happened on hardware yet).
-SHARD_MS_PER_STEP = {1_000_000: {"overlapped": 0.1353, "synchronous": 0.1795},
-                     500_000: {"overlapped": 0.0711, "synchronous": 0.1141},
-                     250_000: {"overlapped": 0.0385, "synchronous": 0.0802},
-                     125_000: {"overlapped": 0.0241, "synchronous": 0.0650}}
+SHARD_MS_PER_STEP = {1_000_000: {"overlapped": 0.1357, "synchronous": 0.1760},
+                     500_000: {"overlapped": 0.0705, "synchronous": 0.1155},
+                     250_000: {"overlapped": 0.0393, "synchronous": 0.0777},
+                     125_000: {"overlapped": 0.0232, "synchronous": 0.0623}}
 XGMI_LINK_GBS, XGMI_LINKS = 153.0, 7  # 7 links x ~153 GB/s per GPU (~76 per direction if that figure is bidirectional)
 
 
@@ -102,7 +102,7 @@ def scaling_model(n_job, world, rows_per_step):
     sizes = sorted(SHARD_MS_PER_STEP)
     lo = max([k for k in sizes if k <= shard] or [sizes[0]])
     hi = min([k for k in sizes if k >= shard] or [sizes[-1]])
-    model = {"shard_rays": shard, "from": "profiles/r5/shard_scaling.txt (one GPU tracing a rank's shard; config 2)"}
+    model = {"shard_rays": shard, "from": "profiles/r6/shard_scaling.txt (one GPU tracing a rank's shard; config 2)"}
     for mode in ("overlapped", "synchronous"):
         a, b = SHARD_MS_PER_STEP[lo][mode], SHARD_MS_PER_STEP[hi][mode]
         ms = a if hi == lo else a + (b - a) * (shard - lo) / (hi - lo)
@@ -119,7 +119,7 @@ def scaling_model(n_job, world, rows_per_step):
                                "region) is what the model's `overlapped` line predicts; value_with_gather adds this"}
     model["note"] = ("strong scaling of one 1M-ray job: at N = 8 a rank's shard is 125k rays, less than one round of workgroups "
                      "(1280 x 256 rays resident), so a step is a chain of three launches each about as long as one wave lives; "
-                     "the expectation is ~5.6x at N = 8 with four chains in flight, ~2.7x on one stream")
+                     "the expectation is ~5.8x at N = 8 with four chains in flight, ~2.8x with one blocking trace at a time")
     return model
 
 
