@@ -436,6 +436,60 @@ def test_sharded_group_stats_on_the_gpu(tmp_path, name, n, rays_per_source, worl
         assert np.allclose(got_ms, want_ms, rtol=1e-10, atol=1e-300, equal_nan=True), (rank, got_ms, want_ms)
 
 
+def _plan_worker(rank, world, port, n, result_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pyrayt_amd as pyrayt
+
+        torch.cuda.set_device(0)
+        pyrayt.g3d.objects.CountedObject.reset_ids()
+        lens = pyrayt.components.biconvex_lens(2, 2, 0.25, aperture=1)
+        sources = [pyrayt.components.ConeOfRays(cone_angle=6, wavelength=w).move_x(-1.9) for w in (0.5, 0.633)]
+        det = pyrayt.components.baffle((1, 1)).move_x(1)
+        tracer = pyrayt.RayTracer(sources, [lens, det], rays_per_source=n)          # the world group, gather "all"
+        stats = tracer.trace_stats(surface=det, rays_per_source=True, mean_square=("axis_intercept", 1.0, None))
+        table = stats.group_stats("last")
+        np.save(os.path.join(result_dir, f"table_{rank}.npy"), table.to_numpy(dtype=float))
+        np.save(os.path.join(result_dir, f"ms_{rank}.npy"), stats.mean_square(None, per_source=True).to_numpy(dtype=float))
+        tracer.record_only(det)
+        frame = tracer.trace()                                                        # every rank: the whole cut
+        np.save(os.path.join(result_dir, f"rows_{rank}.npy"), frame.to_numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_record_plans_of_a_sharded_tracer(tmp_path, world):
+    """RayTracer.trace_stats / record_only with the rays sharded over ranks (gloo, sharing the one GPU): the sums of the
+    shards add up to the single-rank tables, and the filtered frames re-assemble to the single-rank cut."""
+    import torch.multiprocessing as mp
+
+    import pyrayt_amd as pyrayt
+
+    n = 6007
+    mp.start_processes(_plan_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    pyrayt.g3d.objects.CountedObject.reset_ids()
+    lens = pyrayt.components.biconvex_lens(2, 2, 0.25, aperture=1)
+    sources = [pyrayt.components.ConeOfRays(cone_angle=6, wavelength=w).move_x(-1.9) for w in (0.5, 0.633)]
+    det = pyrayt.components.baffle((1, 1)).move_x(1)
+    tracer = pyrayt.RayTracer(sources, [lens, det], rays_per_source=n)
+    whole = tracer.trace()
+    frame = tracer.device_frame
+    want_table = frame.group_stats(surface=det.get_id(), generation=frame.last_generation_number(), rays_per_source=n,
+                                   n_groups=2).to_numpy(dtype=float)
+    want_ms = frame.mean_square("axis_intercept", about=1.0, surface=det.get_id(), rays_per_source=n,
+                                n_groups=2).to_numpy(dtype=float)
+    want_rows = whole.loc[whole["surface"] == det.get_id()].to_numpy()
+    for rank in range(world):
+        assert np.allclose(np.load(tmp_path / f"table_{rank}.npy"), want_table, rtol=1e-9, atol=1e-12, equal_nan=True), rank
+        assert np.allclose(np.load(tmp_path / f"ms_{rank}.npy"), want_ms, rtol=1e-10, atol=1e-300, equal_nan=True), rank
+        assert np.array_equal(np.load(tmp_path / f"rows_{rank}.npy"), want_rows, equal_nan=True), rank
+
+
 def test_sharded_group_stats_over_a_one_rank_rccl_communicator():
     """prt_frame_stats_sharded itself (two ncclAllReduce inside the library) with the one rank a 1-GPU box allows."""
     from pyrayt_amd import distributed as pdist
