@@ -1004,6 +1004,19 @@ static size_t scene_image(const prt_scene* s, char* write, std::vector<size_t>* 
   return pos;
 }
 
+// what a ticket needs on the host side, made when the ticket traces for the first time (most scenes only ever use
+// ticket 0, and a scene's first trace should not pay for four)
+static int ticket_resources(TraceTicket& t) {
+  if (t.mirror) return PRT_OK;
+  HIP_TRY(hipHostMalloc((void**)&t.host_pinned, 16 * sizeof(int64_t), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&t.mirror, 64 + (kMaxBatch + 4) * 64, hipHostMallocMapped | hipHostMallocCoherent));  // header + GenCtrl slots of 64 B
+  std::memset((void*)t.mirror, 0, 64 + (kMaxBatch + 4) * 64);
+  HIP_TRY(hipHostGetDevicePointer((void**)&t.mirror_dev, (void*)t.mirror, 0));
+  HIP_TRY(hipEventCreate(&t.ev0));
+  HIP_TRY(hipEventCreate(&t.ev1));
+  return PRT_OK;
+}
+
 // give back whatever a device copy holds (the device is current)
 static void release_device_copy(DeviceCopy& c) {
   (void)hipFree(c.block);  // (prims, trace_code, trace_component_first, render_code, component_code[] point into it)
@@ -1151,6 +1164,13 @@ extern "C" int prt_scene_update(prt_scene* s, const prt_prim* prims, int n_prims
     // Entry points outside the ticket runtime (prt_propagate, the renderers ...) are not tracked stream by stream: if
     // one of them used the tables since the last update, or the scene has index tables to re-apply, the device is
     // synchronised first, as it always was.
+    if (!c.staging) {  // the first update of this device copy
+      HIP_TRY(hipHostMalloc((void**)&c.staging, c.block_bytes, hipHostMallocDefault));
+      std::memset(c.staging, 0, c.block_bytes);
+      HIP_TRY(hipStreamCreateWithFlags(&c.update_stream, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&c.update_event, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&c.tail_event, hipEventDisableTiming));
+    }
     if (c.update_unsettled) {  // (the previous update's copy reads the staging memory written below: long done as a rule)
       if (hipEventQuery(c.update_event) != hipSuccess) {
         (void)hipGetLastError();
@@ -1253,26 +1273,19 @@ static int on_device(prt_scene* s, int device, DeviceCopy** out, bool tracked = 
     std::vector<size_t> at;
     c.block_bytes = scene_image(s, nullptr, &at);
     HIP_TRY(hipMalloc((void**)&c.block, c.block_bytes));
-    HIP_TRY(hipHostMalloc((void**)&c.staging, c.block_bytes, hipHostMallocDefault));
-    std::memset(c.staging, 0, c.block_bytes);
-    scene_image(s, c.staging, nullptr);
-    HIP_TRY(hipMemcpy(c.block, c.staging, c.block_bytes, hipMemcpyHostToDevice));
+    {
+      // (the pinned image, the stream and the events of prt_scene_update are made by the first update: a scene that is
+      // never updated -- and a scene's first trace -- does not pay for them)
+      std::vector<char> image(c.block_bytes, 0);
+      scene_image(s, image.data(), nullptr);
+      HIP_TRY(hipMemcpy(c.block, image.data(), c.block_bytes, hipMemcpyHostToDevice));
+    }
     c.prims = (DevPrim*)(c.block + at[0]);
     c.trace_code = (DevInstr*)(c.block + at[1]);
     c.trace_component_first = (int32_t*)(c.block + at[2]);
     c.render_code = (DevInstr*)(c.block + at[3]);
     for (size_t k = 0; k < s->component_programs.size(); ++k) c.component_code.push_back((DevInstr*)(c.block + at[4 + k]));
-    HIP_TRY(hipStreamCreateWithFlags(&c.update_stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&c.update_event, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c.tail_event, hipEventDisableTiming));
-    for (TraceTicket& t : c.ticket) {
-      HIP_TRY(hipHostMalloc((void**)&t.host_pinned, 16 * sizeof(int64_t), hipHostMallocDefault));
-      HIP_TRY(hipHostMalloc((void**)&t.mirror, 64 + (kMaxBatch + 4) * 64, hipHostMallocMapped | hipHostMallocCoherent));  // header + GenCtrl slots of 64 B
-      std::memset((void*)t.mirror, 0, 64 + (kMaxBatch + 4) * 64);
-      HIP_TRY(hipHostGetDevicePointer((void**)&t.mirror_dev, (void*)t.mirror, 0));
-      HIP_TRY(hipEventCreate(&t.ev0));
-      HIP_TRY(hipEventCreate(&t.ev1));
-    }
+    // (a ticket's pinned staging, host mirror and events are made when it is first used: ticket_resources)
     int rc_lds = raise_lds_limits();
     if (rc_lds) return rc_lds;
     rc = apply_tables(s, c);

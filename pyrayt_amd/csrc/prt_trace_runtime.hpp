@@ -687,6 +687,8 @@ extern "C" int prt_trace_begin(prt_scene* s, int device, int ticket, const doubl
     if (k != ticket && c->ticket[k].active && n && c->ticket[k].n &&
         (c->ticket[k].w == (char*)workspace || c->ticket[k].rows_out == rows_out))
       return fail(PRT_ERR_ARG, "traces in flight together need their own workspace and record block");
+  rc = ticket_resources(*t);
+  if (rc) return rc;
   rc = settle_timing(t);  // events of the ticket's previous trace, before they are recorded again
   if (rc) return rc;
   t->rays = rays; t->n = n; t->ld = ld; t->limit = generation_limit; t->ray_offset = ray_offset;
