@@ -11,12 +11,19 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
+from .._epoch import SceneEpoch
 from . import color
 from .color import RGBAColor
 
 
 class Material(abc.ABC):
-    """Anything a renderer can ask for pixel colours."""
+    """Anything a renderer can ask for pixel colours.  Assigning to an attribute of a material -- a refractive index, a
+    Sellmeier coefficient, a colour -- moves the scene objects' change counter (``g3d._epoch.SceneEpoch``), like moving a
+    part does: a ``RayTracer`` that holds a compiled copy of a system using the material looks at it again."""
+
+    def __setattr__(self, name, value):
+        object.__setattr__(self, name, value)
+        SceneEpoch.value += 1
 
     @abc.abstractmethod
     def shade(self, rays, normals, light_positions):

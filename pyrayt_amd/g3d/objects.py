@@ -15,6 +15,7 @@ from itertools import count
 import numpy as np
 
 from . import shapes
+from ._epoch import SceneEpoch  # noqa: F401  (the scene objects' change counter; re-exported)
 from .materials import gooch
 
 _UNITS = {"deg": np.pi / 180.0, "rad": 1.0}
@@ -38,19 +39,6 @@ class CountedObject:
         """Restart the global counter (test / fixture helper; the reference restarts it only
         by starting a fresh interpreter)."""
         CountedObject._ids = count(start)
-
-
-class SceneEpoch:
-    """A process-wide counter that moves whenever an attribute of any scene object is assigned -- a transform applied
-    (``_append_world_transform`` assigns the matrices), a material or a normal sign changed, a wavelength set.  What
-    holds a compiled copy of a scene (``RayTracer``: the device scene of its components, the ray set of its sources)
-    remembers the value it was compiled at and looks at the objects again only when it has moved: a design loop that
-    calls ``trace()`` on an unchanged system pays nothing for it, one that moved a part re-snapshots as ever.  Not
-    seen: arrays edited in place (``part._world[0, 3] += 1`` -- upstream's own caches, the inverse matrix and the CSG
-    cull boxes, would be stale as well) and the insides of a user's material object (such systems are looked at
-    again on every trace); ``RayTracer.invalidate()`` is the way out for anything of that kind."""
-
-    value = 0
 
 
 class WorldObject(CountedObject):

@@ -11,6 +11,8 @@ import itertools
 
 import numpy as np
 
+from ._epoch import SceneEpoch
+
 # kind codes, must match include/prt.h PRT_PRIM_*
 SPHERE, CYLINDER, PLANE, CUBE, PARABOLOID = range(5)
 
@@ -121,6 +123,10 @@ class Shape:
     """kind + params + object-space bounds of one primitive."""
 
     kind = -1
+
+    def __setattr__(self, name, value):  # (a shape's parameters are scene data: assigning them counts as a change)
+        object.__setattr__(self, name, value)
+        SceneEpoch.value += 1
 
     def __init__(self, params, lo, hi):
         self.params = tuple(float(p) for p in params)

@@ -283,8 +283,12 @@ def test_scene_objects_count_their_changes():
     seen = SceneEpoch.value
     lens.get_world_transform(); plate.bounding_box; source.wavelength; lens.surface_ids    # reads do not count
     assert SceneEpoch.value == seen
+    glass = pyrayt.materials.BasicRefractor(1.5)
+    ball = pyrayt.g3d.Sphere(1, material=glass)
     for change in (lambda: lens.move_x(0.1), lambda: plate.rotate_z(3), lambda: setattr(plate, "material", pyrayt.materials.mirror),
-                   plate.invert_normals, lambda: setattr(source, "wavelength", 0.5), lambda: source.move_x(-1)):
+                   plate.invert_normals, lambda: setattr(source, "wavelength", 0.5), lambda: source.move_x(-1),
+                   lambda: setattr(glass, "_refractive_index", 1.6),                   # a material's own numbers
+                   lambda: setattr(ball.primitive, "params", (2.0,))):                  # a shape's parameters
         change()
         assert SceneEpoch.value > seen
         seen = SceneEpoch.value
