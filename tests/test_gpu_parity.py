@@ -685,6 +685,15 @@ def test_raytracer_looks_at_its_system_again_only_when_something_was_assigned():
         assert same(tracer.trace(), fresh()) and not same(tracer.get_results(), before)
     finally:
         scene_module.SceneSnapshot.__init__ = original
+    # a material's own numbers edited in place count as well (Material.__setattr__): no trace with the old index
+    own = pyrayt.materials.BasicRefractor(1.5)
+    lens_b = pyrayt.components.biconvex_lens(2, 2, 0.25, aperture=1, material=own)
+    tracer_b = pyrayt.RayTracer(src, [lens_b, det], rays_per_source=5_000)
+    before = tracer_b.trace()
+    own._refractive_index = 1.62
+    after = tracer_b.trace()
+    want = pyrayt.RayTracer(src, [lens_b, det], rays_per_source=5_000).trace()
+    assert same(after, want) and not same(after, before)
 
 
 def test_scene_updates_are_ordered_between_the_traces_around_them():
