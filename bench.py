@@ -948,6 +948,23 @@ def main():
                 del frame, r2, up
             end_to_end = {"ms": min(times[1:]) * 1e3, "rows_per_s": n_rows / min(times[1:]),
                           "first_call_ms": times[0] * 1e3}
+            if args.workload == "config2" and args.flags == 0:
+                # ... and what the notebook's `results.loc[results['surface'] == imager.get_id()]` costs end to end when
+                # the cut is made by the generation kernels (a record plan: the other rows are never written, never copied)
+                detector_plan = engine.RecordPlan(surfaces=(int(snap.prims["surface_id"][-1]),), rows=True, generation_limit=limit)
+                times = []
+                for _ in range(3):
+                    torch.cuda.synchronize(device)
+                    e0 = time.perf_counter()
+                    up = torch.from_numpy(rays).to(device)
+                    r2, _ = scene.trace(up, limit, flags=args.flags, plan=detector_plan)
+                    frame = rows_to_frame(r2)
+                    times.append(time.perf_counter() - e0)
+                    kept_rows = frame.shape[0]
+                    del frame, r2, up
+                scene.set_plan(0, None, device)
+                end_to_end["detector_rows_only_ms"] = min(times[1:]) * 1e3
+                end_to_end["detector_rows"] = kept_rows
         except Exception as exc:  # noqa: BLE001
             end_to_end = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
