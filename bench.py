@@ -962,9 +962,23 @@ def main():
                     times.append(time.perf_counter() - e0)
                     kept_rows = frame.shape[0]
                     del frame, r2, up
-                scene.set_plan(0, None, device)
                 end_to_end["detector_rows_only_ms"] = min(times[1:]) * 1e3
                 end_to_end["detector_rows"] = kept_rows
+                # ... and the spot diagram of cells 11 / 19: two columns (y1, z1) of those rows
+                from pyrayt_amd.frame import DeviceFrame
+
+                spot_plan = engine.RecordPlan(surfaces=detector_plan.surfaces, rows=True, columns=("y1", "z1"), generation_limit=limit)
+                times = []
+                for _ in range(3):
+                    torch.cuda.synchronize(device)
+                    e0 = time.perf_counter()
+                    up = torch.from_numpy(rays).to(device)
+                    r2, c2 = scene.trace(up, limit, flags=args.flags, plan=spot_plan)
+                    frame = DeviceFrame(r2, c2, spot_plan.columns).to_pandas()
+                    times.append(time.perf_counter() - e0)
+                    del frame, r2, up
+                scene.set_plan(0, None, device)
+                end_to_end["detector_spot_columns_ms"] = min(times[1:]) * 1e3
         except Exception as exc:  # noqa: BLE001
             end_to_end = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 

@@ -398,7 +398,8 @@ int prt_trace_batch_busy(const prt_scene* scene, int device, double* out4);
  *   n_surfaces > 0    only rows whose surface id is one of surfaces[] pass (0: the rows of every surface pass);
  *   store_rows        the rows that pass are stored in rows_out, generation-major / id-ascending as ever: the frame
  *                     is exactly frame.loc[frame.surface.isin(surfaces)] of the unfiltered trace, and
- *                     rows_per_generation / the return value count the stored rows.  0: nothing is stored at all
+ *                     rows_per_generation / the return value count the stored rows; `columns` picks which of the fifteen
+ *                     columns those rows write (the notebook's spot diagrams look at two).  0: nothing is stored at all
  *                     (rows_out may be NULL, rows_cap 0; the counts are 0) -- the caller wants the sums only;
  *   n_groups > 0      the rows that pass are also summed, per generation and per group (group = floor(id /
  *                     rays_per_source), pyrayt/_pyrayt.py:349-354; rays_per_source <= 0: one group), into
@@ -433,7 +434,9 @@ typedef struct prt_record_plan {
   int32_t ms_quantity, ms_transform;
   double ms_about;
   int32_t generation_limit;
-  int32_t reserved;
+  int32_t columns;         /* which record columns a stored row writes: bit k = column PRT_COL_k; 0 = all fifteen.  A caller
+                              that will look at x1, y1 only -- a spot diagram -- asks for those (0x600): the other rows of the
+                              (15, rows_cap) block are left as they were, and only two columns need to cross PCIe */
 } prt_record_plan;
 int prt_trace_set_plan(prt_scene* scene, int device, int ticket, const prt_record_plan* plan);
 

@@ -494,7 +494,7 @@ struct PlanDev {
   int32_t ms_transform;   // 0 none, 1 sin
   double ms_about;
   int32_t limit;          // generation_limit the sums were sized for
-  int32_t pad;
+  int32_t columns;        // which of the 15 record columns a stored row writes (bit k = PRT_COL_k); 0x7fff: all of them
 };
 typedef const __attribute__((address_space(4))) PlanDev* ConstPlan;
 
@@ -704,25 +704,29 @@ __device__ __forceinline__ bool interact_store_rows(const Shaded& s, const Ray8&
                                                     unsigned next_bytes, double* __restrict__ nxt, int64_t ld_next,
                                                     double* __restrict__ rec, int64_t ld_rows,
                                                     double next_generation, int relaunch, double ray_offset,
-                                                    bool lean = false, double id0 = 0.0, bool record = true) {
-  // (record == false: a PLAN launch whose record plan drops this ray's row -- see PlanDev; the default kernels pass
-  // the constant `true`)
+                                                    bool lean = false, double id0 = 0.0, bool record = true,
+                                                    unsigned columns = 0x7fffu) {
+  // (record == false: a PLAN launch whose record plan drops this ray's row; columns: the columns such a plan wants of
+  // the rows it keeps (uniform) -- see PlanDev.  The default kernels pass the constants `true` and "all fifteen".)
   if (record) {
-  row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_GENERATION * ld_rows, row_bytes, s.generation);
-  row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_INTENSITY * ld_rows, row_bytes, s.intensity);
-  row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_WAVELENGTH * ld_rows, row_bytes, s.wavelength);
-  row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_INDEX * ld_rows, row_bytes, s.index_in);
-  row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_ID * ld_rows, row_bytes, s.id);
-  row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_SURFACE * ld_rows, row_bytes, s.surface_id);
-  row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_X0 * ld_rows, row_bytes, r.ox);
-  row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_Y0 * ld_rows, row_bytes, r.oy);
-  row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_Z0 * ld_rows, row_bytes, r.oz);
-  row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_X1 * ld_rows, row_bytes, s.px);
-  row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_Y1 * ld_rows, row_bytes, s.py);
-  row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_Z1 * ld_rows, row_bytes, s.pz);
-  row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_XTILT * ld_rows, row_bytes, s.tx);
-  row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_YTILT * ld_rows, row_bytes, s.ty);
-  row_store<PRT_STORE_AUX_REC>(rec + PRT_COL_ZTILT * ld_rows, row_bytes, s.tz);
+#define PRT_STORE_COLUMN(col, value) \
+  if (columns & (1u << (col))) row_store<PRT_STORE_AUX_REC>(rec + (col) * ld_rows, row_bytes, (value))
+  PRT_STORE_COLUMN(PRT_COL_GENERATION, s.generation);
+  PRT_STORE_COLUMN(PRT_COL_INTENSITY, s.intensity);
+  PRT_STORE_COLUMN(PRT_COL_WAVELENGTH, s.wavelength);
+  PRT_STORE_COLUMN(PRT_COL_INDEX, s.index_in);
+  PRT_STORE_COLUMN(PRT_COL_ID, s.id);
+  PRT_STORE_COLUMN(PRT_COL_SURFACE, s.surface_id);
+  PRT_STORE_COLUMN(PRT_COL_X0, r.ox);
+  PRT_STORE_COLUMN(PRT_COL_Y0, r.oy);
+  PRT_STORE_COLUMN(PRT_COL_Z0, r.oz);
+  PRT_STORE_COLUMN(PRT_COL_X1, s.px);
+  PRT_STORE_COLUMN(PRT_COL_Y1, s.py);
+  PRT_STORE_COLUMN(PRT_COL_Z1, s.pz);
+  PRT_STORE_COLUMN(PRT_COL_XTILT, s.tx);
+  PRT_STORE_COLUMN(PRT_COL_YTILT, s.ty);
+  PRT_STORE_COLUMN(PRT_COL_ZTILT, s.tz);
+#undef PRT_STORE_COLUMN
   }
   if (carry) {
     double qx = s.px, qy = s.py, qz = s.pz, qw = s.pw;
@@ -1214,7 +1218,8 @@ k_generation(SceneDev scene, const double* __restrict__ rays, int64_t ld, double
   }
   if (!interact_store_rows<COMPACT>(sh, r, carry, (unsigned)live_rank * 8u, (unsigned)carry_rank * 8u,
                                     next + uniform64(excl_carry), ld_next, rows + uniform64(row_base + excl_live),
-                                    ld_rows, next_generation, relaunch, ray_offset, lean_out, id0, PLAN ? stored : true))
+                                    ld_rows, next_generation, relaunch, ray_offset, lean_out, id0, PLAN ? stored : true,
+                                    PLAN ? (unsigned)plan->columns : 0x7fffu))
     atomicExch(&ctrl->error, PRT_ERR_FULL_ROWS);
   if (sh.err) raise_error(&ctrl->error, sh.err);
   if (PLAN) {

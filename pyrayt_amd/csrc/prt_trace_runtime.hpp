@@ -213,6 +213,7 @@ static unsigned long long plan_key_of(const PlanDev& p) {  // what the plan's de
   auto mix = [&](unsigned long long v) { h = (h ^ v) * 1099511628211ull; };
   mix((unsigned long long)p.n_rec);
   mix((unsigned long long)(p.store_rows != 0));
+  // (the columns a stored row writes do not enter: the plan's dense forms are about WHICH rays store a row)
   for (int k = 0; k < p.n_rec; ++k) mix((unsigned long long)(unsigned)p.rec_prims[k]);
   return h | 1ull;
 }
@@ -255,6 +256,7 @@ extern "C" int prt_trace_set_plan(prt_scene* s, int device, int ticket, const pr
   p.ms_transform = plan->ms_transform;
   p.ms_about = plan->ms_about;
   p.limit = plan->generation_limit;
+  p.columns = (plan->columns & 0x7fff) ? (plan->columns & 0x7fff) : 0x7fff;
   // the slotted sums: as many copies as stay under 8 MiB, at most 64, a power of two
   p.slots = 1;
   size_t per_slot = (size_t)p.limit * (size_t)(p.n_groups > 0 ? p.n_groups : 0) * SINK_STATS * sizeof(double);

@@ -67,7 +67,7 @@ def options_record(options=None):
 PLAN_DTYPE = np.dtype(
     [("struct_size", "<i4"), ("n_surfaces", "<i4"), ("store_rows", "<i4"), ("n_groups", "<i4"), ("surfaces", "<i8", (8,)),
      ("rays_per_source", "<f8"), ("sums_out", "<u8"), ("pivots", "<u8"), ("ms_quantity", "<i4"), ("ms_transform", "<i4"),
-     ("ms_about", "<f8"), ("generation_limit", "<i4"), ("reserved", "<i4")])
+     ("ms_about", "<f8"), ("generation_limit", "<i4"), ("columns", "<i4")])
 assert PLAN_DTYPE.itemsize == 128
 SINK_STATS = 12
 AXIS_INTERCEPT = 15  # PRT_FRAME_AXIS_INTERCEPT
@@ -278,9 +278,14 @@ class RecordPlan:
     """
 
     def __init__(self, surfaces=None, rows=True, stats=False, rays_per_source=None, n_groups=None, pivots=None,
-                 mean_square=None, generation_limit=10):
+                 mean_square=None, generation_limit=10, columns=None):
         from .frame import COLUMNS
 
+        # columns: names of the frame columns a stored row writes (None: all fifteen) -- a spot diagram looks at
+        # ("y1", "z1"); the other rows of the record block are left alone and never cross PCIe
+        self.columns = None if columns is None else tuple(sorted({COLUMNS.index(name) for name in columns}))
+        if self.columns is not None and not self.columns:
+            raise ValueError("a record plan that stores rows needs at least one column")
         self.surfaces = tuple(int(s) for s in (surfaces or ()))
         if len(self.surfaces) > 8:
             raise ValueError("a record plan lists at most 8 surfaces")
@@ -301,7 +306,7 @@ class RecordPlan:
 
     def key(self):
         return (self.surfaces, self.rows, self.stats, self.rays_per_source, self.n_groups, self.ms, self.generation_limit,
-                None if self.pivots is None else self.pivots.data_ptr())
+                None if self.pivots is None else self.pivots.data_ptr(), self.columns)
 
     def record(self, torch, device):
         rec = np.zeros(1, dtype=PLAN_DTYPE)
@@ -311,6 +316,7 @@ class RecordPlan:
         rec["store_rows"] = int(self.rows)
         rec["generation_limit"] = self.generation_limit
         rec["ms_quantity"] = -1
+        rec["columns"] = 0 if self.columns is None else sum(1 << k for k in self.columns)
         if self.stats:
             if self.sums is None or self.sums.device != device:
                 self.sums = torch.zeros((self.generation_limit, self.n_groups, SINK_STATS), dtype=torch.float64, device=device)

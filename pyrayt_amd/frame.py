@@ -21,24 +21,37 @@ _INDEX = {name: k for k, name in enumerate(COLUMNS)}
 
 
 class DeviceFrame:
-    def __init__(self, rows, rows_per_generation=None):
-        """rows: (15, R) tensor (device or host), generation-major."""
+    def __init__(self, rows, rows_per_generation=None, columns=None):
+        """rows: (15, R) tensor (device or host), generation-major.  columns: indices of the columns the trace wrote
+        (a record plan with a column list, ``engine.RecordPlan(columns=...)``; None: all fifteen) -- the other rows of
+        the block hold whatever was there and are never handed out."""
         assert rows.shape[0] == len(COLUMNS)
         self.rows = rows
         self.rows_per_generation = list(rows_per_generation or [])
+        self.written = None if columns is None or len(columns) == len(COLUMNS) else tuple(sorted(columns))
 
     # --- shape / access -----------------------------------------------------------------------
-    columns = COLUMNS
+    @property
+    def columns(self):
+        """Names of the columns this frame holds."""
+        return COLUMNS if self.written is None else tuple(COLUMNS[k] for k in self.written)
 
     def __len__(self):
         return int(self.rows.shape[1])
 
     @property
     def shape(self):
-        return (len(self), len(COLUMNS))
+        return (len(self), len(self.columns))
+
+    def _need(self, *names):
+        if self.written is not None:
+            missing = [name for name in names if _INDEX[name] not in self.written]
+            if missing:
+                raise KeyError(f"this frame was recorded without the column(s) {missing} (RecordPlan(columns=...))")
 
     def __getitem__(self, column):
         """One column as a 1-D tensor view (no copy)."""
+        self._need(column)
         return self.rows[_INDEX[column]]
 
     # --- selections ------------------------------------------------------------------------------
@@ -47,7 +60,7 @@ class DeviceFrame:
         if g < len(self.rows_per_generation):
             start = sum(self.rows_per_generation[:g])
             return DeviceFrame(self.rows[:, start:start + self.rows_per_generation[g]],
-                               [0] * g + [self.rows_per_generation[g]])
+                               [0] * g + [self.rows_per_generation[g]], self.written)
         return self.where(generation=g)
 
     def last_generation(self):
@@ -76,10 +89,10 @@ class DeviceFrame:
             mask = m if mask is None else (mask & m)
         if mask is None:
             return self
-        return DeviceFrame(self.rows[:, mask])
+        return DeviceFrame(self.rows[:, mask], None, self.written)
 
     def select(self, mask):
-        return DeviceFrame(self.rows[:, mask])
+        return DeviceFrame(self.rows[:, mask], None, self.written)
 
     # --- reductions the notebook does on the frame -------------------------------------------------
     def group_stats(self, surface=None, generation=None, rays_per_source=None, n_groups=None, group=None, comm=None):
@@ -102,6 +115,7 @@ class DeviceFrame:
         with a group of another backend), once per pass.  Every rank gets the full statistics and the rows stay
         where they are: the alternative, re-assembling the frame, moves 315 MB into every GPU for a 1M-ray trace.
         Collective: every rank of the group calls it, with the same arguments (``n_groups`` included, or None)."""
+        self._need("generation", "surface", "id", "intensity", "wavelength", "x0", "y0", "x_tilt", "y_tilt", "y1", "z1")
         sharded = group is not None or comm is not None
         if rays_per_source:
             if n_groups is None:
@@ -226,6 +240,7 @@ class DeviceFrame:
 
         column = 15 if quantity == "axis_intercept" else _INDEX[quantity]
         how = {None: 0, "sin": 1}[transform]
+        self._need("generation", "surface", "id", *(("x0", "y0", "x_tilt", "y_tilt") if column == 15 else (quantity,)))
         if generation == "last":
             generation = self.last_generation_number()
             if group is not None:
@@ -283,16 +298,19 @@ class DeviceFrame:
 
     # --- export -------------------------------------------------------------------------------------
     def to_numpy(self):
-        """(R, 15) float64 view of a host copy (one D2H transfer)."""
+        """(R, columns) float64 view of a host copy (one D2H transfer; a frame recorded with a column list brings only
+        those columns across)."""
         from . import engine
 
+        if self.written is not None:
+            return engine.to_host(self.rows[list(self.written)]).T  # (the written columns gathered on the device first)
         return engine.to_host(self.rows).T  # a strided view crosses PCIe as it is: no device-side repack
 
     def to_pandas(self):
         values = self.to_numpy()
         if values.shape[0] == 0:
-            return pd.DataFrame(columns=COLUMNS, dtype="float64")
-        return pd.DataFrame(values, columns=COLUMNS, copy=False)
+            return pd.DataFrame(columns=self.columns, dtype="float64")
+        return pd.DataFrame(values, columns=self.columns, copy=False)
 
 
 class SinkStats:

@@ -250,7 +250,7 @@ def test_binding_structs_have_the_layout_of_the_header(tmp_path):
         "prt_trace_job": (engine.JOB_DTYPE, None),
         "prt_record_plan": (engine.PLAN_DTYPE, ["struct_size", "n_surfaces", "store_rows", "n_groups", "surfaces", "rays_per_source",
                                                 "sums_out", "pivots", "ms_quantity", "ms_transform", "ms_about",
-                                                "generation_limit", "reserved"]),
+                                                "generation_limit", "columns"]),
         "prt_camera": (engine.CAMERA_DTYPE, ["world", "h_pixels", "v_pixels", "h_width", "v_width"]),
     }
     lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{os.path.join(ROOT, "include", "prt.h")}"', "int main(void) {"]

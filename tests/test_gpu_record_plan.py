@@ -280,9 +280,54 @@ def test_raytracer_record_only_and_trace_stats():
         assert np.allclose(table[column].to_numpy(), want_table[column].to_numpy(), rtol=1e-9, atol=1e-12, equal_nan=True), column
     # (the highest generation that counted a row of the detector is the frame's last one here)
     assert np.isclose(stats.mean_square("last"), want_ms, rtol=1e-10)
+    tracer.record_only(det, columns=("y1", "z1"))                   # the spot diagram of cells 11 / 19: two columns of the cut
+    spot = tracer.trace()
+    assert list(spot.columns) == ["y1", "z1"] and np.array_equal(spot.to_numpy(), cut[["y1", "z1"]].to_numpy())
     tracer.record_only()
     again = tracer.trace()
     assert again.shape == whole.shape and np.array_equal(again.to_numpy(), whole.to_numpy(), equal_nan=True)
+
+
+@pytest.mark.parametrize("name", ["config2", "config3", "tutorial", "adv_prism"])
+def test_a_column_list_writes_those_columns_and_no_others(name):
+    """RecordPlan(columns=...): the rows a plan keeps write the listed columns only -- equal to the reference frame's,
+    the other rows of the record block untouched (a block filled with a sentinel keeps it) -- with and without a
+    surface filter, and the DeviceFrame hands out, and brings to the host, those columns alone."""
+    fx = helpers.load(f"scene_{name}.npz")
+    limit = int(fx["generation_limit"])
+    frame = fx["frame"]
+    ds = device_scene(helpers.scene_of(fx))
+    rays = dev(fx["rays0"])
+    cap = rays.shape[1] * limit
+    names = ("y1", "z1", "surface")
+    index = [DeviceFrame(torch.zeros((15, 0))).columns.index(c) for c in names]
+    for ids in (surface_choices(frame)[0], ()):
+        want = filtered(frame, ids) if ids else frame
+        plan = engine.RecordPlan(surfaces=ids, rows=True, columns=names, generation_limit=limit)
+        for attempt in range(2):
+            block = torch.full((15, cap), -7.25, dtype=torch.float64, device="cuda:0")
+            rows, counts = ds.trace(rays, limit, out=block, plan=plan)
+            torch.cuda.synchronize()
+            assert rows.shape[1] == want.shape[0] and counts == counts_of(want, limit)
+            got = rows.cpu().numpy()
+            for k in range(15):
+                if k in index:
+                    assert np.array_equal(got[k], want[:, k], equal_nan=True), (name, ids, k)
+                else:
+                    assert np.all(got[k] == -7.25), (name, ids, k)
+            assert torch.all(block[:, rows.shape[1]:] == -7.25)          # nothing behind the rows either
+        view = DeviceFrame(rows, counts, plan.columns)
+        assert view.columns == tuple(sorted(names, key=lambda c: DeviceFrame(torch.zeros((15, 0))).columns.index(c)))
+        table = view.to_pandas()
+        assert list(table.columns) == list(view.columns) and table.shape == (want.shape[0], 3)
+        assert np.array_equal(table["y1"].to_numpy(), want[:, 10], equal_nan=True)
+        with pytest.raises(KeyError):
+            view["x0"]
+        with pytest.raises(KeyError):
+            view.group_stats()
+    rows, counts = ds.trace(rays, limit, plan=None)
+    helpers.assert_frames_match(rows.cpu().numpy().T, frame, what=f"{name} after the column plans")
+    ds.close()
 
 
 def test_plan_arguments_are_checked():
