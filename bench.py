@@ -948,7 +948,7 @@ def main():
                 del frame, r2, up
             end_to_end = {"ms": min(times[1:]) * 1e3, "rows_per_s": n_rows / min(times[1:]),
                           "first_call_ms": times[0] * 1e3}
-            if args.workload == "config2" and args.flags == 0:
+            if args.workload == "config2" and args.flags == 0 and args.side_steps > 0:
                 # ... and what the notebook's `results.loc[results['surface'] == imager.get_id()]` costs end to end when
                 # the cut is made by the generation kernels (a record plan: the other rows are never written, never copied)
                 detector_plan = engine.RecordPlan(surfaces=(int(snap.prims["surface_id"][-1]),), rows=True, generation_limit=limit)

@@ -29,12 +29,11 @@ class DeviceFrame:
         self.rows = rows
         self.rows_per_generation = list(rows_per_generation or [])
         self.written = None if columns is None or len(columns) == len(COLUMNS) else tuple(sorted(columns))
+        if self.written is not None:
+            self.columns = tuple(COLUMNS[k] for k in self.written)  # (names of the columns THIS frame holds)
 
     # --- shape / access -----------------------------------------------------------------------
-    @property
-    def columns(self):
-        """Names of the columns this frame holds."""
-        return COLUMNS if self.written is None else tuple(COLUMNS[k] for k in self.written)
+    columns = COLUMNS
 
     def __len__(self):
         return int(self.rows.shape[1])
