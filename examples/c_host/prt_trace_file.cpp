@@ -3,7 +3,7 @@
  * driven from plain C-style code with the HIP runtime for device memory (what a maintainer binding the
  * library from another language does).
  *
- *   prt_trace_file <scene+rays file> <result file> [depth]
+ *   prt_trace_file <scene+rays file> <result file> [depth [surface id]]
  *
  * Input file (little endian, written by tests/test_gpu_c_host.py from a golden fixture):
  *   int64 header[8] = {magic 0x70727431, n_prims, n_nodes, n_roots, n_materials, n_rays, generation_limit, trace flags}
@@ -12,6 +12,9 @@
  * Result file: int64 total, int64 rows_per_generation[generation_limit], double rows[15][total].
  * depth > 0: the same ray set is traced 2 * depth + 1 times through prt_trace_batch with `depth` traces in flight
  * on as many streams, and every frame must equal the synchronous one bit for bit (exit code 3 otherwise).
+ * surface id (with depth 0): the trace runs under a record plan (prt_trace_set_plan) that stores the rows of that surface
+ * only and sums them in the generation kernels; behind the rows the result file then holds
+ * double sums[generation_limit][PRT_SINK_STATS] (one source group).
  *
  * (Compiled by hipcc as C++ only because the HIP runtime header wants it; nothing below is more than C99.)
  */
@@ -47,6 +50,8 @@ int main(int argc, char** argv) {
     return 2;
   }
   const int depth = argc > 3 ? atoi(argv[3]) : 0;
+  const int with_plan = argc > 4;
+  const long long plan_surface = with_plan ? atoll(argv[4]) : -1;
   FILE* in = fopen(argv[1], "rb");
   if (!in) { perror(argv[1]); return 2; }
   int64_t* header = (int64_t*)read_exact(in, 8 * sizeof(int64_t));
@@ -80,6 +85,25 @@ int main(int argc, char** argv) {
     CHECK_HIP(hipMalloc(&d_work[k], (size_t)prt_trace_workspace_bytes(n)));
   }
   int64_t* counts = (int64_t*)calloc((size_t)(limit > 0 ? limit : 1), sizeof(int64_t));
+  double* d_sums = NULL;
+  const size_t sums_count = (size_t)(limit > 0 ? limit : 1) * PRT_SINK_STATS;
+  if (with_plan) {  /* what the caller keeps, decided in the generation kernel: rows of one surface, and their sums */
+    CHECK_HIP(hipMalloc((void**)&d_sums, sums_count * sizeof(double)));
+    prt_record_plan plan;
+    memset(&plan, 0, sizeof(plan));
+    plan.struct_size = (int32_t)sizeof(plan);
+    plan.n_surfaces = 1;
+    plan.surfaces[0] = plan_surface;
+    plan.store_rows = 1;
+    plan.n_groups = 1;
+    plan.sums_out = d_sums;
+    plan.ms_quantity = -1;
+    plan.generation_limit = limit > 0 ? limit : 1;
+    if (prt_trace_set_plan(scene, 0, 0, &plan) != 0) {
+      fprintf(stderr, "prt_trace_set_plan: %s\n", prt_last_error());
+      return 1;
+    }
+  }
   const int64_t total = prt_trace(scene, 0, d_rays, n, n, limit, 1e-6, d_rows[0], cap, counts, d_work[0],
                                   flags | PRT_TRACE_SYNC, NULL);
   if (total < 0) {
@@ -132,6 +156,13 @@ int main(int argc, char** argv) {
   fwrite(&total, sizeof(total), 1, out);
   fwrite(counts, sizeof(int64_t), (size_t)limit, out);
   fwrite(rows, sizeof(double), (size_t)PRT_RECORD_COLS * (size_t)total, out);
+  if (with_plan) {  /* (PRT_TRACE_SYNC: the fold behind the trace has run) */
+    double* sums = (double*)malloc(sums_count * sizeof(double));
+    CHECK_HIP(hipMemcpy(sums, d_sums, sums_count * sizeof(double), hipMemcpyDeviceToHost));
+    fwrite(sums, sizeof(double), sums_count, out);
+    free(sums);
+    (void)hipFree(d_sums);
+  }
   fclose(out);
   prt_scene_destroy(scene);
   for (int k = 0; k < blocks; ++k) { (void)hipFree(d_rows[k]); (void)hipFree(d_work[k]); }

@@ -54,7 +54,8 @@ def test_the_c_host_builds_and_links_against_the_abi():
     host = build_host()
     assert os.access(host, os.X_OK)
     symbols = subprocess.run(["nm", "-D", "--undefined-only", host], capture_output=True, text=True, check=True).stdout
-    for name in ("prt_scene_create", "prt_trace", "prt_trace_batch", "prt_trace_workspace_bytes", "prt_scene_destroy"):
+    for name in ("prt_scene_create", "prt_trace", "prt_trace_batch", "prt_trace_workspace_bytes", "prt_scene_destroy",
+                 "prt_trace_set_plan"):
         assert name in symbols, name
 
 
@@ -84,3 +85,33 @@ def test_fixture_traced_from_c_equals_the_golden_frame(tmp_path, name, depth):
     assert counts == py_counts
     assert np.array_equal(py_rows.cpu().numpy(), rows, equal_nan=True)
     ds.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["scene_config2.npz", "scene_config3.npz", "scene_mirrors_and_stops.npz"])
+def test_record_plan_set_from_c(tmp_path, name):
+    """prt_trace_set_plan from the torch-free host: the rows of one surface only, and their sums from the generation
+    kernels -- against the reference's frame filtered and the frame oracle's sums of it."""
+    pytest.importorskip("torch")
+    from oracle import frame_oracle
+
+    fx = helpers.load(name)
+    limit = int(fx["generation_limit"])
+    frame = fx["frame"]
+    last = frame[frame[:, 0] == frame[:, 0].max()]
+    ids, counts_of_ids = np.unique(last[:, 5], return_counts=True)
+    surface = int(ids[np.argmax(counts_of_ids)])
+    host = build_host()
+    src, dst = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    write_input(src, helpers.snapshot_of(fx), np.ascontiguousarray(fx["rays0"]), limit)
+    done = subprocess.run([host, src, dst, "0", str(surface)], capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0, done.stderr[-600:]
+    raw = open(dst, "rb").read()
+    total = int(np.frombuffer(raw, dtype="<i8", count=1)[0])
+    rows = np.frombuffer(raw, dtype="<f8", count=15 * total, offset=8 * (1 + limit)).reshape(15, total)
+    sums = np.frombuffer(raw, dtype="<f8", offset=8 * (1 + limit) + 8 * 15 * total).reshape(limit, 12)
+    want = frame[frame[:, 5] == surface]
+    helpers.assert_frames_match(rows.T, want, what=f"{name}: rows of surface {surface} from C")
+    for g in range(limit):
+        ref = frame_oracle.reduce_sums(want.T, None, float(g), None, 1)[0]
+        assert np.allclose(sums[g, :9], ref, rtol=1e-11, atol=1e-12), (name, g)
