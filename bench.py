@@ -775,7 +775,11 @@ def main():
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s"}}
             scene.trace(rays_dev, limit, out=block, plan=None)
             # ... and the loop those plans are for, through the front end (RayTracer on the same system: sources on the
-            # device, the detector's spot size read every iteration; every second figure with the detector moved first)
+            # device, the detector's spot size read every iteration; every second figure with the detector moved first).
+            # One GPU only: under torch.distributed a RayTracer shards its rays and gathers its frames -- collectives
+            # that have no place in a side measurement of a multi-rank run.
+            if distributed:
+                raise StopIteration
             import pyrayt_amd as pyrayt
 
             CountedObject.reset_ids()
@@ -807,6 +811,8 @@ def main():
                 f"RayTracer on the bench's system, {n} rays from a device-side ConeOfRays, the detector's rms spot radius "
                 "read on the host every iteration (tools/design_loop.py): the frame stored and reduced (prt_frame_stats) "
                 "against the sums accumulated in the generation kernels (RayTracer.trace_stats)"))
+        except StopIteration:
+            pass
         except Exception as exc:  # noqa: BLE001
             record_plans = dict(record_plans or {}, error=f"{type(exc).__name__}: {exc}"[:300])
         respin()
