@@ -17,6 +17,8 @@ from .rayset import RaySet
 from .tracer import RayTracer
 from .frame import DeviceFrame
 from .g3d.objects import pin
+from .utils import wavelength_to_rgb
 
-__all__ = ["RayTracer", "RaySet", "DeviceFrame", "pin", "materials", "components", "g3d", "utils"]
+__all__ = ["RayTracer", "RaySet", "DeviceFrame", "pin", "materials", "components", "g3d", "utils",
+           "wavelength_to_rgb"]
 __version__ = "0.1.0"

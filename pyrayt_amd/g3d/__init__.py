@@ -26,6 +26,7 @@ from .objects import (
     XYPlane,
     bounding_box,
 )
+from . import world_objects
 from . import csg
 from . import renderers
 
@@ -33,5 +34,5 @@ __all__ = [
     "BLACK", "CountedObject", "Cuboid", "Cylinder", "HomogeneousCoordinate", "Intersectable", "ObjectGroup",
     "OrthographicCamera", "Paraboloid", "Point", "Ray", "Sphere", "TracerSurface", "Vector", "WorldObject",
     "XYPlane", "binomial_root", "bounding_box", "bundle_of_rays", "bundle_rays", "csg", "element_wise_dot", "materials",
-    "objects", "operations", "primitives", "reflect", "refract", "renderers", "shapes", "smallest_positive_root",
+    "objects", "operations", "primitives", "reflect", "refract", "renderers", "shapes", "smallest_positive_root", "world_objects",
 ]

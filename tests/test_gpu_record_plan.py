@@ -345,3 +345,21 @@ def test_plan_arguments_are_checked():
     rows, counts = ds.trace(rays, 10, plan=None)
     helpers.assert_frames_match(rows.cpu().numpy().T, fx["frame"], what="after the refused plans")
     ds.close()
+
+
+def test_example_best_focus_agrees_with_the_detector_rows():
+    """examples/best_focus.py: a golden-section search on the fused sums lands on a focus whose spot radius is the
+    one the notebook's arithmetic gives on the detector's rows (which are the only rows the last trace kept)."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "best_focus.py")
+    spec = importlib.util.spec_from_file_location("best_focus_example", path)
+    module = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(module)
+    out = module.main(rays=20_000, verbose=False)
+    assert out["surfaces"] == {out["detector"]} and out["rows"] == 20_000
+    assert 45.0 < out["x"] < 115.0
+    assert abs(out["radius"] - out["from_rows"]) <= 1e-9 * max(1.0, out["from_rows"]) + 1e-12
+    # a focus: the spot there is far smaller than the 16 mm line of rays that went in (RMS 4.6 mm)
+    assert out["radius"] < 0.5

@@ -382,3 +382,24 @@ def test_every_compiled_program_passes_the_library_own_walk():
         seen_mirror += info["both_directions"]
         scene.close()
     assert seen_groups > 5 and seen_mirror > 10      # the forms the walk is there for did come up
+
+
+def test_upstream_module_names_resolve():
+    """``tinygfx.g3d.world_objects`` and the 2-D helpers of ``tinygfx.g3d.primitives`` (``primitives.py:163-217,
+    605-618``) exist under their upstream names; values checked against upstream's in this container."""
+    import numpy as np
+
+    import pyrayt_amd
+    from pyrayt_amd.g3d import objects, primitives, world_objects
+
+    assert world_objects.Sphere is objects.Sphere and world_objects.TracerSurface is objects.TracerSurface
+    assert pyrayt_amd.wavelength_to_rgb is pyrayt_amd.utils.wavelength_to_rgb
+    points = np.array([[0.0, 0.6, 0.8, -0.75, 0.2], [0.0, 0.6, 0.0, 0.35, -0.36]])
+    assert primitives.Disk(0.8).point_in_shape(points).tolist() == [True, False, True, False, True]
+    assert primitives.Disk.from_diameter(1.6).point_in_shape(points[:, 2]) == True  # noqa: E712  (on the edge)
+    assert primitives.Rectangle(1.5, 0.7).point_in_shape(points).tolist() == [True, False, False, True, False]
+    assert primitives.Rectangle(1.5, 0.7).point_in_shape(np.array([0.2, 0.3])) is True
+    left, right = primitives.overlap(np.array([1.0, 5, 3, 9]), np.array([4.0, 2, 12, 8]))
+    assert left.tolist() == [5, 3, 9] and right.tolist() == [4, 2, 8]
+    assert primitives.overlap(np.zeros((2, 2)), np.zeros((2, 2))) is None
+    assert issubclass(primitives.Disk, primitives.Shape2D)
