@@ -248,10 +248,12 @@ class TracerSurface(Intersectable):
     """A primitive shape placed in the world, with a material (``world_objects.py:338-422``)."""
 
     shape_type = None
+    surface = None  # upstream's name for the same class attribute (``world_objects.py:339``): either one may be set
 
     def __init__(self, surface_args, material=BLACK, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        self._shape = type(self).shape_type(*surface_args)
+        cls = type(self)
+        self._shape = (cls.shape_type or cls.surface)(*surface_args)
         self.material = material
 
     @property
@@ -278,35 +280,35 @@ class TracerSurface(Intersectable):
 
 
 class Sphere(TracerSurface):
-    shape_type = shapes.SphereShape
+    shape_type = surface = shapes.SphereShape
 
     def __init__(self, radius=1, material=BLACK, *args, **kwargs):
         super().__init__((radius,), material, *args, **kwargs)
 
 
 class Cylinder(TracerSurface):
-    shape_type = shapes.CylinderShape
+    shape_type = surface = shapes.CylinderShape
 
     def __init__(self, radius=1, min_height=-1, max_height=1, material=BLACK, *args, **kwargs):
         super().__init__((radius, min_height, max_height), material, *args, **kwargs)
 
 
 class Paraboloid(TracerSurface):
-    shape_type = shapes.ParaboloidShape
+    shape_type = surface = shapes.ParaboloidShape
 
     def __init__(self, focus=1, height=1, material=BLACK, *args, **kwargs):
         super().__init__((focus, height), material, *args, **kwargs)
 
 
 class XYPlane(TracerSurface):
-    shape_type = shapes.PlaneShape
+    shape_type = surface = shapes.PlaneShape
 
     def __init__(self, width=2, length=2, material=BLACK, *args, **kwargs):
         super().__init__((width, length), material, *args, **kwargs)
 
 
 class Cuboid(TracerSurface):
-    shape_type = shapes.CubeShape
+    shape_type = surface = shapes.CubeShape
 
     def __init__(self, l_corner=(-1, -1, -1), r_corner=(1, 1, 1), material=BLACK, *args, **kwargs):
         super().__init__((l_corner, r_corner), material, *args, **kwargs)
